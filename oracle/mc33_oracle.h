@@ -1,0 +1,46 @@
+/* mc33_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, single-threaded CPU restatement of the reference's calculate_isosurface path
+ * (reference source/marching_cubes_33.c:1816-1889 sweep, :673-1253 MC33_findCase, :347-462
+ * ambiguity tests, :485-585 vertex stores, :628-649 MC33_surfint).  It exists to CHECK the HIP
+ * path; nothing in the product library may include, link or call it.  Pinned against the real
+ * reference built by oracle/Makefile (oracle/_ref) in tests/test_oracle_vs_reference.py and
+ * against the committed fixtures under tests/golden/.
+ */
+#ifndef MC33_ORACLE_H
+#define MC33_ORACLE_H
+#include <stdint.h>
+
+#ifdef MC33_ORACLE_U16
+typedef uint16_t mc33o_sample; /* INTEGER_GRD, GRD_TYPE_SIZE 2 (marching_cubes_33.h:66-75) */
+#else
+typedef float mc33o_sample;    /* default float grid (marching_cubes_33.h:84-85) */
+#endif
+
+typedef struct {
+	uint32_t nV, nT;
+	float *V;    /* nV x 3 */
+	float *N;    /* nV x 3 */
+	uint32_t *T; /* nT x 3 */
+} mc33o_surface;
+
+/* data: contiguous samples, x fastest, then y, then z; np* = POINT counts per axis.
+ * r0/d: origin and spacing (double, as in _GRD).  Returns 0 on success, -1 on allocation failure.
+ * exact_rsqrt is always used for normals (1.0f/sqrtf, marching_cubes_33.c:70-73). */
+int mc33o_calculate_isosurface(const mc33o_sample *data, uint32_t npx, uint32_t npy, uint32_t npz,
+                               const double r0[3], const double d[3], float iso, mc33o_surface *out);
+void mc33o_free_surface(mc33o_surface *s);
+
+/* Per-cell classification only (no geometry): for every cell writes the 8-bit sign index and the
+ * offset of the chosen triangle pattern inside the table (0 for inactive cells).  Arrays have
+ * (npx-1)*(npy-1)*(npz-1) entries, x fastest. */
+int mc33o_classify(const mc33o_sample *data, uint32_t npx, uint32_t npy, uint32_t npz, float iso,
+                   uint8_t *index_out, uint16_t *pattern_out);
+
+/* FNV-1a 64-bit over raw bytes (golden hashes). */
+uint64_t mc33o_fnv1a64(const void *p, uint64_t nbytes);
+
+/* Fill helpers shared by fixtures: cos x + cos y + cos z sampled the way generate_grid_from_fn
+ * does it (accumulated coordinates, MC33_util_grd.c:660-672), libm cos. */
+void mc33o_fill_cos_field(float *data, uint32_t n, double lo, double h);
+#endif
