@@ -1,0 +1,639 @@
+// mc33_cell.h -- per-cell Marching Cubes 33 logic of the MI355X path, written so that every cell
+// can be processed independently of the serial sweep the reference uses.
+//
+// The reference (source/marching_cubes_33.c, "MC:") numbers vertices in the order its z->y->x sweep
+// first creates them and shares ids between neighbouring cells through five rolling 2-D caches
+// (MC:1783-1808).  Here the same numbering is obtained without a sweep:
+//
+//   * every cut grid edge has exactly one OWNER cell - the first cell of the sweep that contains it
+//      - and the owner alone decides what the edge's vertex id is;
+//   * a cell's decision for each of its edges (its "plan") is a pure function of the grid - the 8 corner
+//     values, the boundary flags and a few neighbouring samples: either a NEW vertex, whose id is
+//     (#vertices created by earlier cells) + (rank of first appearance in this cell's pattern walk),
+//     or an ALIAS of another grid edge (only when a corner value equals the isovalue exactly,
+//     MC:788-1224), which is followed to that edge's owner until a NEW vertex is reached.
+//
+// The functions are __host__ __device__: the HIP kernels (mc33_kernels.hip) run them on the GPU, and
+// tests/host_emu builds them with g++ so the formulation can be checked against the oracle on a box
+// without a GPU.  They are NOT a CPU fallback: the product library only calls them from device code.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MC33_HD __host__ __device__ inline
+#else
+#define MC33_HD inline
+#endif
+
+namespace mc33 {
+
+// ---------------------------------------------------------------------------------------------------
+// Problem description shared by all kernels
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t SEG_CELLS = 256;  // cells of one row segment (one wave: 64 lanes x 4 samples)
+constexpr uint32_t NO_ID = 0xFFFFFFFFu;
+
+struct Params {
+	uint32_t nx, ny, nz;  // cells per axis (= _GRD.N, marching_cubes_33.h:113)
+	uint32_t nseg;        // row segments per row = ceil(nx / SEG_CELLS)
+	float iso;
+	float O[3], D[3];     // float copies of r0, d (MC:1779-1782)
+	float ca, cb;         // MC:1773-1774
+	int32_t store_mode;   // 0: MC33_spn0 (MC:485), 1: MC33_spnA (MC:518), 2: MC33_spnB (MC:551)
+};
+
+struct Tables {
+	const uint16_t *lut;        // MC33_all_tables data (mc33_lut_data.h)
+	const uint32_t *rule_words; // mc33_rules_data.h
+	const uint8_t *rule_index;  // [12][4]
+};
+
+template <typename T>
+struct GridView {  // pitched copy of _GRD.F in HBM: sample (x,y,z) at p[z*slice + y*pitch + x]
+	const T *p;
+	uint32_t pitch;
+	uint64_t slice;
+	MC33_HD T at(uint32_t x, uint32_t y, uint32_t z) const { return p[(uint64_t)z * slice + (uint64_t)y * pitch + x]; }
+};
+
+MC33_HD float sample_diff(float a, float b) { return a - b; }
+// unsigned short promotes to int in the reference's expressions (e.g. MC:851); the difference meets
+// a float operand only afterwards
+MC33_HD float sample_diff(uint16_t a, uint16_t b) { return (float)((int)a - (int)b); }
+
+MC33_HD uint32_t sign_of(float f) { return __builtin_bit_cast(uint32_t, f) >> 31; }  // MC:406-408
+
+// per-thread arrays living wherever the caller wants them (the stack on the host, an LDS column on
+// the device so that run-time indexing never turns into scratch memory)
+struct VRef {
+	float *p;
+	int stride;
+	MC33_HD float &operator[](int k) const { return p[k * stride]; }
+};
+struct URef {
+	uint32_t *p;
+	int stride;
+	MC33_HD uint32_t &operator[](int k) const { return p[k * stride]; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Cube geometry (MC:332-341 vertices, MC:660-668 edges), nibble-packed: lookups are shifts
+// ---------------------------------------------------------------------------------------------------
+MC33_HD uint32_t corner_code(uint32_t k) { return (0x57314620u >> (4 * k)) & 7u; }   // k -> dx | dy<<1 | dz<<2
+MC33_HD uint32_t corner_at(uint32_t code) { return (0x62735140u >> (4 * code)) & 7u; }  // inverse
+// edge e: first end point a (t is measured from a: MC:810,847,883,...), second end point b, direction
+MC33_HD uint32_t edge_a(uint32_t e) { return (uint32_t)(0x321047540310ull >> (4 * e)) & 15u; }
+MC33_HD uint32_t edge_b(uint32_t e) { return (uint32_t)(0x765476653221ull >> (4 * e)) & 15u; }
+MC33_HD uint32_t edge_axis(uint32_t e) { return (uint32_t)(0x000021212121ull >> (4 * e)) & 15u; }
+// owner rule: bit0 "only if x==0", bit1 "only if y==0", bit2 "only if z==0"
+// (MC:788, 822, 861, 897, 932, 1044, 1083, 1117, 1190)
+MC33_HD uint32_t edge_own(uint32_t e) { return (uint32_t)(0x204620043115ull >> (4 * e)) & 15u; }
+
+// grid edge (axis, base point) -> its owner cell and the edge's index inside the owner
+struct OwnerRef {
+	uint32_t x, y, z, e;
+};
+MC33_HD OwnerRef owner_of(uint32_t axis, uint32_t px, uint32_t py, uint32_t pz) {
+	OwnerRef o;
+	uint32_t d0, d1;
+	if (axis == 0) {
+		o.x = px; o.y = py ? py - 1 : 0; o.z = pz ? pz - 1 : 0;
+		d0 = py - o.y; d1 = pz - o.z;
+		o.e = d1 ? (d0 ? 10u : 11u) : (d0 ? 9u : 8u);
+	} else if (axis == 1) {
+		o.x = px ? px - 1 : 0; o.y = py; o.z = pz ? pz - 1 : 0;
+		d0 = px - o.x; d1 = pz - o.z;
+		o.e = d0 ? (d1 ? 6u : 4u) : (d1 ? 2u : 0u);
+	} else {
+		o.x = px ? px - 1 : 0; o.y = py ? py - 1 : 0; o.z = pz;
+		d0 = px - o.x; d1 = py - o.y;
+		o.e = d0 ? (d1 ? 5u : 7u) : (d1 ? 1u : 3u);
+	}
+	return o;
+}
+
+// the 8 corner values v[k] = iso - F (MC:1840-1855) and the sign index (MC:1846-1859)
+template <typename T>
+MC33_HD uint32_t load_cell(const GridView<T> &G, float iso, uint32_t x, uint32_t y, uint32_t z, const VRef &v) {
+	uint32_t i = 0;
+	for (uint32_t k = 0; k < 8; k++) {
+		const uint32_t c = corner_code(k);
+		const float d = iso - (float)G.at(x + (c & 1), y + ((c >> 1) & 1), z + (c >> 2));
+		v[k] = d;
+		i |= sign_of(d) << (7 - k);
+	}
+	return i;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Ambiguity tests (MC:347-386 face tests, MC:431-462 interior test) and case selection (MC:683-779)
+// ---------------------------------------------------------------------------------------------------
+MC33_HD bool face_less(int f, const VRef &v) {
+	switch (f) {
+	case 0: return v[0] * v[5] < v[1] * v[4];
+	case 1: return v[1] * v[6] < v[2] * v[5];
+	case 2: return v[3] * v[6] < v[2] * v[7];
+	case 3: return v[0] * v[7] < v[3] * v[4];
+	case 4: return v[0] * v[2] < v[1] * v[3];
+	default: return v[4] * v[6] < v[5] * v[7];
+	}
+}
+// per face f (byte f): index mask, the diagonal through v0 (faces 0,3,4) / v6 (faces 1,2,5), the other one
+MC33_HD uint32_t face_mask(int f) { return (uint32_t)(0x0FF0993366CCull >> (8 * f)) & 0xFFu; }
+MC33_HD uint32_t face_diag_hi(int f) { return (uint32_t)(0x0AA081124284ull >> (8 * f)) & 0xFFu; }
+MC33_HD uint32_t face_diag_lo(int f) { return (uint32_t)(0x055018212448ull >> (8 * f)) & 0xFFu; }
+
+MC33_HD uint32_t face_test_one(int f, const VRef &v) { return face_less(f, v) ? face_diag_lo(f) : face_diag_hi(f); }  // MC:371-386
+
+MC33_HD int face_tests(int *face, uint32_t ind, const VRef &v) {  // MC:347-367
+	int sum = 0;
+	for (int f = 0; f < 6; f++) {
+		const uint32_t key = (f == 0 || f == 3 || f == 4) ? 0x80u : 0x02u;
+		int r = 0;
+		if (ind & key) {
+			if ((ind & face_mask(f)) == face_diag_hi(f)) r = face_less(f, v) ? -1 : 1;
+		} else {
+			if ((ind & face_mask(f)) == face_diag_lo(f)) r = face_less(f, v) ? 1 : -1;
+		}
+		face[f] = r;
+		sum += r;
+	}
+	return sum;
+}
+
+MC33_HD int interior_test(int s, int flag13, const VRef &v) {  // MC:431-462
+	float a = v[4] - v[0], b = v[5] - v[1], c = v[6] - v[2], d = v[7] - v[3];
+	float t = a * c - b * d;
+	if (sign_of(t)) {
+		if (s & 1) return 0;
+	} else if (!(s & 1) || t == 0)
+		return 0;
+	t = 0.5f * (v[3] * b - v[2] * a + v[1] * d - v[0] * c) / t;
+	if (t > 0 && t < 1) {
+		a = v[0] + a * t; b = v[1] + b * t; c = v[2] + c * t; d = v[3] + d * t;
+		c *= a; d *= b;
+		if (s & 1) {
+			if (c < d && !sign_of(d)) return (int)(sign_of(b) == sign_of(v[s])) + flag13;
+		} else {
+			if (c > d && !sign_of(c)) return (int)(sign_of(a) == sign_of(v[s])) + flag13;
+		}
+	}
+	return 0;
+}
+
+// table word -> offset of the triangle pattern; the walk starts at offset+1 (MC:781).
+// m,n: which of the first two triangle slots is written first (winding, MC:683-691, 1249)
+MC33_HD uint32_t pattern_offset(const uint16_t *lut, uint32_t i, const VRef &v, uint32_t &m, uint32_t &n) {
+	uint32_t c;
+	if (i & 0x80) { c = lut[i ^ 0xFF]; m = (c & 0x800) == 0; n = !m; }
+	else { c = lut[i]; n = (c & 0x800) == 0; m = !n; }
+	const uint32_t k = c & 0x7FF, ci = m ? i : i ^ 0xFF;
+	int f[6];
+	switch (c >> 12) {
+	case 0: return k;                                                                    // cases 1,2,5,8,9,11,14
+	case 1: return (ci & face_test_one((int)(k >> 2), v)) ? 183 + 2 * k : 159 + k;       // case 3
+	case 2: return interior_test((int)k, 0, v) ? 239 + 6 * k : 231 + 2 * k;              // case 4
+	case 3:                                                                              // case 6
+		if (ci & face_test_one((int)(k % 6), v)) return 575 + 5 * k;
+		return interior_test((int)(k / 6), 0, v) ? 407 + 7 * k : 335 + 3 * k;
+	case 4:                                                                              // case 7
+		switch (face_tests(f, ci, v)) {
+		case -3: return 695 + 3 * k;
+		case -1: return (f[4] + f[5] < 0 ? (f[0] + f[2] < 0 ? 759u : 799u) : 719u) + 5 * k;
+		case 1: return (f[4] + f[5] < 0 ? 983u : (f[0] + f[2] < 0 ? 839u : 911u)) + 9 * k;
+		default: return interior_test((int)(k >> 1), 0, v) ? 1095 + 9 * k : 1055 + 5 * k;
+		}
+	case 5:                                                                              // case 10
+		switch (face_tests(f, ci, v)) {
+		case -2:
+			if (k == 2 ? interior_test(0, 0, v) : (interior_test(0, 0, v) || interior_test(k ? 1 : 3, 0, v)))
+				return 1213 + 8 * k;
+			return 1189 + 4 * k;
+		case 0: return (f[2 + k] < 0 ? 1261u : 1285u) + 8 * k;
+		default:
+			if (k == 2 ? interior_test(1, 0, v) : (interior_test(2, 0, v) || interior_test(k ? 3 : 1, 0, v)))
+				return 1237 + 8 * k;
+			return 1201 + 4 * k;
+		}
+	case 6:                                                                              // case 12
+		switch (face_tests(f, ci, v)) {
+		case -2: return interior_test((int)((0xDA010Cu >> (2 * k)) & 3), 0, v) ? 1453 + 8 * k : 1357 + 4 * k;
+		case 0: return (f[k >> 1] < 0 ? 1645u : 1741u) + 8 * k;
+		default: return interior_test((int)((0xA7B7E5u >> (2 * k)) & 3), 0, v) ? 1549 + 8 * k : 1405 + 4 * k;
+		}
+	default: {                                                                           // case 13
+		int s = face_tests(f, 165, v);
+		if (s < 0) s = -s;
+		if (s == 0) {
+			const int kk = ((f[1] < 0) << 1) | (f[5] < 0);
+			if (f[0] * f[1] == f[5]) return (uint32_t)(2157 + 12 * kk);
+			const int r = interior_test(kk, 1, v);
+			return (uint32_t)(2285 + (r ? 10 * kk - 40 * r : 6 * kk));
+		}
+		if (s == 2) {
+			uint32_t off = 1917 + 10 * ((f[0] < 0 ? (uint32_t)(f[2] > 0) : 12u + (f[2] < 0)) +
+			                            (f[1] < 0 ? (uint32_t)(f[3] < 0) : 6u + (f[3] > 0)));
+			if (f[4] > 0) off += 30;
+			return off;
+		}
+		if (s == 4) {
+			uint32_t kk = (uint32_t)(21 + 11 * f[0] + 4 * f[1] + 3 * f[2] + 2 * f[3] + f[4]);
+			if (kk >> 4) kk -= (kk & 32 ? 20 : 10);
+			return 1845 + 3 * kk;
+		}
+		return (uint32_t)(1839 + 2 * f[0]);
+	}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The plan of one active cell: what each edge of its pattern resolves to
+// ---------------------------------------------------------------------------------------------------
+struct CellPlan {
+	uint64_t rank;     // nibble per slot 0..12 (12 = cell centre): rank of the NEW vertex, 0xF = none
+	uint32_t visited;  // slots that appear in the pattern (or were marked on the way, MC:973 etc.)
+	uint32_t created;  // slots that create a vertex here (a slot may also share another slot's rank)
+	uint32_t onpoint;  // subset of created: the vertex lies on a grid point (MC:628 MC33_surfint)
+	uint32_t onb;      // ... and that grid point is the edge's second end point
+	uint32_t tgt[3];   // byte per edge 0..11, meaningful when visited and rank==0xF: the grid edge whose
+	                   // id is used: axis | (dx+1)<<2 | (dy+1)<<4 | (dz+1)<<6, base point = cell + (dx,dy,dz)
+	uint16_t poff;     // pattern offset in the table
+	uint8_t m, n;      // winding selectors
+	uint8_t nnew;      // vertices created by this cell
+	uint8_t ntri;      // triangles in the pattern (before the zero-area filter, MC:1235)
+	uint8_t zmask;     // corners whose value is exactly 0 (bit k)
+};
+
+MC33_HD uint32_t plan_rank(const CellPlan &p, uint32_t e) { return (uint32_t)(p.rank >> (4 * e)) & 15u; }
+MC33_HD void plan_set_rank(CellPlan &p, uint32_t e, uint32_t r) {
+	p.rank = (p.rank & ~(15ull << (4 * e))) | ((uint64_t)r << (4 * e));
+}
+MC33_HD uint32_t plan_tgt(const CellPlan &p, uint32_t e) { return (p.tgt[e >> 2] >> (8 * (e & 3))) & 0xFFu; }
+MC33_HD void plan_set_tgt(CellPlan &p, uint32_t e, uint32_t t) {
+	p.tgt[e >> 2] = (p.tgt[e >> 2] & ~(0xFFu << (8 * (e & 3)))) | (t << (8 * (e & 3)));
+}
+MC33_HD uint32_t make_tgt(uint32_t axis, int dx, int dy, int dz) {
+	return axis | (uint32_t)(dx + 1) << 2 | (uint32_t)(dy + 1) << 4 | (uint32_t)(dz + 1) << 6;
+}
+
+template <typename T>
+MC33_HD void plan_visit(CellPlan &p, const Tables &tab, const Params &P, const GridView<T> &G,
+                        uint32_t x, uint32_t y, uint32_t z, const VRef &v, uint32_t e) {
+	const uint32_t bit = 1u << e;
+	p.visited |= bit;
+	if (e == 12) {  // MC:1225-1230
+		plan_set_rank(p, 12, p.nnew++);
+		p.created |= bit;
+		return;
+	}
+	const uint32_t own = edge_own(e), a = edge_a(e), b = edge_b(e);
+	if (((own & 1) && x) || ((own & 2) && y) || ((own & 4) && z)) {
+		// an earlier cell owns this edge: the reference reads the id from its cache (e.g. MC:789)
+		const uint32_t c = corner_code(a);
+		plan_set_tgt(p, e, make_tgt(edge_axis(e), (int)(c & 1), (int)((c >> 1) & 1), (int)(c >> 2)));
+		return;
+	}
+	const float va = v[(int)a], vb = v[(int)b];
+	if (va == 0 || vb == 0) {
+		// the vertex sits on a grid point: try the id sources in the reference's order (MC:791-808 ...)
+		const uint8_t *ix = tab.rule_index + 4 * e;
+		const uint32_t first = (va == 0) ? ix[0] : ix[2], count = (va == 0) ? ix[1] : ix[3];
+		for (uint32_t q = 0; q < count; q++) {
+			const uint32_t w = tab.rule_words[first + q];
+			const uint32_t need = (w >> 2) & 0x7Fu;
+			if (((need & 1) && !x) || ((need & 2) && !y) || ((need & 4) && !z) || ((need & 8) && !(x + 1 < P.nx)) ||
+			    ((need & 16) && !(y + 1 < P.ny)) || ((need & 32) && x) || ((need & 64) && y))
+				continue;
+			const uint32_t kind = w & 3u, arg = (w >> 9) & 15u;
+			if (kind == 1) {  // another edge of this cell, if already visited
+				if (p.visited & (1u << arg)) {
+					plan_set_rank(p, e, plan_rank(p, arg));
+					plan_set_tgt(p, e, plan_tgt(p, arg));
+					return;
+				}
+				continue;
+			}
+			uint32_t pass;
+			if (w & (1u << 13)) {
+				const int fx = (int)((w >> 14) & 3) - 1, fy = (int)((w >> 16) & 3) - 1, fz = (int)((w >> 18) & 3) - 1;
+				pass = sign_of(P.iso - (float)G.at((uint32_t)((int)x + fx), (uint32_t)((int)y + fy), (uint32_t)((int)z + fz)));
+			} else
+				pass = sign_of(v[(int)arg]);
+			if (!pass) continue;
+			const uint32_t t = (w >> 20) & 0xFFu;  // axis | sx+1 | sy+1 | sz+1, same layout as make_tgt
+			plan_set_tgt(p, e, t);
+			const uint32_t also = w >> 28;
+			if (also != 15u) {
+				p.visited |= 1u << also;
+				plan_set_tgt(p, also, t);
+			}
+			return;
+		}
+		plan_set_rank(p, e, p.nnew++);  // MC33_surfint (MC:628)
+		p.created |= bit;
+		p.onpoint |= bit;
+		if (va != 0) p.onb |= bit;
+		return;
+	}
+	plan_set_rank(p, e, p.nnew++);  // regular interpolated vertex (MC:810-816 ...)
+	p.created |= bit;
+}
+
+template <typename T>
+MC33_HD void plan_cell(CellPlan &p, const Tables &tab, const Params &P, const GridView<T> &G,
+                       uint32_t x, uint32_t y, uint32_t z, uint32_t i, const VRef &v) {
+	uint32_t m, n;
+	p.poff = (uint16_t)pattern_offset(tab.lut, i, v, m, n);
+	p.m = (uint8_t)m; p.n = (uint8_t)n;
+	p.rank = ~0ull;
+	p.visited = p.created = p.onpoint = p.onb = 0;
+	p.tgt[0] = p.tgt[1] = p.tgt[2] = 0;
+	p.nnew = 0; p.ntri = 0;
+	uint32_t zm = 0;
+	for (int k = 0; k < 8; k++) zm |= (uint32_t)(v[k] == 0) << k;
+	p.zmask = (uint8_t)zm;
+	uint32_t pos = p.poff, word;
+	do {  // MC:780-784
+		word = tab.lut[++pos];
+		p.ntri++;
+		uint32_t w = word;
+		for (int k = 0; k < 3; k++) {
+			const uint32_t e = w & 15u;
+			w >>= 4;
+			if (!(p.visited & (1u << e))) plan_visit(p, tab, P, G, x, y, z, v, e);
+		}
+	} while (word >> 12);
+}
+
+// absolute grid edge a plan target byte refers to
+struct GridEdge {
+	uint32_t axis, x, y, z;
+};
+MC33_HD GridEdge tgt_edge(uint32_t t, uint32_t x, uint32_t y, uint32_t z) {
+	GridEdge g;
+	g.axis = t & 3u;
+	g.x = (uint32_t)((int)x + (int)((t >> 2) & 3) - 1);
+	g.y = (uint32_t)((int)y + (int)((t >> 4) & 3) - 1);
+	g.z = (uint32_t)((int)z + (int)((t >> 6) & 3) - 1);
+	return g;
+}
+
+// Follow a grid edge to the cell that creates its vertex (used by the count pass, where no ids exist
+// yet, to decide the reference's zero-area test MC:1235 on vertex IDENTITY).  w: scratch for 8 values.
+struct VertexKey {
+	uint32_t x, y, z, rank;
+};
+template <typename T>
+MC33_HD VertexKey root_of(const Tables &tab, const Params &P, const GridView<T> &G, GridEdge g, const VRef &w) {
+	VertexKey key = {NO_ID, NO_ID, NO_ID, 15u};
+	for (int hop = 0; hop < 64; hop++) {
+		const OwnerRef o = owner_of(g.axis, g.x, g.y, g.z);
+		const uint32_t i = load_cell(G, P.iso, o.x, o.y, o.z, w);
+		if (i == 0 || i == 0xFF) return key;
+		CellPlan q;
+		plan_cell(q, tab, P, G, o.x, o.y, o.z, i, w);
+		if (!(q.visited & (1u << o.e))) return key;
+		const uint32_t r = plan_rank(q, o.e);
+		if (r != 15u) {
+			key.x = o.x; key.y = o.y; key.z = o.z; key.rank = r;
+			return key;
+		}
+		g = tgt_edge(plan_tgt(q, o.e), o.x, o.y, o.z);
+	}
+	return key;
+}
+
+// do pattern slots ea and eb of this cell refer to different vertices?
+template <typename T>
+MC33_HD bool slots_differ(const CellPlan &p, const Tables &tab, const Params &P, const GridView<T> &G,
+                          uint32_t x, uint32_t y, uint32_t z, uint32_t ea, uint32_t eb, const VRef &w) {
+	const uint32_t ra = plan_rank(p, ea), rb = plan_rank(p, eb);
+	if (ra != 15u && rb != 15u) return ra != rb;
+	if (ra != 15u || rb != 15u) return true;  // one created here, the other by an earlier cell
+	const uint32_t ta = plan_tgt(p, ea), tb = plan_tgt(p, eb);
+	if (ta == tb) return false;
+	// two different grid edges share a vertex only when it lies on a common end point with value 0
+	const uint32_t ca = (1u << edge_a(ea)) | (1u << edge_b(ea)), cb = (1u << edge_a(eb)) | (1u << edge_b(eb));
+	if (!(ca & cb & p.zmask)) return true;
+	const VertexKey ka = root_of(tab, P, G, tgt_edge(ta, x, y, z), w);
+	const VertexKey kb = root_of(tab, P, G, tgt_edge(tb, x, y, z), w);
+	return !(ka.x == kb.x && ka.y == kb.y && ka.z == kb.z && ka.rank == kb.rank);
+}
+
+// number of triangles the cell appends (MC:1235 drops triangles with two equal vertex ids)
+template <typename T>
+MC33_HD uint32_t count_triangles(const CellPlan &p, const Tables &tab, const Params &P, const GridView<T> &G,
+                                 uint32_t x, uint32_t y, uint32_t z, const VRef &w) {
+	if (!p.zmask) return p.ntri;  // all vertices distinct
+	uint32_t pos = p.poff, word, nt = 0;
+	do {
+		word = tab.lut[++pos];
+		const uint32_t e0 = word & 15u, e1 = (word >> 4) & 15u, e2 = (word >> 8) & 15u;
+		if (slots_differ(p, tab, P, G, x, y, z, e0, e1, w) && slots_differ(p, tab, P, G, x, y, z, e0, e2, w) &&
+		    slots_differ(p, tab, P, G, x, y, z, e1, e2, w))
+			nt++;
+	} while (word >> 12);
+	return nt;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Vertex geometry.  r[0..2]: position in grid-index units, r[3..5]: gradient of v = iso - F
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+MC33_HD void vertex_on_edge(const Params &P, const GridView<T> &G, uint32_t x, uint32_t y, uint32_t z, uint32_t e,
+                            const VRef &v, float *r) {  // MC:810-816 ... 1212-1220, SURVEY.md Appendix C
+	const uint32_t a = edge_a(e), b = edge_b(e), axis = edge_axis(e);
+	const uint32_t ca = corner_code(a), cb = corner_code(b);
+	const uint32_t cell[3] = {x, y, z}, lim[3] = {P.nx, P.ny, P.nz};
+	const float va = v[(int)a], vb = v[(int)b];
+	const float t = va / (va - vb);
+	for (uint32_t ax = 0; ax < 3; ax++) {
+		if (ax == axis) {
+			r[ax] = (float)cell[ax] + t;
+			r[3 + ax] = vb - va;
+			continue;
+		}
+		const uint32_t off = (ca >> ax) & 1u;
+		r[ax] = (float)(cell[ax] + off);
+		if (off && cell[ax] + 1 < lim[ax]) {
+			// central differences across the edge at both end points, blended along the edge
+			uint32_t pa[3] = {x + (ca & 1), y + ((ca >> 1) & 1), z + (ca >> 2)};
+			uint32_t pb[3] = {x + (cb & 1), y + ((cb >> 1) & 1), z + (cb >> 2)};
+			uint32_t lo[3] = {pa[0], pa[1], pa[2]}, hi[3] = {pa[0], pa[1], pa[2]};
+			lo[ax]--; hi[ax]++;
+			const float da = sample_diff(G.at(lo[0], lo[1], lo[2]), G.at(hi[0], hi[1], hi[2]));
+			lo[0] = hi[0] = pb[0]; lo[1] = hi[1] = pb[1]; lo[2] = hi[2] = pb[2];
+			lo[ax]--; hi[ax]++;
+			const float db = sample_diff(G.at(lo[0], lo[1], lo[2]), G.at(hi[0], hi[1], hi[2]));
+			r[3 + ax] = 0.5f * (da * (1 - t) + db * t);
+		} else {
+			// one-sided: difference of v across the cell at both end points
+			const uint32_t bitax = 1u << ax;
+			const float da = v[(int)corner_at(ca | bitax)] - v[(int)corner_at(ca & ~bitax)];
+			const float db = v[(int)corner_at(cb | bitax)] - v[(int)corner_at(cb & ~bitax)];
+			r[3 + ax] = da * (1 - t) + db * t;
+		}
+	}
+}
+
+template <typename T>
+MC33_HD void vertex_on_point(const Params &P, const GridView<T> &G, uint32_t x, uint32_t y, uint32_t z, float *r) {  // MC:628-649
+	const uint32_t q[3] = {x, y, z}, lim[3] = {P.nx, P.ny, P.nz};
+	r[0] = (float)x; r[1] = (float)y; r[2] = (float)z;
+	for (uint32_t ax = 0; ax < 3; ax++) {
+		uint32_t lo[3] = {x, y, z}, hi[3] = {x, y, z};
+		bool half = false;
+		if (q[ax] == 0) hi[ax] = 1;
+		else if (q[ax] == lim[ax]) lo[ax] = q[ax] - 1;
+		else { lo[ax] = q[ax] - 1; hi[ax] = q[ax] + 1; half = true; }
+		const float d = sample_diff(G.at(lo[0], lo[1], lo[2]), G.at(hi[0], hi[1], hi[2]));
+		r[3 + ax] = half ? 0.5f * d : d;
+	}
+}
+
+MC33_HD void vertex_centre(uint32_t x, uint32_t y, uint32_t z, const VRef &v, float *r) {  // MC:1225-1230
+	r[0] = (float)x + 0.5f; r[1] = (float)y + 0.5f; r[2] = (float)z + 0.5f;
+	r[3] = v[4] + v[5] + v[6] + v[7] - v[0] - v[1] - v[2] - v[3];
+	r[4] = v[1] + v[2] + v[5] + v[6] - v[0] - v[3] - v[4] - v[7];
+	r[5] = v[2] + v[3] + v[6] + v[7] - v[0] - v[1] - v[4] - v[5];
+}
+
+MC33_HD float inv_sqrt_exact(float f) { return 1.0f / sqrtf(f); }  // MC:70-73 (the reference's portable form)
+
+// world position and unit normal of vertex `id` (MC:485-585)
+MC33_HD void store_vertex(const Params &P, float *r, float *V, float *N, uint32_t id) {
+	float *p = V + 3 * (uint64_t)id;
+	if (P.store_mode == 0) {
+		p[0] = r[0]; p[1] = r[1]; p[2] = r[2];
+	} else {
+		for (int k = 0; k < 3; k++) p[k] = r[k] * P.D[k] + P.O[k];
+		if (P.store_mode == 2) { r[3] *= P.ca; r[4] *= P.cb; }
+	}
+	const float s = inv_sqrt_exact(r[3] * r[3] + r[4] * r[4] + r[5] * r[5]);
+	float *n = N + 3 * (uint64_t)id;
+	n[0] = s * r[3]; n[1] = s * r[4]; n[2] = s * r[5];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Work records produced by the count pass and consumed by the emit pass
+// ---------------------------------------------------------------------------------------------------
+// One 16-byte entry per active cell, stored so that the entries of one row segment are contiguous and
+// sorted by x.  Neighbours look each other up through the row-segment directory.
+struct Entry {
+	uint32_t w0;  // x within the segment (8) | sign index (8) | pattern offset (12) | nnew (4)
+	uint32_t w1;  // vertex offset inside the row segment (16) | triangle offset (16)
+	uint32_t w2;  // ranks of edges 0..7  (nibbles)
+	uint32_t w3;  // ranks of edges 8..11 (nibbles); upper half spare
+};
+MC33_HD Entry make_entry(uint32_t xl, uint32_t i, const CellPlan &p, uint32_t voff, uint32_t toff) {
+	Entry e;
+	e.w0 = xl | i << 8 | (uint32_t)p.poff << 16 | (uint32_t)p.nnew << 28;
+	e.w1 = voff | toff << 16;
+	e.w2 = (uint32_t)p.rank;
+	e.w3 = (uint32_t)(p.rank >> 32) & 0xFFFFu;
+	return e;
+}
+MC33_HD uint32_t entry_rank(const Entry &e, uint32_t edge) {
+	return edge < 8 ? (e.w2 >> (4 * edge)) & 15u : (e.w3 >> (4 * (edge - 8))) & 15u;
+}
+
+MC33_HD uint64_t segment_index(const Params &P, uint32_t x, uint32_t y, uint32_t z) {
+	return ((uint64_t)z * P.ny + y) * P.nseg + x / SEG_CELLS;
+}
+
+template <typename T>
+struct EmitCtx {
+	Tables tab;
+	Params P;
+	GridView<T> G;
+	const uint32_t *seg_vbase;  // exclusive scans over the row segments, in sweep order
+	const uint32_t *seg_tbase;
+	const uint32_t *seg_first;  // first entry of the segment
+	const uint32_t *seg_nent;   // number of entries of the segment
+	const Entry *entries;
+	const uint32_t *entry_seg;  // row segment of each entry
+	float *V, *N;
+	uint32_t *Tri;
+};
+
+// per-segment counts packed in one word: vertices (<= 13*256) | triangles (<= 12*256) << 16
+MC33_HD uint32_t seg_pack(uint32_t nv, uint32_t nt) { return nv | nt << 16; }
+
+// id of the vertex on a grid edge, through the owner's entry (emit pass).  w: scratch for 8 values.
+template <typename T>
+MC33_HD uint32_t edge_vertex_id(const EmitCtx<T> &c, GridEdge g, const VRef &w) {
+	for (int hop = 0; hop < 64; hop++) {
+		const OwnerRef o = owner_of(g.axis, g.x, g.y, g.z);
+		const uint64_t s = segment_index(c.P, o.x, o.y, o.z);
+		const uint32_t first = c.seg_first[s], n = c.seg_nent[s], xl = o.x % SEG_CELLS;
+		// entries of a segment are sorted by x: binary search
+		uint32_t lo = 0, hi = n;
+		while (lo < hi) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if ((c.entries[first + mid].w0 & 0xFFu) < xl) lo = mid + 1;
+			else hi = mid;
+		}
+		if (lo >= n) return NO_ID;
+		const Entry e = c.entries[first + lo];
+		if ((e.w0 & 0xFFu) != xl) return NO_ID;
+		const uint32_t r = entry_rank(e, o.e);
+		if (r != 15u) return c.seg_vbase[s] + (e.w1 & 0xFFFFu) + r;
+		// the owner itself took the id from another grid edge: recompute its plan to learn which
+		const uint32_t i = load_cell(c.G, c.P.iso, o.x, o.y, o.z, w);
+		CellPlan q;
+		plan_cell(q, c.tab, c.P, c.G, o.x, o.y, o.z, i, w);
+		if (!(q.visited & (1u << o.e))) return NO_ID;
+		g = tgt_edge(plan_tgt(q, o.e), o.x, o.y, o.z);
+	}
+	return NO_ID;
+}
+
+// Emit pass for one active cell: writes its NEW vertices and its triangles.
+// v, w: 8-value scratch arrays; ids: 13-slot scratch.
+template <typename T>
+MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v, const VRef &w, const URef &ids) {
+	const Entry en = c.entries[entry_index];
+	const uint32_t s = c.entry_seg[entry_index];
+	const uint32_t sx = s % c.P.nseg, row = s / c.P.nseg;
+	const uint32_t y = row % c.P.ny, z = row / c.P.ny;
+	const uint32_t x = sx * SEG_CELLS + (en.w0 & 0xFFu);
+	const uint32_t vbase = c.seg_vbase[s] + (en.w1 & 0xFFFFu);
+	uint32_t tpos = c.seg_tbase[s] + (en.w1 >> 16);
+	const uint32_t i = load_cell(c.G, c.P.iso, x, y, z, v);
+	CellPlan p;
+	plan_cell(p, c.tab, c.P, c.G, x, y, z, i, v);
+	// ids of all slots of the pattern; NEW vertices are written on the way
+	for (uint32_t e = 0; e < 13; e++) {
+		if (!(p.visited & (1u << e))) continue;
+		const uint32_t r = plan_rank(p, e);
+		if (r != 15u) {
+			ids[(int)e] = vbase + r;
+			if (p.created & (1u << e)) {
+				float g[6];
+				if (e == 12) vertex_centre(x, y, z, v, g);
+				else if (p.onpoint & (1u << e)) {
+					const uint32_t cc = corner_code((p.onb & (1u << e)) ? edge_b(e) : edge_a(e));
+					vertex_on_point(c.P, c.G, x + (cc & 1), y + ((cc >> 1) & 1), z + (cc >> 2), g);
+				} else
+					vertex_on_edge(c.P, c.G, x, y, z, e, v, g);
+				store_vertex(c.P, g, c.V, c.N, vbase + r);
+			}
+		} else
+			ids[(int)e] = edge_vertex_id(c, tgt_edge(plan_tgt(p, e), x, y, z), w);
+	}
+	uint32_t pos = p.poff, word;
+	do {  // MC:780-784, 1235-1250
+		word = c.tab.lut[++pos];
+		uint32_t ti[3];
+		ti[2] = ids[(int)(word & 15u)];
+		ti[1] = ids[(int)((word >> 4) & 15u)];
+		ti[0] = ids[(int)((word >> 8) & 15u)];
+		if (ti[0] != ti[1] && ti[0] != ti[2] && ti[1] != ti[2]) {
+			uint32_t *t = c.Tri + 3 * (uint64_t)tpos++;
+			t[0] = p.n ? ti[1] : ti[0]; t[1] = p.m ? ti[1] : ti[0]; t[2] = ti[2];
+		}
+	} while (word >> 12);
+}
+
+}  // namespace mc33

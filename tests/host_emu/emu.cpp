@@ -1,0 +1,86 @@
+// tests/host_emu/emu.cpp -- TEST INFRASTRUCTURE ONLY.
+// Runs the MI355X path's per-cell formulation (mc33_c_library_amd/csrc/mc33_cell.h: plans, owner lookups,
+// entry records, segment scans) serially on the CPU, so that the logic the HIP kernels execute can be
+// checked against the oracle in a container without a GPU.  Never linked into the product library.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../mc33_c_library_amd/csrc/mc33_cell.h"
+#include "../../mc33_c_library_amd/csrc/mc33_lut_data.h"
+#include "../../mc33_c_library_amd/csrc/mc33_rules_data.h"
+
+using namespace mc33;
+
+struct emu_surface {
+	uint32_t nV, nT;
+	float *V, *N;
+	uint32_t *T;
+};
+
+template <typename T>
+static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const double *r0, const double *d, float iso,
+               emu_surface *out) {
+	memset(out, 0, sizeof *out);
+	Params P;
+	P.nx = npx - 1; P.ny = npy - 1; P.nz = npz - 1;
+	P.nseg = (P.nx + SEG_CELLS - 1) / SEG_CELLS;
+	P.iso = iso;
+	if (d[0] != d[1] || d[1] != d[2]) { P.store_mode = 2; P.ca = (float)(d[2] / d[0]); P.cb = (float)(d[2] / d[1]); }
+	else { P.store_mode = (d[0] == 1 && r0[0] == 0 && r0[1] == 0 && r0[2] == 0) ? 0 : 1; P.ca = P.cb = 1; }
+	for (int k = 0; k < 3; k++) { P.O[k] = (float)r0[k]; P.D[k] = (float)d[k]; }
+	GridView<T> G{data, npx, (uint64_t)npx * npy};
+	Tables tab{mc33_lut, mc33_rule_words, &mc33_rule_index[0][0]};
+
+	const uint64_t nsegs = (uint64_t)P.nz * P.ny * P.nseg;
+	std::vector<uint32_t> seg_cnt(nsegs, 0), seg_first(nsegs, 0), seg_nent(nsegs, 0), seg_vbase(nsegs), seg_tbase(nsegs);
+	std::vector<Entry> entries;
+	std::vector<uint32_t> entry_seg;
+	float vbuf[8], wbuf[8];
+	uint32_t idbuf[13];
+	VRef v{vbuf, 1}, w{wbuf, 1};
+	URef ids{idbuf, 1};
+	// count pass
+	for (uint32_t z = 0; z < P.nz; z++)
+		for (uint32_t y = 0; y < P.ny; y++)
+			for (uint32_t x = 0; x < P.nx; x++) {
+				const uint32_t i = load_cell(G, iso, x, y, z, v);
+				if (i == 0 || i == 0xFF) continue;
+				CellPlan p;
+				plan_cell(p, tab, P, G, x, y, z, i, v);
+				const uint32_t nt = count_triangles(p, tab, P, G, x, y, z, w);
+				const uint64_t s = segment_index(P, x, y, z);
+				if (seg_nent[s] == 0) seg_first[s] = (uint32_t)entries.size();
+				const uint32_t voff = seg_cnt[s] & 0xFFFF, toff = seg_cnt[s] >> 16;
+				entries.push_back(make_entry(x % SEG_CELLS, i, p, voff, toff));
+				entry_seg.push_back((uint32_t)s);
+				seg_nent[s]++;
+				seg_cnt[s] = seg_pack(voff + p.nnew, toff + nt);
+			}
+	// scan
+	uint64_t nV = 0, nT = 0;
+	for (uint64_t s = 0; s < nsegs; s++) {
+		seg_vbase[s] = (uint32_t)nV; seg_tbase[s] = (uint32_t)nT;
+		nV += seg_cnt[s] & 0xFFFF; nT += seg_cnt[s] >> 16;
+	}
+	out->nV = (uint32_t)nV; out->nT = (uint32_t)nT;
+	out->V = (float *)malloc(nV * 12 + 16); out->N = (float *)malloc(nV * 12 + 16); out->T = (uint32_t *)malloc(nT * 12 + 16);
+	memset(out->T, 0xFF, nT * 12);
+	EmitCtx<T> c;
+	c.tab = tab; c.P = P; c.G = G;
+	c.seg_vbase = seg_vbase.data(); c.seg_tbase = seg_tbase.data(); c.seg_first = seg_first.data(); c.seg_nent = seg_nent.data();
+	c.entries = entries.data(); c.entry_seg = entry_seg.data();
+	c.V = out->V; c.N = out->N; c.Tri = out->T;
+	for (size_t k = 0; k < entries.size(); k++) emit_cell(c, (uint32_t)k, v, w, ids);
+	return 0;
+}
+
+extern "C" int emu_isosurface_f32(const float *data, uint32_t npx, uint32_t npy, uint32_t npz, const double *r0,
+                                  const double *d, float iso, emu_surface *out) {
+	return run<float>(data, npx, npy, npz, r0, d, iso, out);
+}
+extern "C" int emu_isosurface_u16(const uint16_t *data, uint32_t npx, uint32_t npy, uint32_t npz, const double *r0,
+                                  const double *d, float iso, emu_surface *out) {
+	return run<uint16_t>(data, npx, npy, npz, r0, d, iso, out);
+}
+extern "C" void emu_free(emu_surface *s) { free(s->V); free(s->N); free(s->T); memset(s, 0, sizeof *s); }

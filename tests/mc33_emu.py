@@ -1,0 +1,50 @@
+"""ctypes wrapper of tests/host_emu/libmc33_emu.so: the MI355X path's per-cell logic run serially on
+the CPU (test infrastructure only; lets the parallel formulation be checked without a GPU)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from mc33_capi import ROOT, Surface
+from mc33_oracle import OSURF
+
+EMU_DIR = os.path.join(ROOT, "tests", "host_emu")
+EMU_SO = os.path.join(EMU_DIR, "libmc33_emu.so")
+
+
+def build_emu(force=False):
+    src = os.path.join(EMU_DIR, "emu.cpp")
+    deps = [src] + [os.path.join(ROOT, "mc33_c_library_amd", "csrc", f) for f in
+                    ("mc33_cell.h", "mc33_lut_data.h", "mc33_rules_data.h")]
+    if force or not os.path.exists(EMU_SO) or any(os.path.getmtime(d) > os.path.getmtime(EMU_SO) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", src, "-o", EMU_SO])
+    return EMU_SO
+
+
+class Emu:
+    def __init__(self, dtype="f32"):
+        self.dtype = dtype
+        self.np_dtype = np.float32 if dtype == "f32" else np.uint16
+        self.lib = C.CDLL(build_emu())
+        self.fn = getattr(self.lib, "emu_isosurface_" + dtype)
+        self.fn.restype = C.c_int
+        self.fn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                            C.c_float, C.POINTER(OSURF)]
+        self.lib.emu_free.argtypes = [C.POINTER(OSURF)]
+
+    def isosurface(self, data, iso, r0=None, d=None):
+        data = np.ascontiguousarray(data, dtype=self.np_dtype)
+        nz, ny, nx = data.shape
+        r0a = (C.c_double * 3)(*(r0 if r0 is not None else (0.0, 0.0, 0.0)))
+        da = (C.c_double * 3)(*(d if d is not None else (1.0, 1.0, 1.0)))
+        s = OSURF()
+        self.fn(data.ctypes.data, nx, ny, nz, r0a, da, C.c_float(iso), C.byref(s))
+
+        def arr(ptr, n, dt):
+            if n == 0:
+                return np.zeros((0, 3), dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (n * 12,)).view(dt).reshape(n, 3).copy()
+        out = Surface(s.nV, s.nT, arr(s.V, s.nV, np.float32), arr(s.N, s.nV, np.float32), arr(s.T, s.nT, np.uint32), None, iso)
+        self.lib.emu_free(C.byref(s))
+        return out
