@@ -1,0 +1,105 @@
+/* mc33_hip.h -- device-level C ABI of the MI355X MC33 extractor (plain pointers and sizes only).
+ *
+ * These are the entry points the reference-compatible host layer (mc33_capi.c: create_MC33,
+ * calculate_isosurface, size_of_isosurface, free_MC33 - reference include/marching_cubes_33.h:228-258)
+ * is built on, and what a foreign-language binding would bind.  Each one names the reference code it
+ * replaces ("MC:" = reference source/marching_cubes_33.c).
+ *
+ * All functions return 0 on success, a negative MC33HIP_E* code otherwise (no exceptions, no exit;
+ * the reference's only failure convention is a NULL return, MC:1884-1887).
+ */
+#ifndef MC33_HIP_H
+#define MC33_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC33HIP_OK          0
+#define MC33HIP_EINVAL     -1  /* bad argument                                   */
+#define MC33HIP_ENOGPU     -2  /* no HIP device / runtime error at start-up       */
+#define MC33HIP_ENOMEM     -3  /* host or device allocation failed                */
+#define MC33HIP_ECAPACITY  -4  /* caller's output buffers are too small           */
+#define MC33HIP_ERUNTIME   -5  /* a HIP call or kernel failed (see last_error)    */
+#define MC33HIP_EOVERFLOW  -6  /* more than 2^32-1 vertices or triangles          */
+
+typedef struct mc33hip_ctx mc33hip_ctx;
+
+/* Geometry of the (slab of the) grid one context works on.  Replaces the part of create_MC33 that
+ * snapshots _GRD (MC:1758-1782).  sample_bytes: 4 = float, 2 = unsigned short; it must match the
+ * library variant (libMC33_f32 / libMC33_u16). */
+typedef struct {
+	unsigned int npx, npy;      /* points per row / rows per plane                                       */
+	unsigned int npz_resident;  /* planes resident in this context                                        */
+	unsigned int plane0;        /* global z index of the first resident plane (0 for a whole grid)        */
+	unsigned int nz_total;      /* cell slices of the WHOLE grid (points along z - 1)                     */
+	double r0[3], d[3];         /* origin and spacing of the WHOLE grid (_GRD.r0, _GRD.d)                 */
+	int sample_bytes;
+	int device;                 /* HIP device ordinal, -1: current device                                 */
+} mc33hip_grid_desc;
+
+/* Work range of one extraction: cell slices [z_begin, z_end) are emitted; when ghost_below is non-zero
+ * slice z_begin-1 is classified too, so that ids of vertices on the slab interface - which belong to
+ * the rank below - can be resolved.  Single GPU: {0, nz_total, 0, 0}. */
+typedef struct {
+	unsigned int z_begin, z_end;
+	unsigned int ghost_below;
+	unsigned int id_base;       /* number of vertices created by all slices below z_begin (global numbering) */
+} mc33hip_range;
+
+typedef struct {
+	unsigned long long nV, nT;            /* vertices / triangles of slices [z_begin, z_end)                */
+	unsigned long long nV_ghost, nT_ghost;/* ... of the ghost slice (0 without ghost)                       */
+	unsigned long long active_cells;      /* cells cut by the surface in the classified slices             */
+} mc33hip_counts;
+
+typedef struct {
+	float sweep_ms, scan_ms, emit_ms;     /* hipEvent time of each pass of the last extraction, on its stream */
+	float total_ms;
+	unsigned int sweep_launches;          /* >1 if the work-record buffer had to grow and the sweep re-ran     */
+} mc33hip_timing;
+
+int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *desc);
+void mc33hip_destroy(mc33hip_ctx *c);
+const char *mc33hip_last_error(void);
+
+/* Grid upload: replaces "M->F = G->F" (MC:1792) - the reference re-reads host memory on every call,
+ * this library keeps a pitched copy in HBM.
+ *   upload_rows : F[k][j] row pointers exactly as _GRD.F holds them (rows may be separate mallocs,
+ *                 reference MC33_util_grd.c:147-169), k counts resident planes
+ *   adopt_device: use a caller-owned device buffer in place (no copy); pitch/slice in samples      */
+int mc33hip_upload_rows(mc33hip_ctx *c, const void *const *const *F);
+int mc33hip_upload_contiguous(mc33hip_ctx *c, const void *host_samples);
+int mc33hip_adopt_device(mc33hip_ctx *c, const void *device_samples, size_t pitch, size_t slice);
+
+/* Stream all work is enqueued on (a hipStream_t passed as void*; NULL = the default stream). */
+int mc33hip_set_stream(mc33hip_ctx *c, void *hip_stream);
+
+/* Count pass only: classification + prefix sums; the device twin of size_of_isosurface (MC:1892-1940).
+ * Synchronises the stream. */
+int mc33hip_count(mc33hip_ctx *c, float iso, const mc33hip_range *range, mc33hip_counts *out);
+
+/* Emit pass for the range last counted, into caller-owned DEVICE buffers:
+ * V, N: capV x 3 floats; T: capT x 3 unsigned.  Replaces the vertex/triangle appends of MC33_findCase
+ * (MC:780-1252).  Asynchronous on the context's stream. */
+int mc33hip_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long long capV, unsigned long long capT);
+
+/* Whole extraction (count + emit) with ONE synchronisation at the end; fails with MC33HIP_ECAPACITY
+ * (and reports the needed sizes in *out) when the buffers are too small.  This is the path
+ * calculate_isosurface (MC:1816-1889) and bench.py use. */
+int mc33hip_extract(mc33hip_ctx *c, float iso, const mc33hip_range *range, void *dV, void *dN, void *dT,
+                    unsigned long long capV, unsigned long long capT, mc33hip_counts *out);
+
+int mc33hip_last_timing(const mc33hip_ctx *c, mc33hip_timing *t);
+
+/* Device-to-host copy helper for callers without a HIP runtime of their own (blocking). */
+int mc33hip_download(mc33hip_ctx *c, void *host_dst, const void *device_src, size_t bytes);
+/* Plain device allocations on the context's device (for language bindings). */
+int mc33hip_device_alloc(mc33hip_ctx *c, void **dptr, size_t bytes);
+int mc33hip_device_free(mc33hip_ctx *c, void *dptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

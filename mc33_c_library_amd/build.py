@@ -1,0 +1,73 @@
+"""Build the two product libraries in-tree with hipcc (gfx950) + gcc.
+
+    mc33_c_library_amd/libMC33_f32.so   GRD_data_type = float
+    mc33_c_library_amd/libMC33_u16.so   GRD_data_type = unsigned short (-DINTEGER_GRD -DGRD_TYPE_SIZE=2)
+
+One library per grid sample type, like the reference's one-type-per-compile model
+(reference include/marching_cubes_33.h:57-88).  hipcc cross-compiles without a GPU.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+ROOT = os.path.dirname(PKG)
+BUILD = os.path.join(PKG, "_build")
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+GCC = os.environ.get("CC") or "gcc"
+
+# -ffp-contract=off: the reference's face / interior tests compare rounded products (MC:349-364, 436-445);
+# fusing a*b+c changes which sub-case is chosen.  Division and sqrt stay IEEE-correct (hipcc default).
+HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+C_FLAGS = ["-O2", "-ffp-contract=off", "-std=c11", "-fPIC", "-Wall", "-Wextra"]
+
+VARIANTS = {
+    "f32": {"hip": [], "c": []},
+    "u16": {"hip": ["-DMC33_GRD_U16"], "c": ["-DINTEGER_GRD", "-DGRD_TYPE_SIZE=2"]},
+}
+
+
+def lib_path(dtype):
+    return os.path.join(PKG, "libMC33_%s.so" % dtype)
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    print("+ " + " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build(dtype, force=False, verbose_resources=False):
+    os.makedirs(BUILD, exist_ok=True)
+    var = VARIANTS[dtype]
+    hip_src = os.path.join(CSRC, "mc33_kernels.hip")
+    c_src = os.path.join(CSRC, "mc33_capi.c")
+    deps = [hip_src, c_src] + [os.path.join(CSRC, f) for f in ("mc33_cell.h", "mc33_lut_data.h", "mc33_rules_data.h")] + [
+        os.path.join(ROOT, "include", f) for f in ("mc33_hip.h", "marching_cubes_33.h")] + [os.path.abspath(__file__)]
+    out = lib_path(dtype)
+    if not force and not _newer(out, deps):
+        return out
+    hip_obj = os.path.join(BUILD, "mc33_kernels_%s.o" % dtype)
+    c_obj = os.path.join(BUILD, "mc33_capi_%s.o" % dtype)
+    extra = ["-Rpass-analysis=kernel-resource-usage"] if verbose_resources else []
+    _run([HIPCC] + HIP_FLAGS + var["hip"] + extra + ["-c", hip_src, "-o", hip_obj])
+    _run([GCC] + C_FLAGS + var["c"] + ["-c", c_src, "-o", c_obj])
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", hip_obj, c_obj, "-o", out])
+    return out
+
+
+def build_all(force=False):
+    return [build(d, force) for d in VARIANTS]
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

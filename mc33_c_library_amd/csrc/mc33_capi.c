@@ -1,0 +1,335 @@
+/* mc33_capi.c -- host layer in C: the reference's public API (include/marching_cubes_33.h) on top of the
+ * device-level C ABI (include/mc33_hip.h).  No HIP types here; everything GPU-side happens behind
+ * mc33hip_*.  "MC:" = reference source/marching_cubes_33.c, "UTIL:" = reference source/MC33_util_grd.c.
+ *
+ * Behaviour kept from the reference:
+ *   - create_MC33 snapshots N, r0, d (MC:1758-1782) and returns NULL on failure (MC:1753-1757);
+ *   - calculate_isosurface returns a caller-owned `surface` whose T, V, N, color and the struct itself
+ *     are five separate malloc blocks (MC:84-92 frees them one by one); an empty result is a zeroed,
+ *     non-NULL surface (MC:1880-1883); failure is NULL with M->memoryfault = 1 (MC:1884-1887);
+ *   - every vertex gets DefaultColorMC (MC:1875-1877); S->user is left alone (MC:1873 copies 52 bytes).
+ * Deliberate difference: the grid is copied to HBM in create_MC33 and stays resident.  A caller that
+ * rewrites G->F between calls sets MC33_HIP_REUPLOAD=1 (re-upload before every extraction).
+ */
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/marching_cubes_33.h"
+#include "../../include/mc33_hip.h"
+
+/* layout contract with programs compiled against the reference header */
+_Static_assert(sizeof(_GRD) == 416 && offsetof(_GRD, d) == 48 && offsetof(_GRD, nonortho) == 96 &&
+               offsetof(_GRD, internal_data) == 252, "_GRD layout differs from the reference");
+_Static_assert(sizeof(surface) == 64 && offsetof(surface, iso) == 48 && offsetof(surface, user) == 56,
+               "surface layout differs from the reference");
+_Static_assert(sizeof(MC33) == 304 && offsetof(MC33, memoryfault) == 52 && offsetof(MC33, nx) == 96 &&
+               offsetof(MC33, Dx) == 264, "MC33 layout differs from the reference");
+
+#ifndef DEFAULT_SURFACE_COLOR
+#define DEFAULT_SURFACE_COLOR 0xff5c5c5c /* grey, 0xAABBGGRR (MC:76-78) */
+#endif
+int DefaultColorMC = (int)DEFAULT_SURFACE_COLOR;
+
+/* private object: the public MC33 first, so callers can keep treating the pointer as MC33* */
+typedef struct {
+	MC33 pub;
+	unsigned long long magic;
+	mc33hip_ctx *ctx;
+	_GRD *grid;          /* for MC33_HIP_REUPLOAD */
+	void *dV, *dN, *dT;  /* device staging of the last result, grown on demand */
+	unsigned long long capV, capT;
+	int reupload;
+} mc33_private;
+#define MC33_MAGIC 0x4D43333348495031ull /* "MC33HIP1" */
+
+static mc33_private *priv(MC33 *M) {
+	mc33_private *p = (mc33_private *)M;
+	return (p && p->magic == MC33_MAGIC) ? p : 0;
+}
+
+MC33 *create_MC33(_GRD *G) {
+	if (!G || !G->F)
+		return 0;
+	if (G->nonortho) /* inclined grids use MC33_spnC (MC:587-621): not accelerated yet */
+		return 0;
+	mc33_private *p = (mc33_private *)calloc(1, sizeof *p);
+	if (!p)
+		return 0;
+	p->magic = MC33_MAGIC;
+	MC33 *M = &p->pub;
+	M->nx = G->N[0]; M->ny = G->N[1]; M->nz = G->N[2];
+	M->F = (const GRD_data_type ***)G->F;
+	for (int j = 0; j != 3; j++) { /* MC:1779-1782 */
+		M->O[j] = (MC33_real)G->r0[j];
+		M->D[j] = (MC33_real)G->d[j];
+	}
+	if (G->d[0] != G->d[1] || G->d[1] != G->d[2]) { /* MC:1772-1775 */
+		M->ca = (MC33_real)(G->d[2] / G->d[0]);
+		M->cb = (MC33_real)(G->d[2] / G->d[1]);
+	}
+	mc33hip_grid_desc d;
+	memset(&d, 0, sizeof d);
+	d.npx = G->N[0] + 1; d.npy = G->N[1] + 1; d.npz_resident = G->N[2] + 1;
+	d.plane0 = 0; d.nz_total = G->N[2];
+	for (int j = 0; j != 3; j++) { d.r0[j] = G->r0[j]; d.d[j] = G->d[j]; }
+	d.sample_bytes = (int)sizeof(GRD_data_type);
+	d.device = -1;
+	const char *e = getenv("MC33_HIP_REUPLOAD");
+	p->reupload = e && *e && *e != '0';
+	p->grid = G;
+	if (G->N[0] < 1 || G->N[1] < 1 || G->N[2] < 1 || mc33hip_create(&p->ctx, &d) != MC33HIP_OK ||
+	    mc33hip_upload_rows(p->ctx, (const void *const *const *)G->F) != MC33HIP_OK) {
+		free_MC33(M);
+		return 0;
+	}
+	return M;
+}
+
+void free_MC33(MC33 *M) {
+	mc33_private *p = priv(M);
+	if (!p)
+		return;
+	if (p->ctx) {
+		if (p->dV) mc33hip_device_free(p->ctx, p->dV);
+		if (p->dN) mc33hip_device_free(p->ctx, p->dN);
+		if (p->dT) mc33hip_device_free(p->ctx, p->dT);
+		mc33hip_destroy(p->ctx);
+	}
+	p->magic = 0;
+	free(p);
+}
+
+static int refresh_grid(mc33_private *p) {
+	if (!p->reupload)
+		return 0;
+	return mc33hip_upload_rows(p->ctx, (const void *const *const *)p->grid->F);
+}
+
+unsigned long long size_of_isosurface(MC33 *M, MC33_real iso, unsigned int *nV, unsigned int *nT) {
+	mc33_private *p = priv(M);
+	mc33hip_counts cnt;
+	mc33hip_range r;
+	memset(&cnt, 0, sizeof cnt);
+	if (p) {
+		r.z_begin = 0; r.z_end = M->nz; r.ghost_below = 0; r.id_base = 0;
+		M->iso = iso;
+		if (refresh_grid(p) != MC33HIP_OK || mc33hip_count(p->ctx, iso, &r, &cnt) != MC33HIP_OK)
+			memset(&cnt, 0, sizeof cnt);
+	}
+	if (nV) *nV = (unsigned int)cnt.nV;
+	if (nT) *nT = (unsigned int)cnt.nT;
+	/* MC:1939 */
+	return cnt.nV * (6 * sizeof(MC33_real) + sizeof(int)) + cnt.nT * (3 * sizeof(int)) + sizeof(surface);
+}
+
+static int ensure_staging(mc33_private *p, unsigned long long nV, unsigned long long nT) {
+	if (p->capV < nV) {
+		if (p->dV) mc33hip_device_free(p->ctx, p->dV);
+		if (p->dN) mc33hip_device_free(p->ctx, p->dN);
+		p->dV = p->dN = 0; p->capV = 0;
+		unsigned long long cap = nV + nV / 8 + 1024;
+		if (mc33hip_device_alloc(p->ctx, &p->dV, cap * 12) != MC33HIP_OK) return -1;
+		if (mc33hip_device_alloc(p->ctx, &p->dN, cap * 12) != MC33HIP_OK) return -1;
+		p->capV = cap;
+	}
+	if (p->capT < nT) {
+		if (p->dT) mc33hip_device_free(p->ctx, p->dT);
+		p->dT = 0; p->capT = 0;
+		unsigned long long cap = nT + nT / 8 + 1024;
+		if (mc33hip_device_alloc(p->ctx, &p->dT, cap * 12) != MC33HIP_OK) return -1;
+		p->capT = cap;
+	}
+	return 0;
+}
+
+surface *calculate_isosurface(MC33 *M, MC33_real iso) {
+	mc33_private *p = priv(M);
+	if (!p)
+		return 0;
+	surface *S = (surface *)malloc(sizeof(surface));
+	if (!S)
+		return 0;
+	M->nT = M->nV = 0;
+	M->memoryfault = 0;
+	M->iso = iso;
+	mc33hip_range r;
+	r.z_begin = 0; r.z_end = M->nz; r.ghost_below = 0; r.id_base = 0;
+	mc33hip_counts cnt;
+	memset(&cnt, 0, sizeof cnt);
+	int rc = refresh_grid(p);
+	if (rc == MC33HIP_OK) {
+		/* one pass with the staging buffers of the previous call; if they are too small the counts
+		 * come back anyway, the buffers grow and only the emit pass is repeated */
+		rc = mc33hip_extract(p->ctx, iso, &r, p->dV, p->dN, p->dT, p->capV, p->capT, &cnt);
+		if (rc == MC33HIP_ECAPACITY) {
+			rc = ensure_staging(p, cnt.nV, cnt.nT) ? MC33HIP_ENOMEM
+			                                       : mc33hip_emit(p->ctx, p->dV, p->dN, p->dT, p->capV, p->capT);
+		}
+	}
+	if (rc != MC33HIP_OK) {
+		M->memoryfault = 1;
+		free(S);
+		return 0;
+	}
+	if (!cnt.nV) { /* MC:1880-1883 */
+		memset(S, 0, sizeof(surface));
+		return S;
+	}
+	const size_t nV = (size_t)cnt.nV, nT = (size_t)cnt.nT;
+	S->V = (MC33_real(*)[3])malloc(nV * 3 * sizeof(MC33_real));
+	S->N = (float(*)[3])malloc(nV * 3 * sizeof(float));
+	S->T = (unsigned int(*)[3])malloc((nT ? nT : 1) * 3 * sizeof(int));
+	S->color = (int *)malloc(nV * sizeof(int));
+	if (!S->V || !S->N || !S->T || !S->color ||
+	    mc33hip_download(p->ctx, S->V, p->dV, nV * 12) != MC33HIP_OK ||
+	    mc33hip_download(p->ctx, S->N, p->dN, nV * 12) != MC33HIP_OK ||
+	    mc33hip_download(p->ctx, S->T, p->dT, nT * 12) != MC33HIP_OK) {
+		free(S->V); free(S->N); free(S->T); free(S->color); free(S);
+		M->memoryfault = 1;
+		return 0;
+	}
+	const int col = DefaultColorMC;
+	for (size_t k = 0; k != nV; k++)
+		S->color[k] = col;
+	S->nV = (unsigned int)nV; S->nT = (unsigned int)nT;
+	S->capv = (unsigned int)nV; S->capt = (unsigned int)(nT ? nT : 1);
+	S->iso = iso;
+	/* mirror of the copy MC:1873 makes into the MC33 object's public prefix */
+	M->T = S->T; M->V = S->V; M->N = S->N; M->color = S->color;
+	M->nT = S->nT; M->capt = S->capt; M->capv = S->capv;
+	return S;
+}
+
+void free_surface_memory(surface *S) { /* MC:84-92 */
+	if (S) {
+		free(S->T); free(S->V); free(S->N); free(S->color);
+		free(S);
+	}
+}
+
+void adjustvectorlenght_s(surface *S) { /* MC:94-127: shrink the four arrays to nV / nT elements */
+	if (!S)
+		return;
+	if (S->capv > S->nV) {
+		void *c = malloc(sizeof(int) * (size_t)S->nV), *n = malloc(3 * sizeof(float) * (size_t)S->nV),
+		     *v = malloc(3 * sizeof(MC33_real) * (size_t)S->nV);
+		if (!c || !n || !v) { free(c); free(n); free(v); return; }
+		memcpy(c, S->color, sizeof(int) * (size_t)S->nV);
+		memcpy(n, S->N, 3 * sizeof(float) * (size_t)S->nV);
+		memcpy(v, S->V, 3 * sizeof(MC33_real) * (size_t)S->nV);
+		free(S->color); free(S->N); free(S->V);
+		S->color = (int *)c; S->N = (float(*)[3])n; S->V = (MC33_real(*)[3])v;
+		S->capv = S->nV;
+	}
+	if (S->capt > S->nT) {
+		void *t = malloc(3 * sizeof(int) * (size_t)S->nT);
+		if (!t) return;
+		memcpy(t, S->T, 3 * sizeof(int) * (size_t)S->nT);
+		free(S->T);
+		S->T = (unsigned int(*)[3])t;
+		S->capt = S->nT;
+	}
+}
+
+/* ---- grid container helpers (UTIL:125-169, 585-686), needed by callers that build grids ---------- */
+static void ident3(double (*A)[3]) {
+	for (int i = 0; i != 3; i++)
+		for (int j = 0; j != 3; j++)
+			A[i][j] = i == j ? 1.0 : 0.0;
+}
+
+void free_memory_grd(_GRD *Z) { /* UTIL:125-145 */
+	if (!Z)
+		return;
+	if (Z->F) {
+		for (unsigned int k = 0; k <= Z->N[2] && Z->F[k]; k++) {
+			if (Z->internal_data)
+				for (unsigned int j = 0; j <= Z->N[1]; j++)
+					free(Z->F[k][j]);
+			free(Z->F[k]);
+		}
+		free(Z->F);
+	}
+	free(Z);
+}
+
+int alloc_F(_GRD *Z) { /* UTIL:147-169: every row is its own allocation */
+	const size_t np = (size_t)Z->N[2] + 1, nr = (size_t)Z->N[1] + 1, nc = (size_t)Z->N[0] + 1;
+	Z->F = (GRD_data_type ***)calloc(np + 1, sizeof(void *)); /* one spare NULL terminates partial grids */
+	if (!Z->F)
+		return -1;
+	Z->internal_data = 1;
+	for (size_t k = 0; k != np; k++) {
+		Z->F[k] = (GRD_data_type **)calloc(nr, sizeof(void *));
+		if (!Z->F[k])
+			return -1;
+		for (size_t j = 0; j != nr; j++)
+			if (!(Z->F[k][j] = (GRD_data_type *)malloc(nc * sizeof(GRD_data_type))))
+				return -1;
+	}
+	return 0;
+}
+
+_GRD *grid_from_data_pointer(unsigned int Nx, unsigned int Ny, unsigned int Nz, GRD_data_type *data) { /* UTIL:585-627 */
+	if (!data || !Nx || !Ny || !Nz)
+		return 0;
+	_GRD *Z = (_GRD *)calloc(1, sizeof(_GRD));
+	if (!Z)
+		return 0;
+	Z->F = (GRD_data_type ***)calloc((size_t)Nz + 1, sizeof(void *));
+	if (!Z->F) { free(Z); return 0; }
+	Z->N[0] = Nx - 1; Z->N[1] = Ny - 1; Z->N[2] = Nz - 1;
+	for (unsigned int k = 0; k != Nz; k++) {
+		Z->F[k] = (GRD_data_type **)malloc((size_t)Ny * sizeof(void *));
+		if (!Z->F[k]) { free_memory_grd(Z); return 0; }
+		for (unsigned int j = 0; j != Ny; j++)
+			Z->F[k][j] = data + ((size_t)k * Ny + j) * Nx;
+	}
+	for (int i = 0; i != 3; i++) {
+		Z->L[i] = (float)Z->N[i];
+		Z->d[i] = 1.0;
+		Z->r0[i] = 0.0;
+		Z->Ang[i] = 90.0f;
+	}
+	ident3(Z->_A);
+	ident3(Z->A_);
+	return Z;
+}
+
+_GRD *generate_grid_from_fn(double xi, double yi, double zi, double xf, double yf, double zf, double dx, double dy,
+                            double dz, double (*fn)(double x, double y, double z)) { /* UTIL:630-686 */
+	if (dx <= 0 || dy <= 0 || dz <= 0 || xi == xf || yi == yf || zi == zf)
+		return 0;
+	double lo[3] = {xi, yi, zi}, hi[3] = {xf, yf, zf}, st[3] = {dx, dy, dz};
+	_GRD *Z = (_GRD *)calloc(1, sizeof(_GRD));
+	if (!Z)
+		return 0;
+	for (int i = 0; i != 3; i++) {
+		if (lo[i] > hi[i]) { double t = lo[i]; lo[i] = hi[i]; hi[i] = t; }
+		if (hi[i] - lo[i] < st[i]) st[i] = hi[i] - lo[i];
+		Z->N[i] = (unsigned int)(int)((hi[i] - lo[i]) / st[i] + 0.5); /* intervals, UTIL:649-651 */
+		Z->d[i] = st[i];
+		Z->r0[i] = lo[i];
+	}
+	if (alloc_F(Z)) { free_memory_grd(Z); return 0; }
+	if (fn) { /* coordinates advance by repeated addition, UTIL:660-672 */
+		double z = lo[2];
+		for (unsigned int k = 0; k <= Z->N[2]; k++, z += st[2]) {
+			double y = lo[1];
+			for (unsigned int j = 0; j <= Z->N[1]; j++, y += st[1]) {
+				double x = lo[0];
+				GRD_data_type *row = Z->F[k][j];
+				for (unsigned int i = 0; i <= Z->N[0]; i++, x += st[0])
+					row[i] = (GRD_data_type)fn(x, y, z);
+			}
+		}
+	}
+	for (int i = 0; i != 3; i++) {
+		Z->L[i] = (float)(Z->N[i] * Z->d[i]);
+		Z->Ang[i] = 90.0f;
+	}
+	ident3(Z->_A);
+	ident3(Z->A_);
+	return Z;
+}

@@ -37,6 +37,7 @@ constexpr uint32_t NO_ID = 0xFFFFFFFFu;
 struct Params {
 	uint32_t nx, ny, nz;  // cells per axis (= _GRD.N, marching_cubes_33.h:113)
 	uint32_t nseg;        // row segments per row = ceil(nx / SEG_CELLS)
+	uint32_t zs;          // first cell slice this launch covers (row-segment records are relative to it)
 	float iso;
 	float O[3], D[3];     // float copies of r0, d (MC:1779-1782)
 	float ca, cb;         // MC:1773-1774
@@ -50,11 +51,12 @@ struct Tables {
 };
 
 template <typename T>
-struct GridView {  // pitched copy of _GRD.F in HBM: sample (x,y,z) at p[z*slice + y*pitch + x]
+struct GridView {  // pitched copy of _GRD.F in HBM: sample (x,y,z) at p[(z-z0)*slice + y*pitch + x]
 	const T *p;
-	uint32_t pitch;
-	uint64_t slice;
-	MC33_HD T at(uint32_t x, uint32_t y, uint32_t z) const { return p[(uint64_t)z * slice + (uint64_t)y * pitch + x]; }
+	uint32_t pitch;  // samples per row (>= nx+1)
+	uint32_t z0;     // global index of the first resident plane (0 unless the volume is z-slabbed over GPUs)
+	uint64_t slice;  // samples per plane
+	MC33_HD T at(uint32_t x, uint32_t y, uint32_t z) const { return p[(uint64_t)(z - z0) * slice + (uint64_t)y * pitch + x]; }
 };
 
 MC33_HD float sample_diff(float a, float b) { return a - b; }
@@ -539,7 +541,7 @@ MC33_HD uint32_t entry_rank(const Entry &e, uint32_t edge) {
 }
 
 MC33_HD uint64_t segment_index(const Params &P, uint32_t x, uint32_t y, uint32_t z) {
-	return ((uint64_t)z * P.ny + y) * P.nseg + x / SEG_CELLS;
+	return ((uint64_t)(z - P.zs) * P.ny + y) * P.nseg + x / SEG_CELLS;
 }
 
 template <typename T>
@@ -555,6 +557,10 @@ struct EmitCtx {
 	const uint32_t *entry_seg;  // row segment of each entry
 	float *V, *N;
 	uint32_t *Tri;
+	// z-slab decomposition: cells below z_emit are ghosts (counted so that ids of the slab interface
+	// can be looked up, but written by the rank below); local vertex k is stored at k - v_skip and is
+	// known globally as k + id_delta; local triangle k is stored at k - t_skip.
+	uint32_t z_emit, v_skip, t_skip, id_delta;
 };
 
 // per-segment counts packed in one word: vertices (<= 13*256) | triangles (<= 12*256) << 16
@@ -596,10 +602,11 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 	const Entry en = c.entries[entry_index];
 	const uint32_t s = c.entry_seg[entry_index];
 	const uint32_t sx = s % c.P.nseg, row = s / c.P.nseg;
-	const uint32_t y = row % c.P.ny, z = row / c.P.ny;
+	const uint32_t y = row % c.P.ny, z = row / c.P.ny + c.P.zs;
+	if (z < c.z_emit) return;
 	const uint32_t x = sx * SEG_CELLS + (en.w0 & 0xFFu);
 	const uint32_t vbase = c.seg_vbase[s] + (en.w1 & 0xFFFFu);
-	uint32_t tpos = c.seg_tbase[s] + (en.w1 >> 16);
+	uint32_t tpos = c.seg_tbase[s] + (en.w1 >> 16) - c.t_skip;
 	const uint32_t i = load_cell(c.G, c.P.iso, x, y, z, v);
 	CellPlan p;
 	plan_cell(p, c.tab, c.P, c.G, x, y, z, i, v);
@@ -617,7 +624,7 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 					vertex_on_point(c.P, c.G, x + (cc & 1), y + ((cc >> 1) & 1), z + (cc >> 2), g);
 				} else
 					vertex_on_edge(c.P, c.G, x, y, z, e, v, g);
-				store_vertex(c.P, g, c.V, c.N, vbase + r);
+				store_vertex(c.P, g, c.V, c.N, vbase + r - c.v_skip);
 			}
 		} else
 			ids[(int)e] = edge_vertex_id(c, tgt_edge(plan_tgt(p, e), x, y, z), w);
@@ -631,7 +638,7 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 		ti[0] = ids[(int)((word >> 8) & 15u)];
 		if (ti[0] != ti[1] && ti[0] != ti[2] && ti[1] != ti[2]) {
 			uint32_t *t = c.Tri + 3 * (uint64_t)tpos++;
-			t[0] = p.n ? ti[1] : ti[0]; t[1] = p.m ? ti[1] : ti[0]; t[2] = ti[2];
+			t[0] = (p.n ? ti[1] : ti[0]) + c.id_delta; t[1] = (p.m ? ti[1] : ti[0]) + c.id_delta; t[2] = ti[2] + c.id_delta;
 		}
 	} while (word >> 12);
 }

@@ -1,0 +1,765 @@
+// mc33_kernels.hip -- HIP kernels (gfx950 / CDNA4, wave64) and the device-level C ABI (include/mc33_hip.h)
+// of the MI355X Marching Cubes 33 extractor.  One shared object per grid sample type, like the
+// reference's one-type-per-compile model (reference include/marching_cubes_33.h:57-88):
+//     default            -> float samples          (libMC33_f32.so)
+//     -DMC33_GRD_U16     -> unsigned short samples  (libMC33_u16.so)
+//
+// Passes ("MC:" = reference source/marching_cubes_33.c):
+//   k_sweep  - streams the volume once (MC:1832-1868): sign bit per sample by wave ballot, the bit
+//              rows of a 64-row x 256-sample tile are parked one row per LANE, so that the all-equal
+//              test of every cell of a tile slice is a handful of 64-bit logic ops; only cells cut
+//              by the surface are classified (MC:683-779) and planned; per row segment it leaves
+//              (#new vertices, #triangles) and one 16-byte work record per active cell.
+//   k_scan_* - exclusive prefix sums over the row segments in the reference's sweep order: this IS the
+//              reference's vertex/triangle numbering.
+//   k_emit   - one thread per active cell: interpolated vertices + normals (MC:810-1230, 485-585),
+//              vertex ids of shared edges through the owner cell's record, triangles (MC:1235-1250).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/mc33_hip.h"
+#include "mc33_cell.h"
+#include "mc33_lut_data.h"
+#include "mc33_rules_data.h"
+
+using namespace mc33;
+
+#ifdef MC33_GRD_U16
+typedef uint16_t sample_t;
+#define MC33_SAMPLE_BYTES 2
+#else
+typedef float sample_t;
+#define MC33_SAMPLE_BYTES 4
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// device-side bookkeeping
+// ---------------------------------------------------------------------------------------------------
+struct Counters {
+	uint32_t entry_cursor;  // work records requested by the sweep (may exceed the capacity)
+	uint32_t emit_skipped;  // set by k_emit when it refused to run (capacity / overflow)
+	uint64_t totV, totT;    // totals over all classified slices (ghost included)
+	uint64_t ghostV, ghostT;
+};
+
+struct SweepArgs {
+	GridView<sample_t> G;
+	Params P;
+	Tables tab;
+	uint32_t ze;             // classify cell slices [P.zs, ze)
+	uint32_t nXG, nYT, rz;   // tiles: 4 segments wide, 63 cell rows high, rz slices deep
+	uint32_t *seg_cnt, *seg_first, *seg_nent;
+	Entry *entries;
+	uint32_t *entry_seg;
+	uint32_t entry_cap;
+	Counters *ctr;
+};
+
+__device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return (uint64_t)hi << 32 | lo; }
+
+// ---------------------------------------------------------------------------------------------------
+// k_sweep: one wave per tile column (256 samples in x, 64 sample rows, rz+1 planes), 4 waves per block
+// side by side in x so that a block reads whole 1024-sample (4 KiB) row pieces.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
+	__shared__ float s_v[4][8][64];
+	__shared__ float s_w[4][8][64];
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	uint32_t b = blockIdx.x;
+	const uint32_t xg = b % a.nXG;
+	b /= a.nXG;
+	const uint32_t yt = b % a.nYT, zc = b / a.nYT;
+	const uint32_t seg = xg * 4 + wv;
+	const Params &P = a.P;
+	if (seg >= P.nseg) return;  // no block-level barrier is used below
+	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
+	const uint32_t nrows = min(64u, P.ny + 1 - y0);  // sample rows of this tile
+	const uint32_t z_lo = P.zs + zc * a.rz, z_hi = min(z_lo + a.rz, a.ze);
+	const float iso = P.iso;
+
+	// per-lane x offsets of its four samples (clamped into the row: bits of samples beyond the grid
+	// belong to cells that the valid masks remove)
+	uint32_t xo[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) xo[k] = min(xbase + 64u * k + lane, P.nx);
+	const uint32_t xh = min(xbase + SEG_CELLS, P.nx);  // halo sample (first sample of the next segment)
+	uint64_t valid[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const uint32_t first = xbase + 64u * k;
+		const uint32_t n = first >= P.nx ? 0u : min(64u, P.nx - first);
+		valid[k] = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+	}
+	const bool rowvalid = lane < 63u && y0 + lane < P.ny;
+	const uint32_t rowclamp = min(lane, nrows - 1);
+
+	// sign bits of the tile: word k of row r lives in lane r
+	uint32_t cur_lo[4], cur_hi[4], prev_lo[4] = {0, 0, 0, 0}, prev_hi[4] = {0, 0, 0, 0};
+	uint32_t cur_h = 0, prev_h = 0;
+	const VRef v{&s_v[wv][0][lane], 64}, w{&s_w[wv][0][lane], 64};
+
+	for (uint32_t p = z_lo; p <= z_hi; ++p) {
+		const sample_t *plane = a.G.p + (uint64_t)(p - a.G.z0) * a.G.slice + (uint64_t)y0 * a.G.pitch;
+#pragma unroll
+		for (int k = 0; k < 4; k++) cur_lo[k] = cur_hi[k] = 0;
+		for (uint32_t r = 0; r < nrows; r += 4) {
+			float d[4][4];
+#pragma unroll
+			for (int rr = 0; rr < 4; rr++) {
+				const sample_t *row = plane + (uint64_t)min(r + rr, nrows - 1) * a.G.pitch;
+#pragma unroll
+				for (int k = 0; k < 4; k++) d[rr][k] = iso - (float)row[xo[k]];  // MC:1852-1855
+			}
+#pragma unroll
+			for (int rr = 0; rr < 4; rr++) {
+				const bool mine = lane == r + rr;  // the bit row of sample row r+rr is parked in lane r+rr
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const uint64_t m = __ballot(__float_as_uint(d[rr][k]) >> 31);  // MC:1856-1859
+					cur_lo[k] = mine ? (uint32_t)m : cur_lo[k];
+					cur_hi[k] = mine ? (uint32_t)(m >> 32) : cur_hi[k];
+				}
+			}
+		}
+		// halo column: lane r reads sample xh of row r
+		cur_h = __float_as_uint(iso - (float)plane[(uint64_t)rowclamp * a.G.pitch + xh]) >> 31;
+
+		if (p > z_lo) {
+			const uint32_t z = p - 1;
+			// AND / OR of the four samples (y,z),(y+1,z),(y,z+1),(y+1,z+1) at every x of the segment
+			uint64_t A[4], O[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const uint64_t q0 = u64(prev_lo[k], prev_hi[k]), q1 = u64(cur_lo[k], cur_hi[k]);
+				const uint64_t q0n = u64(__shfl_down(prev_lo[k], 1), __shfl_down(prev_hi[k], 1));
+				const uint64_t q1n = u64(__shfl_down(cur_lo[k], 1), __shfl_down(cur_hi[k], 1));
+				A[k] = q0 & q0n & q1 & q1n;
+				O[k] = q0 | q0n | q1 | q1n;
+			}
+			const uint32_t ph = __shfl_down(prev_h, 1), ch = __shfl_down(cur_h, 1);
+			const uint64_t hA = prev_h & ph & cur_h & ch, hO = prev_h | ph | cur_h | ch;
+			uint64_t act[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const uint64_t nA = (k < 3) ? (A[k < 3 ? k + 1 : 3] & 1ull) : hA;
+				const uint64_t nO = (k < 3) ? (O[k < 3 ? k + 1 : 3] & 1ull) : hO;
+				const uint64_t As = (A[k] >> 1) | (nA << 63), Os = (O[k] >> 1) | (nO << 63);
+				// a cell is skipped when its 8 sign bits are all ones or all zeros (MC:1860)
+				act[k] = rowvalid ? (~((A[k] & As) | ~(O[k] | Os)) & valid[k]) : 0ull;
+			}
+			const uint32_t cnt = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
+			uint32_t incl = cnt;
+#pragma unroll
+			for (int dlt = 1; dlt < 64; dlt <<= 1) {
+				const uint32_t t = __shfl_up(incl, dlt);
+				if ((int)lane >= dlt) incl += t;
+			}
+			const uint32_t total = __shfl(incl, 63);
+			uint32_t base = 0;
+			if (total) {
+				if (lane == 0) base = atomicAdd(&a.ctr->entry_cursor, total);
+				base = __shfl(base, 0);
+			}
+			const uint32_t y = y0 + lane;
+			const uint64_t sidx = ((uint64_t)(z - P.zs) * P.ny + y) * P.nseg + seg;
+			uint32_t idx = base + incl - cnt, nv_run = 0, nt_run = 0;
+			const uint32_t first = idx;
+			for (;;) {
+				const bool has = (act[0] | act[1] | act[2] | act[3]) != 0ull;
+				if (!__any(has)) break;
+				if (has) {
+					uint32_t xl;
+					if (act[0]) { xl = (uint32_t)__ffsll((long long)act[0]) - 1u; act[0] &= act[0] - 1; }
+					else if (act[1]) { xl = 64u + (uint32_t)__ffsll((long long)act[1]) - 1u; act[1] &= act[1] - 1; }
+					else if (act[2]) { xl = 128u + (uint32_t)__ffsll((long long)act[2]) - 1u; act[2] &= act[2] - 1; }
+					else { xl = 192u + (uint32_t)__ffsll((long long)act[3]) - 1u; act[3] &= act[3] - 1; }
+					const uint32_t x = xbase + xl;
+					const uint32_t i = load_cell(a.G, iso, x, y, z, v);
+					CellPlan pl;
+					plan_cell(pl, a.tab, P, a.G, x, y, z, i, v);
+					const uint32_t nt = count_triangles(pl, a.tab, P, a.G, x, y, z, w);
+					if (idx < a.entry_cap) {
+						a.entries[idx] = make_entry(xl, i, pl, nv_run, nt_run);
+						a.entry_seg[idx] = (uint32_t)sidx;
+					}
+					idx++;
+					nv_run += pl.nnew;
+					nt_run += nt;
+				}
+			}
+			if (rowvalid) {
+				a.seg_cnt[sidx] = seg_pack(nv_run, nt_run);
+				a.seg_first[sidx] = first;
+				a.seg_nent[sidx] = cnt;
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 4; k++) { prev_lo[k] = cur_lo[k]; prev_hi[k] = cur_hi[k]; }
+		prev_h = cur_h;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------
+// prefix sums over the row segments (sweep order)
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t SCAN_PER_THREAD = 8, SCAN_CHUNK = 256 * SCAN_PER_THREAD;
+
+__device__ __forceinline__ uint64_t wave_sum(uint64_t x) {
+#pragma unroll
+	for (int d = 32; d; d >>= 1) x += __shfl_xor(x, d);
+	return x;
+}
+
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, uint64_t n, uint64_t *bsV, uint64_t *bsT) {
+	__shared__ uint64_t sv[4], st[4];
+	const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
+	uint64_t v = 0, t = 0;
+	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
+		const uint64_t q = base + (uint64_t)k * 256 + threadIdx.x;
+		if (q < n) { const uint32_t c = seg_cnt[q]; v += c & 0xFFFFu; t += c >> 16; }
+	}
+	v = wave_sum(v); t = wave_sum(t);
+	if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; st[threadIdx.x >> 6] = t; }
+	__syncthreads();
+	if (threadIdx.x == 0) { bsV[blockIdx.x] = sv[0] + sv[1] + sv[2] + sv[3]; bsT[blockIdx.x] = st[0] + st[1] + st[2] + st[3]; }
+}
+
+// one block: exclusive scan of the per-chunk sums, totals into the counters
+__global__ __launch_bounds__(1024) void k_scan_spine(uint64_t *bsV, uint64_t *bsT, uint32_t nb, Counters *ctr) {
+	__shared__ uint64_t pv[1024], pt[1024];
+	const uint32_t per = (nb + 1023u) / 1024u, lo = threadIdx.x * per, hi = min(lo + per, nb);
+	uint64_t v = 0, t = 0;
+	for (uint32_t k = lo; k < hi; k++) { v += bsV[k]; t += bsT[k]; }
+	pv[threadIdx.x] = v; pt[threadIdx.x] = t;
+	__syncthreads();
+	for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan in LDS
+		uint64_t av = 0, at = 0;
+		if (threadIdx.x >= d) { av = pv[threadIdx.x - d]; at = pt[threadIdx.x - d]; }
+		__syncthreads();
+		pv[threadIdx.x] += av; pt[threadIdx.x] += at;
+		__syncthreads();
+	}
+	uint64_t ev = pv[threadIdx.x] - v, et = pt[threadIdx.x] - t;
+	for (uint32_t k = lo; k < hi; k++) {
+		const uint64_t cv = bsV[k], ct = bsT[k];
+		bsV[k] = ev; bsT[k] = et;
+		ev += cv; et += ct;
+	}
+	if (threadIdx.x == 1023) { ctr->totV = pv[1023]; ctr->totT = pt[1023]; }
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uint64_t n, const uint64_t *bsV, const uint64_t *bsT,
+                                                    uint32_t *seg_vbase, uint32_t *seg_tbase, uint64_t ghost_segs, Counters *ctr) {
+	__shared__ uint32_t sv[4], st[4];
+	const uint64_t q0 = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+	uint32_t cv[SCAN_PER_THREAD], ct[SCAN_PER_THREAD], v = 0, t = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
+		const uint32_t c = (q0 + k < n) ? seg_cnt[q0 + k] : 0u;
+		cv[k] = c & 0xFFFFu; ct[k] = c >> 16;
+		v += cv[k]; t += ct[k];
+	}
+	uint32_t iv = v, it = t;
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t a = __shfl_up(iv, d), b = __shfl_up(it, d);
+		if ((int)lane >= d) { iv += a; it += b; }
+	}
+	if (lane == 63) { sv[wv] = iv; st[wv] = it; }
+	__syncthreads();
+	uint32_t ev = (uint32_t)bsV[blockIdx.x] + iv - v, et = (uint32_t)bsT[blockIdx.x] + it - t;
+	for (uint32_t k = 0; k < wv; k++) { ev += sv[k]; et += st[k]; }
+#pragma unroll
+	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
+		if (q0 + k < n) {
+			seg_vbase[q0 + k] = ev; seg_tbase[q0 + k] = et;
+			if (q0 + k == ghost_segs) { ctr->ghostV = ev; ctr->ghostT = et; }  // first segment of the emitted range
+		}
+		ev += cv[k]; et += ct[k];
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_emit: one thread per work record
+// ---------------------------------------------------------------------------------------------------
+struct EmitArgs {
+	EmitCtx<sample_t> c;
+	Counters *ctr;
+	uint32_t entry_cap;
+	uint64_t capV, capT;
+	uint64_t ghost_segs;  // row segments of the ghost slice (0 without ghost)
+	uint32_t id_base;
+};
+
+__global__ __launch_bounds__(256) void k_emit(const EmitArgs a) {
+	__shared__ float s_v[8][256];
+	__shared__ float s_w[8][256];
+	__shared__ uint32_t s_id[13][256];
+	const Counters ctr = *a.ctr;
+	const uint64_t gV = a.ghost_segs ? ctr.ghostV : 0, gT = a.ghost_segs ? ctr.ghostT : 0;
+	if (ctr.entry_cursor > a.entry_cap || ctr.totV - gV > a.capV || ctr.totT - gT > a.capT || ctr.totV > 0xFFFFFFFFull ||
+	    ctr.totT > 0xFFFFFFFFull || (uint64_t)a.id_base + (ctr.totV - gV) > 0xFFFFFFFFull) {
+		if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->emit_skipped = 1;
+		return;
+	}
+	EmitCtx<sample_t> c = a.c;
+	c.v_skip = (uint32_t)gV;
+	c.t_skip = (uint32_t)gT;
+	c.id_delta = a.id_base - (uint32_t)gV;
+	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
+	const URef ids{&s_id[0][threadIdx.x], 256};
+	const uint32_t n = ctr.entry_cursor;
+	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) emit_cell(c, e, v, w, ids);
+}
+
+// ===================================================================================================
+// Host side: context, uploads, launches (C ABI of include/mc33_hip.h)
+// ===================================================================================================
+static thread_local char g_err[512] = "";
+static void set_err(const char *fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	if (getenv("MC33_HIP_VERBOSE")) fprintf(stderr, "[mc33hip] %s\n", g_err);
+}
+#define HIP_TRY(expr)                                                                         \
+	do {                                                                                      \
+		hipError_t e_ = (expr);                                                               \
+		if (e_ != hipSuccess) {                                                               \
+			set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return e_ == hipErrorOutOfMemory ? MC33HIP_ENOMEM : MC33HIP_ERUNTIME;             \
+		}                                                                                     \
+	} while (0)
+
+struct mc33hip_ctx {
+	mc33hip_grid_desc desc;
+	int device;
+	hipStream_t stream;
+	sample_t *d_grid;
+	bool owns_grid;
+	size_t pitch, slice;  // in samples
+	uint16_t *d_lut;
+	uint32_t *d_rules;
+	uint8_t *d_rule_index;
+	uint32_t *seg_cnt, *seg_first, *seg_nent, *seg_vbase, *seg_tbase;
+	uint64_t seg_cap;
+	uint64_t *bsV, *bsT;
+	uint64_t bs_cap;
+	Entry *entries;
+	uint32_t *entry_seg;
+	uint64_t entry_cap;
+	Counters *d_ctr, *h_ctr;
+	hipEvent_t ev[4];
+	// state of the last count
+	bool counted;
+	Params P;
+	mc33hip_range range;
+	uint64_t nsegs, ghost_segs;
+	mc33hip_counts counts;
+	mc33hip_timing timing;
+};
+
+extern "C" const char *mc33hip_last_error(void) { return g_err; }
+
+static int use_device(mc33hip_ctx *c) {
+	HIP_TRY(hipSetDevice(c->device));
+	return 0;
+}
+
+extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
+	if (!out || !d) return MC33HIP_EINVAL;
+	*out = nullptr;
+	if (d->sample_bytes != MC33_SAMPLE_BYTES) { set_err("sample_bytes %d does not match this library (%d)", d->sample_bytes, MC33_SAMPLE_BYTES); return MC33HIP_EINVAL; }
+	if (d->npx < 2 || d->npy < 2 || d->npz_resident < 2 || d->nz_total < 1) { set_err("grid needs at least 2 points per axis"); return MC33HIP_EINVAL; }
+	if ((uint64_t)d->plane0 + d->npz_resident > (uint64_t)d->nz_total + 1) { set_err("resident planes exceed the grid"); return MC33HIP_EINVAL; }
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err("no HIP device available"); return MC33HIP_ENOGPU; }
+	mc33hip_ctx *c = (mc33hip_ctx *)calloc(1, sizeof *c);
+	if (!c) return MC33HIP_ENOMEM;
+	c->desc = *d;
+	if (d->device >= 0) c->device = d->device;
+	else if (hipGetDevice(&c->device) != hipSuccess) { free(c); set_err("hipGetDevice failed"); return MC33HIP_ENOGPU; }
+	*out = c;
+	int rc = use_device(c);
+	if (rc) { free(c); *out = nullptr; return rc; }
+	c->pitch = ((size_t)d->npx + 3) & ~(size_t)3;  // rows start 16-byte aligned for float samples
+	c->slice = c->pitch * d->npy;
+	hipError_t e;
+#define CREATE_TRY(expr)                                                                    \
+	if ((e = (expr)) != hipSuccess) {                                                       \
+		set_err("%s failed: %s", #expr, hipGetErrorString(e));                              \
+		mc33hip_destroy(c);                                                                 \
+		*out = nullptr;                                                                     \
+		return e == hipErrorOutOfMemory ? MC33HIP_ENOMEM : MC33HIP_ERUNTIME;                \
+	}
+	CREATE_TRY(hipMalloc(&c->d_lut, sizeof mc33_lut));
+	CREATE_TRY(hipMalloc(&c->d_rules, sizeof mc33_rule_words));
+	CREATE_TRY(hipMalloc(&c->d_rule_index, sizeof mc33_rule_index));
+	CREATE_TRY(hipMemcpy(c->d_lut, mc33_lut, sizeof mc33_lut, hipMemcpyHostToDevice));
+	CREATE_TRY(hipMemcpy(c->d_rules, mc33_rule_words, sizeof mc33_rule_words, hipMemcpyHostToDevice));
+	CREATE_TRY(hipMemcpy(c->d_rule_index, mc33_rule_index, sizeof mc33_rule_index, hipMemcpyHostToDevice));
+	CREATE_TRY(hipMalloc(&c->d_ctr, sizeof(Counters)));
+	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
+	for (int k = 0; k < 4; k++) CREATE_TRY(hipEventCreate(&c->ev[k]));
+#undef CREATE_TRY
+	return MC33HIP_OK;
+}
+
+extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	else (void)hipDeviceSynchronize();
+	if (c->owns_grid) (void)hipFree(c->d_grid);
+	(void)hipFree(c->d_lut); (void)hipFree(c->d_rules); (void)hipFree(c->d_rule_index);
+	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_first); (void)hipFree(c->seg_nent);
+	(void)hipFree(c->seg_vbase); (void)hipFree(c->seg_tbase);
+	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
+	(void)hipFree(c->entries); (void)hipFree(c->entry_seg);
+	(void)hipFree(c->d_ctr);
+	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
+	free(c);
+}
+
+extern "C" int mc33hip_set_stream(mc33hip_ctx *c, void *s) {
+	if (!c) return MC33HIP_EINVAL;
+	c->stream = (hipStream_t)s;
+	return MC33HIP_OK;
+}
+
+static int ensure_grid(mc33hip_ctx *c) {
+	if (c->d_grid && c->owns_grid) return 0;
+	if (c->d_grid && !c->owns_grid) { c->d_grid = nullptr; }
+	c->pitch = ((size_t)c->desc.npx + 3) & ~(size_t)3;
+	c->slice = c->pitch * c->desc.npy;
+	// +64 samples of slack: tile loads clamp their addresses into the row, never past the buffer
+	HIP_TRY(hipMalloc(&c->d_grid, (c->slice * c->desc.npz_resident + 64) * sizeof(sample_t)));
+	c->owns_grid = true;
+	return 0;
+}
+
+extern "C" int mc33hip_upload_contiguous(mc33hip_ctx *c, const void *host) {
+	if (!c || !host) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	if ((rc = ensure_grid(c))) return rc;
+	const size_t rowb = (size_t)c->desc.npx * sizeof(sample_t);
+	HIP_TRY(hipMemcpy2D(c->d_grid, c->pitch * sizeof(sample_t), host, rowb, rowb, (size_t)c->desc.npy * c->desc.npz_resident,
+	                    hipMemcpyHostToDevice));
+	c->counted = false;
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_upload_rows(mc33hip_ctx *c, const void *const *const *F) {
+	if (!c || !F) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	if ((rc = ensure_grid(c))) return rc;
+	const uint32_t npx = c->desc.npx, npy = c->desc.npy, npz = c->desc.npz_resident;
+	const size_t rowb = (size_t)npx * sizeof(sample_t);
+	// fast path: rows laid out back to back (grid_from_data_pointer, reference MC33_util_grd.c:609-611)
+	bool contiguous = true;
+	const char *expect = (const char *)F[0][0];
+	for (uint32_t k = 0; k < npz && contiguous; k++)
+		for (uint32_t j = 0; j < npy; j++, expect += rowb)
+			if ((const char *)F[k][j] != expect) { contiguous = false; break; }
+	if (contiguous) return mc33hip_upload_contiguous(c, F[0][0]);
+	// rows are separate allocations (alloc_F, reference MC33_util_grd.c:147-169): pack them through a
+	// pinned staging buffer, one plane group at a time
+	const size_t planeb = c->slice * sizeof(sample_t);
+	size_t planes_per = (64u << 20) / planeb;
+	if (planes_per < 1) planes_per = 1;
+	char *stage = nullptr;
+	HIP_TRY(hipHostMalloc(&stage, planes_per * planeb, hipHostMallocDefault));
+	for (uint32_t k0 = 0; k0 < npz; k0 += (uint32_t)planes_per) {
+		const uint32_t kn = (uint32_t)((k0 + planes_per <= npz) ? planes_per : npz - k0);
+		for (uint32_t k = 0; k < kn; k++)
+			for (uint32_t j = 0; j < npy; j++)
+				memcpy(stage + k * planeb + (size_t)j * c->pitch * sizeof(sample_t), F[k0 + k][j], rowb);
+		hipError_t e = hipMemcpy((char *)c->d_grid + (size_t)k0 * planeb, stage, (size_t)kn * planeb, hipMemcpyHostToDevice);
+		if (e != hipSuccess) { (void)hipHostFree(stage); set_err("grid upload failed: %s", hipGetErrorString(e)); return MC33HIP_ERUNTIME; }
+	}
+	(void)hipHostFree(stage);
+	c->counted = false;
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_adopt_device(mc33hip_ctx *c, const void *dptr, size_t pitch, size_t slice) {
+	if (!c || !dptr || pitch < c->desc.npx || slice < pitch * c->desc.npy) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	if (c->owns_grid) (void)hipFree(c->d_grid);
+	c->d_grid = (sample_t *)dptr;
+	c->owns_grid = false;
+	c->pitch = pitch;
+	c->slice = slice;
+	c->counted = false;
+	return MC33HIP_OK;
+}
+
+static int check_range(mc33hip_ctx *c, const mc33hip_range *r) {
+	const mc33hip_grid_desc &d = c->desc;
+	if (!r || r->z_begin >= r->z_end || r->z_end > d.nz_total) { set_err("bad z range"); return MC33HIP_EINVAL; }
+	if (r->ghost_below && r->z_begin == 0) { set_err("ghost slice below z = 0"); return MC33HIP_EINVAL; }
+	const uint32_t zs = r->z_begin - (r->ghost_below ? 1u : 0u);
+	// planes the passes touch: cells need planes z and z+1; normals read z+2 (MC:888, 1036, 1182, 1217)
+	// when it exists, and z-1 for vertices on grid points (MC:643-647, 836, 909, 980, 1058)
+	const uint32_t lo = zs ? zs - 1 : 0, hi = (r->z_end + 1 <= d.nz_total) ? r->z_end + 1 : d.nz_total;
+	if (lo < d.plane0 || hi > d.plane0 + d.npz_resident - 1) {
+		set_err("range needs planes %u..%u, resident are %u..%u", lo, hi, d.plane0, d.plane0 + d.npz_resident - 1);
+		return MC33HIP_EINVAL;
+	}
+	if (!c->d_grid) { set_err("no grid uploaded"); return MC33HIP_EINVAL; }
+	return 0;
+}
+
+static void fill_params(mc33hip_ctx *c, float iso, const mc33hip_range *r) {
+	const mc33hip_grid_desc &d = c->desc;
+	Params &P = c->P;
+	P.nx = d.npx - 1; P.ny = d.npy - 1; P.nz = d.nz_total;
+	P.nseg = (P.nx + SEG_CELLS - 1) / SEG_CELLS;
+	P.zs = r->z_begin - (r->ghost_below ? 1u : 0u);
+	P.iso = iso;
+	// store selection and float copies: MC:1772-1782
+	if (d.d[0] != d.d[1] || d.d[1] != d.d[2]) { P.store_mode = 2; P.ca = (float)(d.d[2] / d.d[0]); P.cb = (float)(d.d[2] / d.d[1]); }
+	else { P.store_mode = (d.d[0] == 1 && d.r0[0] == 0 && d.r0[1] == 0 && d.r0[2] == 0) ? 0 : 1; P.ca = P.cb = 1.0f; }
+	for (int k = 0; k < 3; k++) { P.O[k] = (float)d.r0[k]; P.D[k] = (float)d.d[k]; }
+	c->range = *r;
+	c->nsegs = (uint64_t)(r->z_end - P.zs) * P.ny * P.nseg;
+	c->ghost_segs = r->ghost_below ? (uint64_t)P.ny * P.nseg : 0;
+}
+
+static uint32_t env_u32(const char *name, uint32_t dflt) {
+	const char *s = getenv(name);
+	if (!s || !*s) return dflt;
+	long v = strtol(s, nullptr, 10);
+	return v > 0 ? (uint32_t)v : dflt;
+}
+
+static int ensure_workspaces(mc33hip_ctx *c) {
+	if (c->seg_cap < c->nsegs) {
+		(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_first); (void)hipFree(c->seg_nent); (void)hipFree(c->seg_vbase); (void)hipFree(c->seg_tbase);
+		c->seg_cnt = c->seg_first = c->seg_nent = c->seg_vbase = c->seg_tbase = nullptr;
+		c->seg_cap = 0;
+		HIP_TRY(hipMalloc(&c->seg_cnt, c->nsegs * 4));
+		HIP_TRY(hipMalloc(&c->seg_first, c->nsegs * 4));
+		HIP_TRY(hipMalloc(&c->seg_nent, c->nsegs * 4));
+		HIP_TRY(hipMalloc(&c->seg_vbase, c->nsegs * 4));
+		HIP_TRY(hipMalloc(&c->seg_tbase, c->nsegs * 4));
+		c->seg_cap = c->nsegs;
+	}
+	const uint64_t nb = (c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK;
+	if (c->bs_cap < nb) {
+		(void)hipFree(c->bsV); (void)hipFree(c->bsT);
+		c->bsV = c->bsT = nullptr;
+		c->bs_cap = 0;
+		HIP_TRY(hipMalloc(&c->bsV, nb * 8));
+		HIP_TRY(hipMalloc(&c->bsT, nb * 8));
+		c->bs_cap = nb;
+	}
+	if (!c->entries) {
+		// first guess: one cell in 32 is cut (BASELINE fields: 0.4-6 % of the cells); grown on demand
+		const uint64_t cells = (uint64_t)c->P.nx * c->P.ny * (c->range.z_end - c->P.zs);
+		uint64_t cap = cells / 32 + 4096;
+		if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+		HIP_TRY(hipMalloc(&c->entries, cap * sizeof(Entry)));
+		HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
+		c->entry_cap = cap;
+	}
+	return 0;
+}
+
+static int grow_entries(mc33hip_ctx *c, uint64_t need) {
+	(void)hipFree(c->entries); (void)hipFree(c->entry_seg);
+	c->entries = nullptr; c->entry_seg = nullptr; c->entry_cap = 0;
+	uint64_t cap = need + need / 8 + 4096;
+	if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+	if (cap < need) { set_err("more than 2^32 work records"); return MC33HIP_EOVERFLOW; }
+	HIP_TRY(hipMalloc(&c->entries, cap * sizeof(Entry)));
+	HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
+	c->entry_cap = cap;
+	return 0;
+}
+
+// enqueue sweep + scans on the context's stream (no synchronisation)
+static int enqueue_count(mc33hip_ctx *c) {
+	const Params &P = c->P;
+	hipStream_t st = c->stream;
+	HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
+	SweepArgs a;
+	a.G.p = c->d_grid; a.G.pitch = (uint32_t)c->pitch; a.G.z0 = c->desc.plane0; a.G.slice = c->slice;
+	a.P = P;
+	a.tab.lut = c->d_lut; a.tab.rule_words = c->d_rules; a.tab.rule_index = c->d_rule_index;
+	a.ze = c->range.z_end;
+	a.nXG = (P.nseg + 3) / 4;
+	a.nYT = (P.ny + 62) / 63;
+	a.rz = env_u32("MC33_HIP_RZ", 16);
+	const uint32_t nZC = (a.ze - P.zs + a.rz - 1) / a.rz;
+	a.seg_cnt = c->seg_cnt; a.seg_first = c->seg_first; a.seg_nent = c->seg_nent;
+	a.entries = c->entries; a.entry_seg = c->entry_seg; a.entry_cap = (uint32_t)c->entry_cap;
+	a.ctr = c->d_ctr;
+	const uint64_t blocks = (uint64_t)a.nXG * a.nYT * nZC;
+	if (blocks > 0x7FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
+	HIP_TRY(hipEventRecord(c->ev[0], st));
+	hipLaunchKernelGGL(k_sweep, dim3((uint32_t)blocks), dim3(256), 0, st, a);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(c->ev[1], st));
+	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
+	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, c->bsV, c->bsT);
+	hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, c->bsV, c->bsT, nb, c->d_ctr);
+	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, c->bsV, c->bsT, c->seg_vbase, c->seg_tbase,
+	                   c->ghost_segs, c->d_ctr);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(c->ev[2], st));
+	return 0;
+}
+
+static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t capV, uint64_t capT) {
+	EmitArgs a;
+	a.c.tab.lut = c->d_lut; a.c.tab.rule_words = c->d_rules; a.c.tab.rule_index = c->d_rule_index;
+	a.c.P = c->P;
+	a.c.G.p = c->d_grid; a.c.G.pitch = (uint32_t)c->pitch; a.c.G.z0 = c->desc.plane0; a.c.G.slice = c->slice;
+	a.c.seg_vbase = c->seg_vbase; a.c.seg_tbase = c->seg_tbase; a.c.seg_first = c->seg_first; a.c.seg_nent = c->seg_nent;
+	a.c.entries = c->entries; a.c.entry_seg = c->entry_seg;
+	a.c.V = (float *)dV; a.c.N = (float *)dN; a.c.Tri = (uint32_t *)dT;
+	a.c.z_emit = c->range.z_begin; a.c.v_skip = a.c.t_skip = a.c.id_delta = 0;
+	a.ctr = c->d_ctr;
+	a.entry_cap = (uint32_t)c->entry_cap;
+	a.capV = capV; a.capT = capT;
+	a.ghost_segs = c->ghost_segs;
+	a.id_base = c->range.id_base;
+	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 8u);
+	hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, c->stream, a);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+	return 0;
+}
+
+static int fetch_counters(mc33hip_ctx *c) {
+	HIP_TRY(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+static int finish_counts(mc33hip_ctx *c, mc33hip_counts *out) {
+	const Counters &h = *c->h_ctr;
+	const uint64_t gV = c->ghost_segs ? h.ghostV : 0, gT = c->ghost_segs ? h.ghostT : 0;
+	c->counts.nV = h.totV - gV; c->counts.nT = h.totT - gT;
+	c->counts.nV_ghost = gV; c->counts.nT_ghost = gT;
+	c->counts.active_cells = h.entry_cursor;
+	if (out) *out = c->counts;
+	if (h.totV > 0xFFFFFFFFull || h.totT > 0xFFFFFFFFull || (uint64_t)c->range.id_base + c->counts.nV > 0xFFFFFFFFull) {
+		set_err("surface exceeds 2^32-1 vertices or triangles");
+		return MC33HIP_EOVERFLOW;
+	}
+	return 0;
+}
+
+static void read_timing(mc33hip_ctx *c, bool with_emit, unsigned launches) {
+	mc33hip_timing &t = c->timing;
+	t.sweep_ms = t.scan_ms = t.emit_ms = t.total_ms = 0.f;
+	(void)hipEventElapsedTime(&t.sweep_ms, c->ev[0], c->ev[1]);
+	(void)hipEventElapsedTime(&t.scan_ms, c->ev[1], c->ev[2]);
+	if (with_emit) {
+		(void)hipEventElapsedTime(&t.emit_ms, c->ev[2], c->ev[3]);
+		(void)hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[3]);
+	} else
+		(void)hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[2]);
+	t.sweep_launches = launches;
+}
+
+extern "C" int mc33hip_count(mc33hip_ctx *c, float iso, const mc33hip_range *range, mc33hip_counts *out) {
+	if (!c) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	if ((rc = check_range(c, range))) return rc;
+	c->counted = false;
+	fill_params(c, iso, range);
+	if ((rc = ensure_workspaces(c))) return rc;
+	unsigned launches = 0;
+	for (;;) {
+		if ((rc = enqueue_count(c))) return rc;
+		launches++;
+		if ((rc = fetch_counters(c))) return rc;
+		if (c->h_ctr->entry_cursor <= c->entry_cap) break;
+		if ((rc = grow_entries(c, c->h_ctr->entry_cursor))) return rc;
+	}
+	read_timing(c, false, launches);
+	if ((rc = finish_counts(c, out))) return rc;
+	c->counted = true;
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long long capV, unsigned long long capT) {
+	if (!c || !c->counted) { set_err("mc33hip_emit needs a successful mc33hip_count first"); return MC33HIP_EINVAL; }
+	if (capV < c->counts.nV || capT < c->counts.nT) { set_err("output buffers too small"); return MC33HIP_ECAPACITY; }
+	if ((c->counts.nV && (!dV || !dN)) || (c->counts.nT && !dT)) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	return enqueue_emit(c, dV, dN, dT, capV, capT);
+}
+
+extern "C" int mc33hip_extract(mc33hip_ctx *c, float iso, const mc33hip_range *range, void *dV, void *dN, void *dT,
+                               unsigned long long capV, unsigned long long capT, mc33hip_counts *out) {
+	if (!c) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	if ((rc = check_range(c, range))) return rc;
+	c->counted = false;
+	fill_params(c, iso, range);
+	if ((rc = ensure_workspaces(c))) return rc;
+	unsigned launches = 0;
+	for (;;) {
+		if ((rc = enqueue_count(c))) return rc;
+		launches++;
+		if ((rc = enqueue_emit(c, dV, dN, dT, capV, capT))) return rc;  // checks capacities on the device
+		if ((rc = fetch_counters(c))) return rc;
+		if (c->h_ctr->entry_cursor <= c->entry_cap) break;
+		if ((rc = grow_entries(c, c->h_ctr->entry_cursor))) return rc;
+	}
+	read_timing(c, true, launches);
+	if ((rc = finish_counts(c, out))) return rc;
+	c->counted = true;
+	if (c->h_ctr->emit_skipped) { set_err("output buffers too small: need %llu vertices, %llu triangles", c->counts.nV, c->counts.nT); return MC33HIP_ECAPACITY; }
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_last_timing(const mc33hip_ctx *c, mc33hip_timing *t) {
+	if (!c || !t) return MC33HIP_EINVAL;
+	*t = c->timing;
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_download(mc33hip_ctx *c, void *dst, const void *src, size_t bytes) {
+	if (!c || (bytes && (!dst || !src))) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	if (!bytes) return MC33HIP_OK;
+	HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_device_alloc(mc33hip_ctx *c, void **dptr, size_t bytes) {
+	if (!c || !dptr) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	*dptr = nullptr;
+	HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_device_free(mc33hip_ctx *c, void *dptr) {
+	if (!c) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	HIP_TRY(hipFree(dptr));
+	return MC33HIP_OK;
+}

@@ -25,11 +25,11 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	Params P;
 	P.nx = npx - 1; P.ny = npy - 1; P.nz = npz - 1;
 	P.nseg = (P.nx + SEG_CELLS - 1) / SEG_CELLS;
-	P.iso = iso;
+	P.iso = iso; P.zs = 0;
 	if (d[0] != d[1] || d[1] != d[2]) { P.store_mode = 2; P.ca = (float)(d[2] / d[0]); P.cb = (float)(d[2] / d[1]); }
 	else { P.store_mode = (d[0] == 1 && r0[0] == 0 && r0[1] == 0 && r0[2] == 0) ? 0 : 1; P.ca = P.cb = 1; }
 	for (int k = 0; k < 3; k++) { P.O[k] = (float)r0[k]; P.D[k] = (float)d[k]; }
-	GridView<T> G{data, npx, (uint64_t)npx * npy};
+	GridView<T> G{data, npx, 0, (uint64_t)npx * npy};
 	Tables tab{mc33_lut, mc33_rule_words, &mc33_rule_index[0][0]};
 
 	const uint64_t nsegs = (uint64_t)P.nz * P.ny * P.nseg;
@@ -71,6 +71,7 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	c.seg_vbase = seg_vbase.data(); c.seg_tbase = seg_tbase.data(); c.seg_first = seg_first.data(); c.seg_nent = seg_nent.data();
 	c.entries = entries.data(); c.entry_seg = entry_seg.data();
 	c.V = out->V; c.N = out->N; c.Tri = out->T;
+	c.z_emit = 0; c.v_skip = 0; c.t_skip = 0; c.id_delta = 0;
 	for (size_t k = 0; k < entries.size(); k++) emit_cell(c, (uint32_t)k, v, w, ids);
 	return 0;
 }

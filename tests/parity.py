@@ -1,0 +1,29 @@
+"""Comparison rules of SURVEY.md 8(c): nV, nT equal; T identical element-wise (same order, same ids);
+V and N within 1e-5 relative (NaN normals of zero gradients must be NaN on both sides)."""
+import numpy as np
+
+RTOL = 1e-5  # BASELINE.json north_star: "interpolated float positions/normals within 1e-5 relative"
+
+
+def bits_equal(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def max_rel(a, b, scale):
+    if a.size == 0:
+        return 0.0
+    fin = np.isfinite(a) & np.isfinite(b)
+    den = np.maximum(np.abs(b), scale)
+    return float(np.max(np.where(fin, np.abs(a - b) / den, 0.0)))
+
+
+def assert_surface_parity(got, ref, extent=1.0, label=""):
+    assert (got.nV, got.nT) == (ref.nV, ref.nT), "%s: counts %s vs reference %s" % (label, (got.nV, got.nT), (ref.nV, ref.nT))
+    assert np.array_equal(got.T, ref.T), "%s: triangle indices differ from the reference" % label
+    nan_g, nan_r = np.isnan(got.N), np.isnan(ref.N)
+    assert np.array_equal(nan_g, nan_r), "%s: NaN normals differ" % label
+    ev = max_rel(got.V, ref.V, extent)
+    en = max_rel(got.N, ref.N, 1.0)
+    assert ev <= RTOL, "%s: positions differ by %g relative" % (label, ev)
+    assert en <= RTOL, "%s: normals differ by %g relative" % (label, en)
+    return ev, en, bits_equal(got.V, ref.V), bits_equal(got.N, ref.N)

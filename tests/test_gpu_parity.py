@@ -1,0 +1,126 @@
+"""GPU parity tests: the product libraries (HIP kernels behind the reference's C API) against the
+unmodified reference (oracle/_ref) and the oracle restatement, on the same seeded grids."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+from parity import assert_surface_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def check(products, reflibs, dtype, data, iso, r0=None, d=None, label=""):
+    got = products[dtype].isosurface(data, iso, r0, d)
+    ref = reflibs[dtype].isosurface(data, iso, r0, d)
+    extent = float(max(1.0, max(data.shape))) if d is None else float(max(abs(a) + abs(b) * n for a, b, n in zip(r0, d, data.shape[::-1])))
+    ev, en, vb, nb = assert_surface_parity(got, ref, extent, label)
+    print("%-28s nV %8d nT %8d  maxrel V %.2e N %.2e  bit-exact V %s N %s" % (label, got.nV, got.nT, ev, en, vb, nb))
+    if got.nV:
+        assert np.all(got.color == got.color[0]) and got.capv >= got.nV and got.capt >= got.nT
+    return got
+
+
+@pytest.mark.parametrize("n", [17, 64, 130])
+def test_cos_field_small(products, reflibs, n):
+    data, r0, d = fx.cos_field(n)
+    check(products, reflibs, "f32", data, 0.0, r0, d, "cos%d" % n)
+
+
+def test_config1_cos256(products, reflibs):
+    """BASELINE.json configs[1]: 256^3 float grid, iso 0, topology / vertex diff vs the CPU reference."""
+    data, r0, d = fx.cos_field(256)
+    got = check(products, reflibs, "f32", data, 0.0, r0, d, "cos256")
+    assert (got.nV, got.nT) == (243552, 484184)
+
+
+def test_readme_sphere(products, reflibs):
+    data, r0, d = fx.sphere_field()
+    got = check(products, reflibs, "f32", data, 1.0, r0, d, "sphere")
+    assert (got.nV, got.nT) == (21030, 42056)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 7])
+def test_noise_all_mc33_groups(products, reflibs, seed):
+    check(products, reflibs, "f32", fx.noise_f32(32, seed), 0.0, label="noise32 s%d" % seed)
+
+
+@pytest.mark.parametrize("seed,iso", [(1, 0.0), (1, 0.5), (1, 1.0), (2, 0.0), (3, -1.0), (7, 2.0)])
+def test_degenerate_samples_equal_iso(products, reflibs, seed, iso):
+    check(products, reflibs, "f32", fx.noise_quant(32, seed), iso, label="quant s%d iso %g" % (seed, iso))
+
+
+def test_degenerate_small_alphabet(products, reflibs):
+    check(products, reflibs, "f32", fx.noise_quant(0, 9, L=3, shape=(7, 9, 300)), 0.0, label="quant L3 wide")
+    check(products, reflibs, "f32", fx.noise_quant(0, 4, L=2, shape=(20, 20, 20)), 0.0, label="quant L2")
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 2), (2, 3, 5), (3, 2, 2), (9, 17, 33), (5, 70, 3), (4, 3, 600), (66, 65, 258)])
+def test_ragged_shapes(products, reflibs, shape):
+    check(products, reflibs, "f32", fx.noise_f32(0, 11, shape=shape), 0.05, label="ragged %s" % (shape,))
+
+
+def test_spacing_variants(products, reflibs):
+    data = fx.noise_f32(0, 5, shape=(9, 17, 33))
+    check(products, reflibs, "f32", data, 0.1, (1, 2, 3), (0.5, 0.25, 1.0), "spnB anisotropic")
+    check(products, reflibs, "f32", data, 0.1, (1, 2, 3), (0.5, 0.5, 0.5), "spnA")
+    check(products, reflibs, "f32", data, 0.1, (0, 0, 0), (1, 1, 1), "spn0")
+
+
+@pytest.mark.parametrize("name", ["tangle", "torus3", "decocube", "gyroid"])
+def test_analytic_fields(products, reflibs, name):
+    check(products, reflibs, "f32", fx.analytic_field(name, 48), 0.0, label=name)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_u16_noise(products, reflibs, seed):
+    data = fx.noise_u16(32, seed)
+    check(products, reflibs, "u16", data, 32768.0, label="u16 s%d iso 32768" % seed)
+    check(products, reflibs, "u16", data, 32767.5, label="u16 s%d iso 32767.5" % seed)
+    data = fx.noise_u16(32, seed, 7)
+    check(products, reflibs, "u16", data, 3.0, label="u16%%7 s%d iso 3" % seed)
+    check(products, reflibs, "u16", data, 2.5, label="u16%%7 s%d iso 2.5" % seed)
+
+
+def test_u16_cos_sweep(products, reflibs):
+    """Scaled-down BASELINE.json configs[4]: ushort field, sweep over 8 isovalues on one upload."""
+    data = fx.cos_field_u16(96, 80, 48)
+    for k in range(8):
+        check(products, reflibs, "u16", data, 15268.5 + 5000.0 * k, label="u16 cos iso#%d" % k)
+
+
+def test_empty_surface_is_zeroed_struct(products):
+    import ctypes as C
+    lib = products["f32"]
+    data = fx.noise_f32(8, 1)
+    G, keep = lib.make_grid(data)
+    M = lib.lib.create_MC33(G)
+    assert M
+    S = lib.lib.calculate_isosurface(M, C.c_float(100.0))
+    assert S and S.contents.nV == 0 and S.contents.nT == 0 and not S.contents.V and S.contents.iso == 0.0
+    lib.lib.free_surface_memory(S)
+    lib.lib.free_MC33(M)
+    lib.lib.free_memory_grd(G)
+
+
+def test_size_of_isosurface_matches(products, reflibs):
+    for data, iso in ((fx.noise_f32(32, 1), 0.0), (fx.noise_quant(32, 1), 0.0)):
+        assert products["f32"].sizes(data, iso) == reflibs["f32"].sizes(data, iso)
+
+
+def test_repeatable_and_reusable_context(products):
+    """Same MC33 object, several isovalues, run twice: outputs must be bit-identical (no race)."""
+    import ctypes as C
+    lib = products["f32"]
+    data, r0, d = fx.cos_field(96)
+    G, keep = lib.make_grid(data, r0, d)
+    M = lib.lib.create_MC33(G)
+    outs = []
+    for rep in range(2):
+        for iso in (0.0, 0.7, -1.3):
+            S = lib.lib.calculate_isosurface(M, C.c_float(iso))
+            outs.append(lib.copy_surface(S))
+            lib.lib.free_surface_memory(S)
+    for a, b in zip(outs[:3], outs[3:]):
+        assert np.array_equal(a.T, b.T) and np.array_equal(a.V.view(np.uint32), b.V.view(np.uint32))
+    lib.lib.free_MC33(M)
+    lib.lib.free_memory_grd(G)
