@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py - Mvoxels/s of the MC33 hot path (calculate_isosurface) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A step = one isosurface extraction (sweep + prefix sums + emit) at iso 0 over the rank's part of the
+`cos x + cos y + cos z` volume, grid already resident in HBM, outputs left in HBM.
+  N = 1 : BASELINE.json configs[2] - 1024^3 float grid (4 GiB).
+  N > 1 : weak scaling, BASELINE.json configs[3] / SURVEY.md 8(d) C4: 1024 x 1024 x (1024 N) points, one
+          1024^3-point z-slab per GPU (+ ghost planes); per step every rank extracts its slab, the ranks
+          exchange their counts, rebase triangle ids and all-gather the surface arrays over RCCL.
+Rank 0 prints ONE JSON line (contract in the task statement) extended with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("MC33_BENCH_N", "1024")), help="points per axis per GPU slab")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("MC33_BENCH_CPU_N", "640")),
+                    help="points per axis of the sub-grid the CPU reference is timed on")
+    return ap.parse_args()
+
+
+def cpu_baseline(field_cpu, r0, d, iso):
+    """The unmodified reference (oracle/_ref, built with the reference Makefile's own flags) timed on this
+    host, one core (the reference is single-threaded), on a bounded corner sub-grid of the SAME field."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mc33_capi import MC33Lib, ref_path
+    path = ref_path("f32", fast=True)
+    kind = "reference"
+    if not os.path.exists(path):
+        return None
+    lib = MC33Lib(path, "f32")
+    G, keep = lib.make_grid(field_cpu, r0, d)
+    M = lib.lib.create_MC33(G)
+    best, nT = None, 0
+    for _ in range(2):
+        t0 = time.perf_counter()
+        S = lib.lib.calculate_isosurface(M, C.c_float(iso))
+        dt = time.perf_counter() - t0
+        nT = S.contents.nT
+        lib.lib.free_surface_memory(S)
+        best = dt if best is None else min(best, dt)
+    lib.lib.free_MC33(M)
+    lib.lib.free_memory_grd(G)
+    n = field_cpu.shape[0]
+    cells = (field_cpu.shape[0] - 1) * (field_cpu.shape[1] - 1) * (field_cpu.shape[2] - 1)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": cells / best / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": kind,
+            "sample": "corner %d^3-point sub-grid of the same field, calculate_isosurface best of 2, %.2f s, %d triangles"
+                      % (n, best, nT),
+            "host_cores_available": os.cpu_count(), "cpu": model, "mtris_per_s": nT / best / 1e6}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from mc33_c_library_amd import DeviceGrid, Range
+    from mc33_c_library_amd.fields import cos_field_slab
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.n
+    iso = 0.0
+    lo, h = -4.0, 8.0 / (n - 1)
+    nz_total = n * world - 1                   # cell slices of the whole volume
+    z_begin = rank * n                         # cell slices this rank emits: n per rank ...
+    z_end = min((rank + 1) * n, nz_total)      # ... the last rank has one slice less
+    ghost = 1 if rank else 0
+    p_lo = max(z_begin - ghost - 1, 0)         # resident planes: cells + normals + ghost
+    p_hi = min(z_end + 1, nz_total)
+    field = cos_field_slab(n, p_hi - p_lo + 1, h, lo, dev, z_first=p_lo)
+    grid = DeviceGrid(field, nz_total=nz_total, plane0=p_lo, r0=(lo, lo, lo), d=(h, h, h))
+    cells_rank = (n - 1) * (n - 1) * (z_end - z_begin)
+
+    def rng(id_base=0):
+        return Range(z_begin, z_end, ghost, id_base)
+
+    # capacity from one count pass (all ranks use the same capacity so the gather is a plain all-gather)
+    cnt = grid.count(iso, rng())
+    capV, capT = int(cnt.nV * 1.05) + 1024, int(cnt.nT * 1.05) + 1024
+    if world > 1:
+        caps = torch.tensor([capV, capT], dtype=torch.int64, device=dev)
+        dist.all_reduce(caps, op=dist.ReduceOp.MAX)
+        capV, capT = (int(x) for x in caps.tolist())
+        counts_all = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+        gV = torch.empty((world, capV, 3), dtype=torch.float32, device=dev)
+        gN = torch.empty_like(gV)
+        gT = torch.empty((world, capT, 3), dtype=torch.int32, device=dev)
+    V = torch.empty((capV, 3), dtype=torch.float32, device=dev)
+    N = torch.empty_like(V)
+    T = torch.empty((capT, 3), dtype=torch.int32, device=dev)
+
+    sweep_ms, scan_ms, emit_ms, gather_ms = [], [], [], []
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def step(record):
+        if world == 1:
+            c, ok = grid.extract_into(iso, V, N, T, rng())
+            assert ok
+            if record:
+                t = grid.timing()
+                sweep_ms.append(t.sweep_ms); scan_ms.append(t.scan_ms); emit_ms.append(t.emit_ms)
+            return c
+        # z-slabs: count -> exchange counts -> emit with the global id base -> all-gather the surface arrays
+        c = grid.count(iso, rng())
+        t = grid.timing()
+        mine = torch.tensor([c.nV, c.nT], dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(counts_all, mine)
+        id_base = int(counts_all[:rank, 0].sum().item()) if rank else 0
+        grid.emit_into(V, N, T, id_base)
+        ev[0].record()
+        dist.all_gather_into_tensor(gV, V)
+        dist.all_gather_into_tensor(gN, N)
+        dist.all_gather_into_tensor(gT, T)
+        ev[1].record()
+        if record:
+            ev[1].synchronize()
+            gather_ms.append(ev[0].elapsed_time(ev[1]))
+            sweep_ms.append(t.sweep_ms); scan_ms.append(t.scan_ms)
+        return c
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([cells_rank, last.nV, last.nT], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        cells_all, nV_all, nT_all = (int(x) for x in tot.tolist())
+    else:
+        cells_all, nV_all, nT_all = cells_rank, last.nV, last.nT
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        avg = lambda a: (sum(a) / len(a)) if a else 0.0
+        sw = avg(sweep_ms)
+        grid_bytes = (p_hi - p_lo + 1) * n * n * 4 if world > 1 else n * n * n * 4
+        grid_bytes_alg = n * n * (z_end - z_begin + 1) * 4  # every sample of the rank's cells read once
+        out_bytes = last.nV * 28 + last.nT * 12               # V, N, colour + T written once
+        roof = {"bound": "hbm", "kernel": "k_sweep", "achieved": grid_bytes_alg / (sw * 1e-3) / 1e9 if sw else None,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": (grid_bytes_alg / (sw * 1e-3) / 1e9 / PEAK_HBM_GBS) if sw else None,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": grid_bytes_alg,
+                "kernel_ms": {"k_sweep": sw, "k_scan_x3": avg(scan_ms), "k_emit": avg(emit_ms)},
+                "whole_call": {"algorithmic_bytes": grid_bytes_alg + out_bytes,
+                               "device_ms": sw + avg(scan_ms) + avg(emit_ms),
+                               "frac": ((grid_bytes_alg + out_bytes) / ((sw + avg(scan_ms) + avg(emit_ms)) * 1e-3) / 1e9 / PEAK_HBM_GBS)
+                               if sw else None}}
+        pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                roof["traffic"] = json.load(open(pmc)).get("k_sweep_bytes_per_launch")
+            except Exception:
+                pass
+        res = {"metric": "Mvoxels/s", "value": cells_all / (dt / args.steps) / 1e6, "unit": "Mvoxels/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%dx%dx%d-point float grid cos x+cos y+cos z on h=8/%d, iso=0.0, calculate_isosurface "
+                                      "(sweep+scan+emit), grid and outputs resident in HBM" % (n, n, n * world, n - 1),
+                          "cells": cells_all, "vertices": nV_all, "triangles": nT_all,
+                          "parallelism": "z-slab x%d" % world if world > 1 else "single GPU"},
+               "mtris_per_s": nT_all / (dt / args.steps) / 1e6,
+               "roofline": roof}
+        if world > 1:
+            res["gather_ms"] = avg(gather_ms)
+        if not args.no_cpu_baseline and world == 1:
+            m = min(args.cpu_sample, n)
+            sub = field[:m, :m, :m].contiguous().cpu().numpy()
+            res["cpu_baseline"] = cpu_baseline(sub, (lo, lo, lo), (h, h, h), iso)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,10 @@ int mc33hip_set_stream(mc33hip_ctx *c, void *hip_stream);
  * Synchronises the stream. */
 int mc33hip_count(mc33hip_ctx *c, float iso, const mc33hip_range *range, mc33hip_counts *out);
 
+/* Global number of the first vertex of the range last counted (z-slab decomposition: known only after
+ * the ranks have exchanged their counts).  Takes effect in the next mc33hip_emit. */
+int mc33hip_set_id_base(mc33hip_ctx *c, unsigned int id_base);
+
 /* Emit pass for the range last counted, into caller-owned DEVICE buffers:
  * V, N: capV x 3 floats; T: capT x 3 unsigned.  Replaces the vertex/triangle appends of MC33_findCase
  * (MC:780-1252).  Asynchronous on the context's stream. */

@@ -1,0 +1,177 @@
+"""Python view of the C ABI (include/mc33_hip.h, include/marching_cubes_33.h).
+
+Plumbing only: device memory and streams come from PyTorch-ROCm, the work is done by the HIP kernels
+inside libMC33_{f32,u16}.so.  There is no CPU fallback: loading fails loudly when the shared object is
+missing, and every call into it fails loudly when no GPU is present.
+"""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+
+OK, EINVAL, ENOGPU, ENOMEM, ECAPACITY, ERUNTIME, EOVERFLOW = 0, -1, -2, -3, -4, -5, -6
+
+
+class GridDesc(C.Structure):
+    _fields_ = [("npx", C.c_uint), ("npy", C.c_uint), ("npz_resident", C.c_uint), ("plane0", C.c_uint),
+                ("nz_total", C.c_uint), ("r0", C.c_double * 3), ("d", C.c_double * 3),
+                ("sample_bytes", C.c_int), ("device", C.c_int)]
+
+
+class Range(C.Structure):
+    _fields_ = [("z_begin", C.c_uint), ("z_end", C.c_uint), ("ghost_below", C.c_uint), ("id_base", C.c_uint)]
+
+
+class Counts(C.Structure):
+    _fields_ = [("nV", C.c_ulonglong), ("nT", C.c_ulonglong), ("nV_ghost", C.c_ulonglong),
+                ("nT_ghost", C.c_ulonglong), ("active_cells", C.c_ulonglong)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("sweep_ms", C.c_float), ("scan_ms", C.c_float), ("emit_ms", C.c_float), ("total_ms", C.c_float),
+                ("sweep_launches", C.c_uint)]
+
+
+HIP_API = ["mc33hip_set_id_base", "mc33hip_create", "mc33hip_destroy", "mc33hip_last_error", "mc33hip_upload_rows",
+           "mc33hip_upload_contiguous", "mc33hip_adopt_device", "mc33hip_set_stream", "mc33hip_count",
+           "mc33hip_emit", "mc33hip_extract", "mc33hip_last_timing", "mc33hip_download",
+           "mc33hip_device_alloc", "mc33hip_device_free"]
+REFERENCE_API = ["create_MC33", "calculate_isosurface", "size_of_isosurface", "free_MC33", "free_surface_memory",
+                 "adjustvectorlenght_s", "DefaultColorMC", "free_memory_grd", "alloc_F", "grid_from_data_pointer",
+                 "generate_grid_from_fn"]
+
+
+class MC33Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mc33hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path(dtype="f32"):
+    return os.path.join(PKG, "libMC33_%s.so" % dtype)
+
+
+_libs = {}
+
+
+def load_library(dtype="f32"):
+    """dlopen the product library; raises if it was not built (python -m mc33_c_library_amd.build)."""
+    if dtype in _libs:
+        return _libs[dtype]
+    path = library_path(dtype)
+    if not os.path.exists(path):
+        raise FileNotFoundError("%s not built - run `python -m mc33_c_library_amd.build` (hipcc, gfx950); "
+                                "there is no CPU fallback" % path)
+    try:  # torch's bundled HIP runtime must be the one the process loads first (same SONAME)
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(path)
+    P, V = C.POINTER, C.c_void_p
+    lib.mc33hip_create.argtypes = [P(V), P(GridDesc)]
+    lib.mc33hip_destroy.argtypes = [V]
+    lib.mc33hip_destroy.restype = None
+    lib.mc33hip_last_error.restype = C.c_char_p
+    lib.mc33hip_upload_rows.argtypes = [V, V]
+    lib.mc33hip_upload_contiguous.argtypes = [V, V]
+    lib.mc33hip_adopt_device.argtypes = [V, V, C.c_size_t, C.c_size_t]
+    lib.mc33hip_set_stream.argtypes = [V, V]
+    lib.mc33hip_count.argtypes = [V, C.c_float, P(Range), P(Counts)]
+    lib.mc33hip_set_id_base.argtypes = [V, C.c_uint]
+    lib.mc33hip_emit.argtypes = [V, V, V, V, C.c_ulonglong, C.c_ulonglong]
+    lib.mc33hip_extract.argtypes = [V, C.c_float, P(Range), V, V, V, C.c_ulonglong, C.c_ulonglong, P(Counts)]
+    lib.mc33hip_last_timing.argtypes = [V, P(Timing)]
+    lib.mc33hip_download.argtypes = [V, V, V, C.c_size_t]
+    lib.mc33hip_device_alloc.argtypes = [V, P(V), C.c_size_t]
+    lib.mc33hip_device_free.argtypes = [V, V]
+    _libs[dtype] = lib
+    return lib
+
+
+def _check(lib, rc, allow=()):
+    if rc != OK and rc not in allow:
+        raise MC33Error(rc, lib.mc33hip_last_error().decode(errors="replace"))
+    return rc
+
+
+class DeviceGrid:
+    """A grid (or a z-slab of one) resident in HBM as a torch tensor [planes, rows, pitch], plus the
+    extraction context working on it.  dtype float32 or uint16 (carried as torch.int16 bit patterns)."""
+
+    def __init__(self, tensor, nz_total=None, plane0=0, r0=(0.0, 0.0, 0.0), d=(1.0, 1.0, 1.0), npx=None):
+        import torch
+        assert tensor.is_cuda and tensor.dim() == 3 and tensor.stride(2) == 1, "need a device tensor [z, y, x]"
+        if tensor.dtype == torch.float32:
+            self.dtype, sb = "f32", 4
+        elif tensor.dtype in (torch.int16, torch.uint16):
+            self.dtype, sb = "u16", 2
+        else:
+            raise TypeError("grid samples must be float32 or (u)int16")
+        self.lib = load_library(self.dtype)
+        self.tensor = tensor  # keeps the memory alive
+        npz, npy, pitch = tensor.shape[0], tensor.shape[1], tensor.stride(1)
+        npx = npx if npx is not None else tensor.shape[2]
+        desc = GridDesc(npx, npy, npz, plane0, (nz_total if nz_total is not None else npz - 1),
+                        (C.c_double * 3)(*r0), (C.c_double * 3)(*d), sb, tensor.device.index)
+        self.desc = desc
+        self.ctx = C.c_void_p()
+        _check(self.lib, self.lib.mc33hip_create(C.byref(self.ctx), C.byref(desc)))
+        _check(self.lib, self.lib.mc33hip_adopt_device(self.ctx, C.c_void_p(tensor.data_ptr()), pitch, tensor.stride(0)))
+        self.device = tensor.device
+        self.use_stream(torch.cuda.current_stream(self.device))
+
+    def use_stream(self, stream):
+        self.stream = stream
+        _check(self.lib, self.lib.mc33hip_set_stream(self.ctx, C.c_void_p(stream.cuda_stream)))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.mc33hip_destroy(self.ctx)
+            self.ctx = None
+
+    __del__ = close
+
+    def full_range(self):
+        return Range(0, self.desc.nz_total, 0, 0)
+
+    def count(self, iso, rng=None):
+        rng = rng or self.full_range()
+        cnt = Counts()
+        _check(self.lib, self.lib.mc33hip_count(self.ctx, C.c_float(iso), C.byref(rng), C.byref(cnt)))
+        return cnt
+
+    def extract_into(self, iso, V, N, T, rng=None):
+        """One extraction into caller-owned device tensors V, N [capV,3] float32 and T [capT,3] int32.
+        Returns (Counts, enough_capacity)."""
+        rng = rng or self.full_range()
+        cnt = Counts()
+        rc = self.lib.mc33hip_extract(self.ctx, C.c_float(iso), C.byref(rng), C.c_void_p(V.data_ptr()),
+                                      C.c_void_p(N.data_ptr()), C.c_void_p(T.data_ptr()), V.shape[0], T.shape[0],
+                                      C.byref(cnt))
+        _check(self.lib, rc, allow=(ECAPACITY,))
+        return cnt, rc == OK
+
+    def emit_into(self, V, N, T, id_base=None):
+        """Emit pass for the range last counted (asynchronous on the stream)."""
+        if id_base is not None:
+            _check(self.lib, self.lib.mc33hip_set_id_base(self.ctx, id_base))
+        _check(self.lib, self.lib.mc33hip_emit(self.ctx, C.c_void_p(V.data_ptr()), C.c_void_p(N.data_ptr()),
+                                               C.c_void_p(T.data_ptr()), V.shape[0], T.shape[0]))
+
+    def extract(self, iso, rng=None):
+        """Count, allocate exact-size outputs with torch, emit.  Returns (V, N, T, Counts)."""
+        import torch
+        rng = rng or self.full_range()
+        cnt = self.count(iso, rng)
+        V = torch.empty((max(cnt.nV, 1), 3), dtype=torch.float32, device=self.device)
+        N = torch.empty_like(V)
+        T = torch.empty((max(cnt.nT, 1), 3), dtype=torch.int32, device=self.device)
+        _check(self.lib, self.lib.mc33hip_emit(self.ctx, C.c_void_p(V.data_ptr()), C.c_void_p(N.data_ptr()),
+                                               C.c_void_p(T.data_ptr()), V.shape[0], T.shape[0]))
+        self.stream.synchronize()
+        return V[:cnt.nV], N[:cnt.nV], T[:cnt.nT], cnt
+
+    def timing(self):
+        t = Timing()
+        _check(self.lib, self.lib.mc33hip_last_timing(self.ctx, C.byref(t)))
+        return t

@@ -56,7 +56,12 @@ struct GridView {  // pitched copy of _GRD.F in HBM: sample (x,y,z) at p[(z-z0)*
 	uint32_t pitch;  // samples per row (>= nx+1)
 	uint32_t z0;     // global index of the first resident plane (0 unless the volume is z-slabbed over GPUs)
 	uint64_t slice;  // samples per plane
-	MC33_HD T at(uint32_t x, uint32_t y, uint32_t z) const { return p[(uint64_t)(z - z0) * slice + (uint64_t)y * pitch + x]; }
+	MC33_HD T at(uint32_t x, uint32_t y, uint32_t z) const {
+#ifdef MC33_BOUNDS_HOOK  // tests/host_emu only: record reads outside the resident planes
+		MC33_BOUNDS_HOOK(x, y, z);
+#endif
+		return p[(uint64_t)(z - z0) * slice + (uint64_t)y * pitch + x];
+	}
 };
 
 MC33_HD float sample_diff(float a, float b) { return a - b; }

@@ -51,6 +51,7 @@ struct SweepArgs {
 	Params P;
 	Tables tab;
 	uint32_t ze;             // classify cell slices [P.zs, ze)
+	uint32_t z_emit;         // slices below are ghosts of a z-slab (their triangles are never written)
 	uint32_t nXG, nYT, rz;   // tiles: 4 segments wide, 63 cell rows high, rz slices deep
 	uint32_t *seg_cnt, *seg_first, *seg_nent;
 	Entry *entries;
@@ -181,7 +182,9 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 					const uint32_t i = load_cell(a.G, iso, x, y, z, v);
 					CellPlan pl;
 					plan_cell(pl, a.tab, P, a.G, x, y, z, i, v);
-					const uint32_t nt = count_triangles(pl, a.tab, P, a.G, x, y, z, w);
+					// Ghost cells only lend vertex ids to the slab above; their triangle count cancels out of
+					// every offset, so the identity test (which may read one more plane below) is skipped.
+					const uint32_t nt = z < a.z_emit ? pl.ntri : count_triangles(pl, a.tab, P, a.G, x, y, z, w);
 					if (idx < a.entry_cap) {
 						a.entries[idx] = make_entry(xl, i, pl, nv_run, nt_run);
 						a.entry_seg[idx] = (uint32_t)sidx;
@@ -598,6 +601,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	a.P = P;
 	a.tab.lut = c->d_lut; a.tab.rule_words = c->d_rules; a.tab.rule_index = c->d_rule_index;
 	a.ze = c->range.z_end;
+	a.z_emit = c->range.z_begin;
 	a.nXG = (P.nseg + 3) / 4;
 	a.nYT = (P.ny + 62) / 63;
 	a.rz = env_u32("MC33_HIP_RZ", 16);
@@ -694,6 +698,13 @@ extern "C" int mc33hip_count(mc33hip_ctx *c, float iso, const mc33hip_range *ran
 	read_timing(c, false, launches);
 	if ((rc = finish_counts(c, out))) return rc;
 	c->counted = true;
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_set_id_base(mc33hip_ctx *c, unsigned int id_base) {
+	if (!c || !c->counted) return MC33HIP_EINVAL;
+	if ((uint64_t)id_base + c->counts.nV > 0xFFFFFFFFull) { set_err("vertex ids exceed 2^32-1"); return MC33HIP_EOVERFLOW; }
+	c->range.id_base = id_base;
 	return MC33HIP_OK;
 }
 

@@ -6,6 +6,12 @@
 #include <cstring>
 #include <vector>
 
+// resident-plane window of the emulated rank; reads outside it are counted (and served from the full
+// array, so the run completes and the test can report the violation instead of crashing)
+static unsigned g_plane_lo = 0, g_plane_hi = 0xFFFFFFFFu, g_px = 0xFFFFFFFFu, g_py = 0xFFFFFFFFu;
+static unsigned long long g_violations = 0;
+#define MC33_BOUNDS_HOOK(x, y, z) \
+	do { if ((z) < g_plane_lo || (z) > g_plane_hi || (x) >= g_px || (y) >= g_py) g_violations++; } while (0)
 #include "../../mc33_c_library_amd/csrc/mc33_cell.h"
 #include "../../mc33_c_library_amd/csrc/mc33_lut_data.h"
 #include "../../mc33_c_library_amd/csrc/mc33_rules_data.h"
@@ -18,21 +24,33 @@ struct emu_surface {
 	uint32_t *T;
 };
 
+struct emu_slab {
+	uint32_t z_begin, z_end, ghost, id_base;  // as mc33hip_range
+	uint32_t plane_lo, plane_hi;              // planes the emulated rank holds
+};
+
 template <typename T>
 static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const double *r0, const double *d, float iso,
-               emu_surface *out) {
+               emu_surface *out, const emu_slab *slab = nullptr) {
 	memset(out, 0, sizeof *out);
 	Params P;
 	P.nx = npx - 1; P.ny = npy - 1; P.nz = npz - 1;
 	P.nseg = (P.nx + SEG_CELLS - 1) / SEG_CELLS;
 	P.iso = iso; P.zs = 0;
+	uint32_t z_emit = 0, ze = P.nz, id_base = 0;
+	g_plane_lo = 0; g_plane_hi = npz - 1; g_px = npx; g_py = npy;
+	if (slab) {
+		z_emit = slab->z_begin; ze = slab->z_end; id_base = slab->id_base;
+		P.zs = slab->z_begin - (slab->ghost ? 1 : 0);
+		g_plane_lo = slab->plane_lo; g_plane_hi = slab->plane_hi;
+	}
 	if (d[0] != d[1] || d[1] != d[2]) { P.store_mode = 2; P.ca = (float)(d[2] / d[0]); P.cb = (float)(d[2] / d[1]); }
 	else { P.store_mode = (d[0] == 1 && r0[0] == 0 && r0[1] == 0 && r0[2] == 0) ? 0 : 1; P.ca = P.cb = 1; }
 	for (int k = 0; k < 3; k++) { P.O[k] = (float)r0[k]; P.D[k] = (float)d[k]; }
 	GridView<T> G{data, npx, 0, (uint64_t)npx * npy};
 	Tables tab{mc33_lut, mc33_rule_words, &mc33_rule_index[0][0]};
 
-	const uint64_t nsegs = (uint64_t)P.nz * P.ny * P.nseg;
+	const uint64_t nsegs = (uint64_t)(ze - P.zs) * P.ny * P.nseg;
 	std::vector<uint32_t> seg_cnt(nsegs, 0), seg_first(nsegs, 0), seg_nent(nsegs, 0), seg_vbase(nsegs), seg_tbase(nsegs);
 	std::vector<Entry> entries;
 	std::vector<uint32_t> entry_seg;
@@ -41,14 +59,14 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	VRef v{vbuf, 1}, w{wbuf, 1};
 	URef ids{idbuf, 1};
 	// count pass
-	for (uint32_t z = 0; z < P.nz; z++)
+	for (uint32_t z = P.zs; z < ze; z++)
 		for (uint32_t y = 0; y < P.ny; y++)
 			for (uint32_t x = 0; x < P.nx; x++) {
 				const uint32_t i = load_cell(G, iso, x, y, z, v);
 				if (i == 0 || i == 0xFF) continue;
 				CellPlan p;
 				plan_cell(p, tab, P, G, x, y, z, i, v);
-				const uint32_t nt = count_triangles(p, tab, P, G, x, y, z, w);
+				const uint32_t nt = z < z_emit ? p.ntri : count_triangles(p, tab, P, G, x, y, z, w);  // as k_sweep
 				const uint64_t s = segment_index(P, x, y, z);
 				if (seg_nent[s] == 0) seg_first[s] = (uint32_t)entries.size();
 				const uint32_t voff = seg_cnt[s] & 0xFFFF, toff = seg_cnt[s] >> 16;
@@ -63,6 +81,9 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 		seg_vbase[s] = (uint32_t)nV; seg_tbase[s] = (uint32_t)nT;
 		nV += seg_cnt[s] & 0xFFFF; nT += seg_cnt[s] >> 16;
 	}
+	const uint64_t gseg = (uint64_t)(z_emit - P.zs) * P.ny * P.nseg;
+	const uint32_t gV = gseg ? seg_vbase[gseg] : 0, gT = gseg ? seg_tbase[gseg] : 0;
+	nV -= gV; nT -= gT;
 	out->nV = (uint32_t)nV; out->nT = (uint32_t)nT;
 	out->V = (float *)malloc(nV * 12 + 16); out->N = (float *)malloc(nV * 12 + 16); out->T = (uint32_t *)malloc(nT * 12 + 16);
 	memset(out->T, 0xFF, nT * 12);
@@ -71,7 +92,7 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	c.seg_vbase = seg_vbase.data(); c.seg_tbase = seg_tbase.data(); c.seg_first = seg_first.data(); c.seg_nent = seg_nent.data();
 	c.entries = entries.data(); c.entry_seg = entry_seg.data();
 	c.V = out->V; c.N = out->N; c.Tri = out->T;
-	c.z_emit = 0; c.v_skip = 0; c.t_skip = 0; c.id_delta = 0;
+	c.z_emit = z_emit; c.v_skip = gV; c.t_skip = gT; c.id_delta = id_base - gV;
 	for (size_t k = 0; k < entries.size(); k++) emit_cell(c, (uint32_t)k, v, w, ids);
 	return 0;
 }
@@ -85,3 +106,19 @@ extern "C" int emu_isosurface_u16(const uint16_t *data, uint32_t npx, uint32_t n
 	return run<uint16_t>(data, npx, npy, npz, r0, d, iso, out);
 }
 extern "C" void emu_free(emu_surface *s) { free(s->V); free(s->N); free(s->T); memset(s, 0, sizeof *s); }
+
+extern "C" int emu_slab_f32(const float *data, uint32_t npx, uint32_t npy, uint32_t npz, const double *r0, const double *d,
+                            float iso, const emu_slab *slab, emu_surface *out, unsigned long long *violations) {
+	g_violations = 0;
+	int rc = run<float>(data, npx, npy, npz, r0, d, iso, out, slab);
+	*violations = g_violations;
+	return rc;
+}
+extern "C" int emu_slab_u16(const uint16_t *data, uint32_t npx, uint32_t npy, uint32_t npz, const double *r0, const double *d,
+                            float iso, const emu_slab *slab, emu_surface *out, unsigned long long *violations) {
+	g_violations = 0;
+	int rc = run<uint16_t>(data, npx, npy, npz, r0, d, iso, out, slab);
+	*violations = g_violations;
+	return rc;
+}
+extern "C" unsigned long long emu_last_violations(void) { return g_violations; }

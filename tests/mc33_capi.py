@@ -98,6 +98,16 @@ REF_API = [
 ]
 
 
+def preload_torch():
+    """PyTorch-ROCm bundles its own libamdhip64.so.7; the product library links the system one with the
+    same SONAME.  Whichever is loaded first serves the whole process, and torch only works with its own,
+    so in a Python process that uses both, torch must be imported before the product library is opened."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 class Surface:
     """Host copy of a `surface` (numpy arrays)."""
 
@@ -113,6 +123,8 @@ class MC33Lib:
         self.path = path
         self.dtype = dtype
         self.np_dtype = np.float32 if dtype == "f32" else np.uint16
+        if os.path.basename(path).startswith("libMC33_"):
+            preload_torch()
         # RTLD_LOCAL (default): several of these libraries define the same symbols.
         self.lib = C.CDLL(path)
         L = self.lib

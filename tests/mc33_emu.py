@@ -22,6 +22,11 @@ def build_emu(force=False):
     return EMU_SO
 
 
+class SLAB(C.Structure):
+    _fields_ = [("z_begin", C.c_uint32), ("z_end", C.c_uint32), ("ghost", C.c_uint32), ("id_base", C.c_uint32),
+                ("plane_lo", C.c_uint32), ("plane_hi", C.c_uint32)]
+
+
 class Emu:
     def __init__(self, dtype="f32"):
         self.dtype = dtype
@@ -32,14 +37,26 @@ class Emu:
         self.fn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                             C.c_float, C.POINTER(OSURF)]
         self.lib.emu_free.argtypes = [C.POINTER(OSURF)]
+        self.slab_fn = getattr(self.lib, "emu_slab_" + dtype)
+        self.slab_fn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.c_float, C.POINTER(SLAB), C.POINTER(OSURF), C.POINTER(C.c_ulonglong)]
+        self.lib.emu_last_violations.restype = C.c_ulonglong
 
-    def isosurface(self, data, iso, r0=None, d=None):
+    def isosurface(self, data, iso, r0=None, d=None, slab=None):
+        """slab = (z_begin, z_end, ghost, id_base, plane_lo, plane_hi) emulates one rank of a z-slab run;
+        self.violations then holds the number of reads outside planes [plane_lo, plane_hi]."""
         data = np.ascontiguousarray(data, dtype=self.np_dtype)
         nz, ny, nx = data.shape
         r0a = (C.c_double * 3)(*(r0 if r0 is not None else (0.0, 0.0, 0.0)))
         da = (C.c_double * 3)(*(d if d is not None else (1.0, 1.0, 1.0)))
         s = OSURF()
-        self.fn(data.ctypes.data, nx, ny, nz, r0a, da, C.c_float(iso), C.byref(s))
+        if slab is None:
+            self.fn(data.ctypes.data, nx, ny, nz, r0a, da, C.c_float(iso), C.byref(s))
+            self.violations = self.lib.emu_last_violations()
+        else:
+            viol = C.c_ulonglong(0)
+            self.slab_fn(data.ctypes.data, nx, ny, nz, r0a, da, C.c_float(iso), C.byref(SLAB(*slab)), C.byref(s), C.byref(viol))
+            self.violations = viol.value
 
         def arr(ptr, n, dt):
             if n == 0:

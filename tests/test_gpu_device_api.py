@@ -1,0 +1,94 @@
+"""GPU tests of the device-level C ABI (include/mc33_hip.h) through mc33_c_library_amd.DeviceGrid:
+torch-owned device memory in, device arrays out; z-slab decomposition with a ghost slice must
+reproduce the whole-volume result exactly (this is the N>1 path of bench.py without the collective)."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def whole(data, iso, r0=(0, 0, 0), d=(1, 1, 1)):
+    import torch
+    from mc33_c_library_amd import DeviceGrid
+    t = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    if t.dtype == torch.uint16:
+        t = t.view(torch.int16)
+    g = DeviceGrid(t, r0=r0, d=d)
+    V, N, T, cnt = g.extract(iso)
+    return V.cpu().numpy(), N.cpu().numpy(), T.cpu().numpy().view(np.uint32), cnt
+
+
+def slabbed(data, iso, cuts, r0=(0, 0, 0), d=(1, 1, 1)):
+    """Emulates ranks = len(cuts)+1 z-slabs on one GPU: every slab has its own context holding only the
+    planes it needs, counts are 'exchanged' on the host, outputs concatenated."""
+    import torch
+    from mc33_c_library_amd import DeviceGrid, Range
+    nz_total = data.shape[0] - 1
+    bounds = [0] + list(cuts) + [nz_total]
+    grids, counts = [], []
+    for r in range(len(bounds) - 1):
+        zb, ze = bounds[r], bounds[r + 1]
+        ghost = 1 if zb else 0
+        p_lo = max(zb - ghost - 1, 0)
+        p_hi = min(ze + 1, nz_total)
+        t = torch.from_numpy(np.ascontiguousarray(data[p_lo:p_hi + 1])).cuda()
+        if t.dtype == torch.uint16:
+            t = t.view(torch.int16)
+        g = DeviceGrid(t, nz_total=nz_total, plane0=p_lo, r0=r0, d=d)
+        c = g.count(iso, Range(zb, ze, ghost, 0))
+        grids.append(g)
+        counts.append(c)
+    Vs, Ns, Ts = [], [], []
+    base = 0
+    for g, c in zip(grids, counts):
+        V = torch.empty((max(c.nV, 1), 3), dtype=torch.float32, device="cuda")
+        N = torch.empty_like(V)
+        T = torch.empty((max(c.nT, 1), 3), dtype=torch.int32, device="cuda")
+        g.emit_into(V, N, T, base)
+        torch.cuda.synchronize()
+        Vs.append(V[:c.nV].cpu().numpy()); Ns.append(N[:c.nV].cpu().numpy()); Ts.append(T[:c.nT].cpu().numpy().view(np.uint32))
+        base += c.nV
+    return np.concatenate(Vs), np.concatenate(Ns), np.concatenate(Ts), counts
+
+
+def beq(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_device_api_matches_reference(reflibs):
+    data, r0, d = fx.cos_field(96)
+    V, N, T, cnt = whole(data, 0.0, r0, d)
+    ref = reflibs["f32"].isosurface(data, 0.0, r0, d)
+    assert cnt.nV == ref.nV and cnt.nT == ref.nT and np.array_equal(T, ref.T) and beq(V, ref.V) and beq(N, ref.N)
+
+
+@pytest.mark.parametrize("case", ["cos", "noise", "quant", "u16"])
+@pytest.mark.parametrize("cuts", [(20,), (7, 8, 30), (1, 46)])
+def test_z_slabs_reproduce_whole_volume(case, cuts):
+    if case == "cos":
+        data, iso = fx.cos_field(48)[0], 0.0
+    elif case == "noise":
+        data, iso = fx.noise_f32(0, 3, shape=(48, 20, 70)), 0.0
+    elif case == "quant":
+        data, iso = fx.noise_quant(0, 5, shape=(48, 24, 40)), 0.0   # aliases chase across the slab interface
+    else:
+        data, iso = fx.noise_u16(0, 2, 7, shape=(48, 20, 30)), 3.0
+    V0, N0, T0, c0 = whole(data, iso)
+    V1, N1, T1, cs = slabbed(data, iso, cuts)
+    assert sum(c.nV for c in cs) == c0.nV and sum(c.nT for c in cs) == c0.nT
+    assert np.array_equal(T0, T1) and beq(V0, V1) and beq(N0, N1)
+
+
+def test_capacity_error_reports_sizes():
+    import torch
+    from mc33_c_library_amd import DeviceGrid
+    data = fx.noise_f32(24, 1)
+    g = DeviceGrid(torch.from_numpy(data).cuda())
+    V = torch.empty((8, 3), dtype=torch.float32, device="cuda")
+    T = torch.empty((8, 3), dtype=torch.int32, device="cuda")
+    cnt, ok = g.extract_into(0.0, V, V.clone(), T)
+    assert not ok and cnt.nV > 8 and cnt.nT > 8
+    V2, N2, T2, c2 = g.extract(0.0)
+    assert c2.nV == cnt.nV and c2.nT == cnt.nT
