@@ -530,20 +530,77 @@ MC33_HD void store_vertex(const Params &P, float *r, float *V, float *N, uint32_
 struct Entry {
 	uint32_t w0;  // x within the segment (8) | sign index (8) | pattern offset (12) | nnew (4)
 	uint32_t w1;  // vertex offset inside the row segment (16) | triangle offset (16)
-	uint32_t w2;  // ranks of edges 0..7  (nibbles)
-	uint32_t w3;  // ranks of edges 8..11 (nibbles); upper half spare
+	uint32_t w2;  // ranks of edges 0..7  (nibbles, 0xF = the cell creates no vertex for that edge)
+	uint32_t w3;  // ranks of edges 8..11 (16) | triangles appended by the cell (4) << 16 | slow flag << 20
 };
-MC33_HD Entry make_entry(uint32_t xl, uint32_t i, const CellPlan &p, uint32_t voff, uint32_t toff) {
+constexpr uint32_t ENTRY_SLOW = 1u << 20;
+MC33_HD Entry make_entry(uint32_t xl, uint32_t i, const CellPlan &p, uint32_t nt, uint32_t voff, uint32_t toff, bool slow) {
 	Entry e;
 	e.w0 = xl | i << 8 | (uint32_t)p.poff << 16 | (uint32_t)p.nnew << 28;
 	e.w1 = voff | toff << 16;
 	e.w2 = (uint32_t)p.rank;
-	e.w3 = (uint32_t)(p.rank >> 32) & 0xFFFFu;
+	e.w3 = ((uint32_t)(p.rank >> 32) & 0xFFFFu) | nt << 16 | (slow ? ENTRY_SLOW : 0u);
 	return e;
 }
 MC33_HD uint32_t entry_rank(const Entry &e, uint32_t edge) {
 	return edge < 8 ? (e.w2 >> (4 * edge)) & 15u : (e.w3 >> (4 * (edge - 8))) & 15u;
 }
+MC33_HD uint32_t entry_nnew(const Entry &e) { return e.w0 >> 28; }
+MC33_HD uint32_t entry_ntri(const Entry &e) { return (e.w3 >> 16) & 15u; }
+
+// Fast path.  A cell is FAST when it owns exactly the three edges meeting at its far corner (x,y,z >= 1),
+// its sign index selects a pattern without tests (table word group 0: MC33 cases 1,2,5,8,9,11,14,
+// MC:694-696) and none of its corners equals the isovalue.  Everything about such a cell follows from
+// the 8-bit sign index alone, precomputed once per library load:
+//   fast[i] = pattern offset (12) | triangles (4) << 12 | nnew (4) << 16 | rank of edge 5 (4) << 20 |
+//             rank of edge 6 (4) << 24 | rank of edge 10 (4) << 28          (0xFFFFFFFF: not fast)
+constexpr uint32_t FAST_NONE = 0xFFFFFFFFu;
+MC33_HD Entry make_fast_entry(uint32_t xl, uint32_t i, uint32_t f, uint32_t voff, uint32_t toff) {
+	Entry e;
+	e.w0 = xl | i << 8 | (f & 0xFFFu) << 16 | ((f >> 16) & 15u) << 28;
+	e.w1 = voff | toff << 16;
+	e.w2 = 0xF00FFFFFu | ((f >> 20) & 15u) << 20 | ((f >> 24) & 15u) << 24;
+	e.w3 = 0xF0FFu | ((f >> 28) & 15u) << 8 | ((f >> 12) & 15u) << 16;
+	return e;
+}
+// placeholder written by the sweep for a cell the slow kernel will plan
+MC33_HD Entry make_pending_entry(uint32_t xl, uint32_t i) {
+	Entry e;
+	e.w0 = xl | i << 8;
+	e.w1 = 0;
+	e.w2 = 0xFFFFFFFFu;
+	e.w3 = 0xFFFFu | ENTRY_SLOW;
+	return e;
+}
+
+inline void build_fast_table(const uint16_t *lut, uint32_t *fast /*[256]*/) {
+	Tables tab{lut, nullptr, nullptr};
+	Params P{};
+	P.nx = P.ny = P.nz = 1u << 20;
+	GridView<float> G{nullptr, 0, 0, 0};
+	for (uint32_t i = 0; i < 256; i++) {
+		fast[i] = FAST_NONE;
+		if (i == 0 || i == 255) continue;
+		const uint32_t c = lut[(i & 0x80) ? (i ^ 0xFF) : i];
+		if (c >> 12) continue;  // needs face / interior tests
+		float vb[8];
+		for (int k = 0; k < 8; k++) vb[k] = ((i >> (7 - k)) & 1) ? -1.0f : 1.0f;
+		CellPlan p;
+		plan_cell(p, tab, P, G, 1, 1, 1, i, VRef{vb, 1});  // interior cell, no corner equal to iso: no rule is consulted
+		fast[i] = (uint32_t)p.poff | (uint32_t)p.ntri << 12 | (uint32_t)p.nnew << 16 | plan_rank(p, 5) << 20 |
+		          plan_rank(p, 6) << 24 | plan_rank(p, 10) << 28;
+	}
+}
+
+// directory of the row segments
+struct SegEnt {
+	uint32_t first;  // first entry of the segment
+	uint32_t nent;   // number of entries (bit 31: the sweep left cells for the slow kernel)
+};
+struct SegBase {
+	uint32_t vbase, tbase;  // exclusive scans of the per-segment counts, in sweep order
+};
+constexpr uint32_t SEG_DIRTY = 1u << 31;
 
 MC33_HD uint64_t segment_index(const Params &P, uint32_t x, uint32_t y, uint32_t z) {
 	return ((uint64_t)(z - P.zs) * P.ny + y) * P.nseg + x / SEG_CELLS;
@@ -554,10 +611,8 @@ struct EmitCtx {
 	Tables tab;
 	Params P;
 	GridView<T> G;
-	const uint32_t *seg_vbase;  // exclusive scans over the row segments, in sweep order
-	const uint32_t *seg_tbase;
-	const uint32_t *seg_first;  // first entry of the segment
-	const uint32_t *seg_nent;   // number of entries of the segment
+	const SegBase *seg_base;
+	const SegEnt *seg_ent;
 	const Entry *entries;
 	const uint32_t *entry_seg;  // row segment of each entry
 	float *V, *N;
@@ -577,7 +632,8 @@ MC33_HD uint32_t edge_vertex_id(const EmitCtx<T> &c, GridEdge g, const VRef &w) 
 	for (int hop = 0; hop < 64; hop++) {
 		const OwnerRef o = owner_of(g.axis, g.x, g.y, g.z);
 		const uint64_t s = segment_index(c.P, o.x, o.y, o.z);
-		const uint32_t first = c.seg_first[s], n = c.seg_nent[s], xl = o.x % SEG_CELLS;
+		const SegEnt se = c.seg_ent[s];
+		const uint32_t first = se.first, n = se.nent & ~SEG_DIRTY, xl = o.x % SEG_CELLS;
 		// entries of a segment are sorted by x: binary search
 		uint32_t lo = 0, hi = n;
 		while (lo < hi) {
@@ -589,7 +645,7 @@ MC33_HD uint32_t edge_vertex_id(const EmitCtx<T> &c, GridEdge g, const VRef &w) 
 		const Entry e = c.entries[first + lo];
 		if ((e.w0 & 0xFFu) != xl) return NO_ID;
 		const uint32_t r = entry_rank(e, o.e);
-		if (r != 15u) return c.seg_vbase[s] + (e.w1 & 0xFFFFu) + r;
+		if (r != 15u) return c.seg_base[s].vbase + (e.w1 & 0xFFFFu) + r;
 		// the owner itself took the id from another grid edge: recompute its plan to learn which
 		const uint32_t i = load_cell(c.G, c.P.iso, o.x, o.y, o.z, w);
 		CellPlan q;
@@ -610,8 +666,9 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 	const uint32_t y = row % c.P.ny, z = row / c.P.ny + c.P.zs;
 	if (z < c.z_emit) return;
 	const uint32_t x = sx * SEG_CELLS + (en.w0 & 0xFFu);
-	const uint32_t vbase = c.seg_vbase[s] + (en.w1 & 0xFFFFu);
-	uint32_t tpos = c.seg_tbase[s] + (en.w1 >> 16) - c.t_skip;
+	const SegBase sb = c.seg_base[s];
+	const uint32_t vbase = sb.vbase + (en.w1 & 0xFFFFu);
+	uint32_t tpos = sb.tbase + (en.w1 >> 16) - c.t_skip;
 	const uint32_t i = load_cell(c.G, c.P.iso, x, y, z, v);
 	CellPlan p;
 	plan_cell(p, c.tab, c.P, c.G, x, y, z, i, v);
@@ -645,6 +702,125 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 			uint32_t *t = c.Tri + 3 * (uint64_t)tpos++;
 			t[0] = (p.n ? ti[1] : ti[0]) + c.id_delta; t[1] = (p.m ? ti[1] : ti[0]) + c.id_delta; t[2] = ti[2] + c.id_delta;
 		}
+	} while (word >> 12);
+}
+
+// --- fast emit ---------------------------------------------------------------------------------------
+// id of the vertex on edge `oe` of the FAST cell's neighbour (ox,oy,oz).  The edge has no end point equal to
+// the isovalue (it is an edge of a fast cell too), so its owner created a regular vertex: no alias to follow.
+template <typename T>
+MC33_HD uint32_t owner_edge_id(const EmitCtx<T> &c, uint32_t ox, uint32_t oy, uint32_t oz, uint32_t e0, uint32_t e1,
+                               uint32_t &id1) {
+	const uint64_t s = segment_index(c.P, ox, oy, oz);
+	const SegEnt se = c.seg_ent[s];
+	const uint32_t vb = c.seg_base[s].vbase;
+	const uint32_t n = se.nent & ~SEG_DIRTY, xl = ox % SEG_CELLS;
+	if (!n) { id1 = NO_ID; return NO_ID; }  // cannot happen for a cut edge; never read past the records
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if ((c.entries[se.first + mid].w0 & 0xFFu) < xl) lo = mid + 1;
+		else hi = mid;
+	}
+	const Entry e = c.entries[se.first + (lo < n ? lo : n - 1)];
+	const uint32_t base = vb + (e.w1 & 0xFFFFu);
+	id1 = base + entry_rank(e, e1);
+	return base + entry_rank(e, e0);
+}
+
+// vertex of one of the three owned edges (5: z-edge, 6: y-edge, 10: x-edge, all through corner 6) of an
+// interior cell; same arithmetic as vertex_on_edge, written out so that every index is static
+template <typename T, int E>
+MC33_HD void fast_owned_vertex(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint32_t z, const float *v, uint32_t id) {
+	const Params &P = c.P;
+	const GridView<T> &G = c.G;
+	float r[6];
+	const float v6 = v[6];
+	if (E == 5) {
+		const float va = v[5], t = va / (va - v6);
+		r[0] = (float)(x + 1); r[1] = (float)(y + 1); r[2] = (float)z + t;
+		r[3] = (x + 1 < P.nx) ? 0.5f * (sample_diff(G.at(x, y + 1, z), G.at(x + 2, y + 1, z)) * (1 - t) +
+		                               sample_diff(G.at(x, y + 1, z + 1), G.at(x + 2, y + 1, z + 1)) * t)
+		                      : (v[5] - v[1]) * (1 - t) + (v6 - v[2]) * t;
+		r[4] = (y + 1 < P.ny) ? 0.5f * (sample_diff(G.at(x + 1, y, z), G.at(x + 1, y + 2, z)) * (1 - t) +
+		                               sample_diff(G.at(x + 1, y, z + 1), G.at(x + 1, y + 2, z + 1)) * t)
+		                      : (v[5] - v[4]) * (1 - t) + (v6 - v[7]) * t;
+		r[5] = v6 - va;
+	} else if (E == 6) {
+		const float va = v[7], t = va / (va - v6);
+		r[0] = (float)(x + 1); r[1] = (float)y + t; r[2] = (float)(z + 1);
+		r[3] = (x + 1 < P.nx) ? 0.5f * (sample_diff(G.at(x, y, z + 1), G.at(x + 2, y, z + 1)) * (1 - t) +
+		                               sample_diff(G.at(x, y + 1, z + 1), G.at(x + 2, y + 1, z + 1)) * t)
+		                      : (v[7] - v[3]) * (1 - t) + (v6 - v[2]) * t;
+		r[4] = v6 - va;
+		r[5] = (z + 1 < P.nz) ? 0.5f * (sample_diff(G.at(x + 1, y, z), G.at(x + 1, y, z + 2)) * (1 - t) +
+		                               sample_diff(G.at(x + 1, y + 1, z), G.at(x + 1, y + 1, z + 2)) * t)
+		                      : (v[7] - v[4]) * (1 - t) + (v6 - v[5]) * t;
+	} else {
+		const float va = v[2], t = va / (va - v6);
+		r[0] = (float)x + t; r[1] = (float)(y + 1); r[2] = (float)(z + 1);
+		r[3] = v6 - va;
+		r[4] = (y + 1 < P.ny) ? 0.5f * (sample_diff(G.at(x, y, z + 1), G.at(x, y + 2, z + 1)) * (1 - t) +
+		                               sample_diff(G.at(x + 1, y, z + 1), G.at(x + 1, y + 2, z + 1)) * t)
+		                      : (v[2] - v[3]) * (1 - t) + (v6 - v[7]) * t;
+		r[5] = (z + 1 < P.nz) ? 0.5f * (sample_diff(G.at(x, y + 1, z), G.at(x, y + 1, z + 2)) * (1 - t) +
+		                               sample_diff(G.at(x + 1, y + 1, z), G.at(x + 1, y + 1, z + 2)) * t)
+		                      : (v[2] - v[1]) * (1 - t) + (v6 - v[5]) * t;
+	}
+	store_vertex(P, r, c.V, c.N, id - c.v_skip);
+}
+
+// Emit pass for one FAST entry (see make_fast_entry).  ids: 12-slot scratch.
+template <typename T>
+MC33_HD void emit_fast_cell(const EmitCtx<T> &c, const Entry &en, uint32_t s, const URef &ids) {
+	const uint32_t sx = s % c.P.nseg, row = s / c.P.nseg;
+	const uint32_t y = row % c.P.ny, z = row / c.P.ny + c.P.zs;
+	if (z < c.z_emit) return;
+	const uint32_t x = sx * SEG_CELLS + (en.w0 & 0xFFu);
+	const SegBase sb = c.seg_base[s];
+	const uint32_t vbase = sb.vbase + (en.w1 & 0xFFFFu);
+	uint32_t tpos = sb.tbase + (en.w1 >> 16) - c.t_skip;
+	const uint32_t i = (en.w0 >> 8) & 0xFFu;
+	float v[8];
+	v[0] = c.P.iso - (float)c.G.at(x, y, z);         v[1] = c.P.iso - (float)c.G.at(x, y + 1, z);
+	v[2] = c.P.iso - (float)c.G.at(x, y + 1, z + 1); v[3] = c.P.iso - (float)c.G.at(x, y, z + 1);
+	v[4] = c.P.iso - (float)c.G.at(x + 1, y, z);     v[5] = c.P.iso - (float)c.G.at(x + 1, y + 1, z);
+	v[6] = c.P.iso - (float)c.G.at(x + 1, y + 1, z + 1); v[7] = c.P.iso - (float)c.G.at(x + 1, y, z + 1);
+	// cut edges: end points on different sides (bit 7-k of i is the side of corner k)
+	const uint32_t b = i;
+#define MC33_SIDE(k) ((b >> (7 - (k))) & 1u)
+	const uint32_t r5 = (en.w2 >> 20) & 15u, r6 = (en.w2 >> 24) & 15u, r10 = (en.w3 >> 8) & 15u;
+	if (r5 != 15u) { ids[5] = vbase + r5; fast_owned_vertex<T, 5>(c, x, y, z, v, vbase + r5); }
+	if (r6 != 15u) { ids[6] = vbase + r6; fast_owned_vertex<T, 6>(c, x, y, z, v, vbase + r6); }
+	if (r10 != 15u) { ids[10] = vbase + r10; fast_owned_vertex<T, 10>(c, x, y, z, v, vbase + r10); }
+	uint32_t t1;
+	// the six neighbours that own the other nine edges: edge k of this cell is
+	// edge k' of the owner - (x-1,y,z-1): 0->6 | (x-1,y,z): 1->5, 2->6 | (x-1,y-1,z): 3->5 |
+	// (x,y,z-1): 4->6, 9->10 | (x,y-1,z): 7->5, 11->10 | (x,y-1,z-1): 8->10
+	if (MC33_SIDE(0) != MC33_SIDE(1)) ids[0] = owner_edge_id(c, x - 1, y, z - 1, 6, 6, t1);
+	if ((MC33_SIDE(1) != MC33_SIDE(2)) || (MC33_SIDE(3) != MC33_SIDE(2))) {
+		const uint32_t a = owner_edge_id(c, x - 1, y, z, 5, 6, t1);
+		ids[1] = a; ids[2] = t1;
+	}
+	if (MC33_SIDE(0) != MC33_SIDE(3)) ids[3] = owner_edge_id(c, x - 1, y - 1, z, 5, 5, t1);
+	if ((MC33_SIDE(4) != MC33_SIDE(5)) || (MC33_SIDE(1) != MC33_SIDE(5))) {
+		const uint32_t a = owner_edge_id(c, x, y, z - 1, 6, 10, t1);
+		ids[4] = a; ids[9] = t1;
+	}
+	if ((MC33_SIDE(4) != MC33_SIDE(7)) || (MC33_SIDE(3) != MC33_SIDE(7))) {
+		const uint32_t a = owner_edge_id(c, x, y - 1, z, 5, 10, t1);
+		ids[7] = a; ids[11] = t1;
+	}
+	if (MC33_SIDE(0) != MC33_SIDE(4)) ids[8] = owner_edge_id(c, x, y - 1, z - 1, 10, 10, t1);
+#undef MC33_SIDE
+	// winding (MC:683-691): n = 1 swaps the first two indices
+	const uint32_t n = ((c.tab.lut[(i & 0x80) ? (i ^ 0xFF) : i] >> 11) ^ (i >> 7) ^ 1u) & 1u;
+	uint32_t pos = (en.w0 >> 16) & 0xFFFu, word;
+	do {  // MC:780-784, 1245-1250 (all three ids differ: regular vertices on three different edges)
+		word = c.tab.lut[++pos];
+		const uint32_t i2 = ids[(int)(word & 15u)], i1 = ids[(int)((word >> 4) & 15u)], i0 = ids[(int)((word >> 8) & 15u)];
+		uint32_t *t = c.Tri + 3 * (uint64_t)tpos++;
+		t[0] = (n ? i1 : i0) + c.id_delta; t[1] = (n ? i0 : i1) + c.id_delta; t[2] = i2 + c.id_delta;
 	} while (word >> 12);
 }
 

@@ -41,7 +41,9 @@ typedef float sample_t;
 // ---------------------------------------------------------------------------------------------------
 struct Counters {
 	uint32_t entry_cursor;  // work records requested by the sweep (may exceed the capacity)
-	uint32_t emit_skipped;  // set by k_emit when it refused to run (capacity / overflow)
+	uint32_t slow_cursor;   // records left to k_slow_plan
+	uint32_t dirty_cursor;  // row segments whose offsets k_seg_fix has to rebuild
+	uint32_t emit_skipped;  // set by the emit kernels when they refused to run (capacity / overflow)
 	uint64_t totV, totT;    // totals over all classified slices (ghost included)
 	uint64_t ghostV, ghostT;
 };
@@ -49,26 +51,39 @@ struct Counters {
 struct SweepArgs {
 	GridView<sample_t> G;
 	Params P;
-	Tables tab;
+	const uint32_t *fast;    // per sign index: everything about a FAST cell (mc33_cell.h build_fast_table)
 	uint32_t ze;             // classify cell slices [P.zs, ze)
-	uint32_t z_emit;         // slices below are ghosts of a z-slab (their triangles are never written)
 	uint32_t nXG, nYT, rz;   // tiles: 4 segments wide, 63 cell rows high, rz slices deep
-	uint32_t *seg_cnt, *seg_first, *seg_nent;
+	uint32_t *seg_cnt;
+	SegEnt *seg_ent;
 	Entry *entries;
 	uint32_t *entry_seg;
+	uint32_t *slow_list, *dirty_list;
 	uint32_t entry_cap;
 	Counters *ctr;
 };
 
 __device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return (uint64_t)hi << 32 | lo; }
+__device__ __forceinline__ uint64_t shfl_down1(uint64_t x) {
+	return u64(__shfl_down((uint32_t)x, 1), __shfl_down((uint32_t)(x >> 32), 1));
+}
 
 // ---------------------------------------------------------------------------------------------------
 // k_sweep: one wave per tile column (256 samples in x, 64 sample rows, rz+1 planes), 4 waves per block
 // side by side in x so that a block reads whole 1024-sample (4 KiB) row pieces.
+//
+// Streaming part: every lane loads 4 samples of a row (x = xbase + 64k + lane: fully coalesced 256-byte
+// requests), v = iso - F, the sign bits of the 64 lanes are collected by ballot into one 64-bit word
+// per k, and the 4 words of sample row r are parked in lane r.  After a plane is in, lane r holds the
+// bits of row r for planes z and z+1 and gets row r+1 from its neighbour lane: the "all 8 corners on
+// the same side" test (MC:1860) of the 63 x 256 cells of the tile slice is ~100 logic ops per wave.
+// Cell part: only cells cut by the surface are touched.  FAST cells (see mc33_cell.h) are finished here
+// from their sign index alone; the others get a placeholder record for k_slow_plan.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
-	__shared__ float s_v[4][8][64];
-	__shared__ float s_w[4][8][64];
+	__shared__ uint32_t s_fast[256];
+	s_fast[threadIdx.x] = a.fast[threadIdx.x];
+	__syncthreads();  // the only block-level barrier (before any wave can leave)
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	uint32_t b = blockIdx.x;
 	const uint32_t xg = b % a.nXG;
@@ -76,7 +91,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	const uint32_t yt = b % a.nYT, zc = b / a.nYT;
 	const uint32_t seg = xg * 4 + wv;
 	const Params &P = a.P;
-	if (seg >= P.nseg) return;  // no block-level barrier is used below
+	if (seg >= P.nseg) return;
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
 	const uint32_t nrows = min(64u, P.ny + 1 - y0);  // sample rows of this tile
 	const uint32_t z_lo = P.zs + zc * a.rz, z_hi = min(z_lo + a.rz, a.ze);
@@ -95,18 +110,19 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		const uint32_t n = first >= P.nx ? 0u : min(64u, P.nx - first);
 		valid[k] = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
 	}
-	const bool rowvalid = lane < 63u && y0 + lane < P.ny;
+	const uint32_t y = y0 + lane;
+	const bool rowvalid = lane < 63u && y < P.ny;
 	const uint32_t rowclamp = min(lane, nrows - 1);
 
-	// sign bits of the tile: word k of row r lives in lane r
-	uint32_t cur_lo[4], cur_hi[4], prev_lo[4] = {0, 0, 0, 0}, prev_hi[4] = {0, 0, 0, 0};
-	uint32_t cur_h = 0, prev_h = 0;
-	const VRef v{&s_v[wv][0][lane], 64}, w{&s_w[wv][0][lane], 64};
+	// sign bits of the tile: word k of sample row r lives in lane r.  *_h: the halo sample's bit;
+	// *_z: "some sample of this row (this segment + halo) equals the isovalue"
+	uint64_t cur[4], prev[4] = {0, 0, 0, 0};
+	uint32_t cur_h = 0, prev_h = 0, cur_z = 0, prev_z = 0;
 
 	for (uint32_t p = z_lo; p <= z_hi; ++p) {
 		const sample_t *plane = a.G.p + (uint64_t)(p - a.G.z0) * a.G.slice + (uint64_t)y0 * a.G.pitch;
-#pragma unroll
-		for (int k = 0; k < 4; k++) cur_lo[k] = cur_hi[k] = 0;
+		uint32_t c_lo[4] = {0, 0, 0, 0}, c_hi[4] = {0, 0, 0, 0};
+		cur_z = 0;
 		for (uint32_t r = 0; r < nrows; r += 4) {
 			float d[4][4];
 #pragma unroll
@@ -118,39 +134,46 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 #pragma unroll
 			for (int rr = 0; rr < 4; rr++) {
 				const bool mine = lane == r + rr;  // the bit row of sample row r+rr is parked in lane r+rr
+				uint64_t zany = 0;
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
 					const uint64_t m = __ballot(__float_as_uint(d[rr][k]) >> 31);  // MC:1856-1859
-					cur_lo[k] = mine ? (uint32_t)m : cur_lo[k];
-					cur_hi[k] = mine ? (uint32_t)(m >> 32) : cur_hi[k];
+					c_lo[k] = mine ? (uint32_t)m : c_lo[k];
+					c_hi[k] = mine ? (uint32_t)(m >> 32) : c_hi[k];
+					zany |= __ballot(d[rr][k] == 0.0f);
 				}
+				cur_z = (mine && zany) ? 1u : cur_z;
 			}
 		}
-		// halo column: lane r reads sample xh of row r
-		cur_h = __float_as_uint(iso - (float)plane[(uint64_t)rowclamp * a.G.pitch + xh]) >> 31;
+#pragma unroll
+		for (int k = 0; k < 4; k++) cur[k] = u64(c_lo[k], c_hi[k]);
+		{  // halo column: lane r reads sample xh of row r
+			const float dh = iso - (float)plane[(uint64_t)rowclamp * a.G.pitch + xh];
+			cur_h = __float_as_uint(dh) >> 31;
+			cur_z |= (dh == 0.0f) ? 1u : 0u;
+		}
 
 		if (p > z_lo) {
 			const uint32_t z = p - 1;
-			// AND / OR of the four samples (y,z),(y+1,z),(y,z+1),(y+1,z+1) at every x of the segment
-			uint64_t A[4], O[4];
-#pragma unroll
-			for (int k = 0; k < 4; k++) {
-				const uint64_t q0 = u64(prev_lo[k], prev_hi[k]), q1 = u64(cur_lo[k], cur_hi[k]);
-				const uint64_t q0n = u64(__shfl_down(prev_lo[k], 1), __shfl_down(prev_hi[k], 1));
-				const uint64_t q1n = u64(__shfl_down(cur_lo[k], 1), __shfl_down(cur_hi[k], 1));
-				A[k] = q0 & q0n & q1 & q1n;
-				O[k] = q0 | q0n | q1 | q1n;
-			}
-			const uint32_t ph = __shfl_down(prev_h, 1), ch = __shfl_down(cur_h, 1);
-			const uint64_t hA = prev_h & ph & cur_h & ch, hO = prev_h | ph | cur_h | ch;
+			const uint32_t prev_hn = __shfl_down(prev_h, 1), cur_hn = __shfl_down(cur_h, 1);
+			// cells cut by the surface: NOT (all 8 sign bits one) and NOT (all zero)  (MC:1860)
 			uint64_t act[4];
+			{
+				uint64_t A[4], O[4];
 #pragma unroll
-			for (int k = 0; k < 4; k++) {
-				const uint64_t nA = (k < 3) ? (A[k < 3 ? k + 1 : 3] & 1ull) : hA;
-				const uint64_t nO = (k < 3) ? (O[k < 3 ? k + 1 : 3] & 1ull) : hO;
-				const uint64_t As = (A[k] >> 1) | (nA << 63), Os = (O[k] >> 1) | (nO << 63);
-				// a cell is skipped when its 8 sign bits are all ones or all zeros (MC:1860)
-				act[k] = rowvalid ? (~((A[k] & As) | ~(O[k] | Os)) & valid[k]) : 0ull;
+				for (int k = 0; k < 4; k++) {
+					const uint64_t q0n = shfl_down1(prev[k]), q1n = shfl_down1(cur[k]);
+					A[k] = prev[k] & q0n & cur[k] & q1n;
+					O[k] = prev[k] | q0n | cur[k] | q1n;
+				}
+				const uint64_t hA = prev_h & prev_hn & cur_h & cur_hn, hO = prev_h | prev_hn | cur_h | cur_hn;
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const uint64_t nA = (k < 3) ? (A[k < 3 ? k + 1 : 3] & 1ull) : hA;
+					const uint64_t nO = (k < 3) ? (O[k < 3 ? k + 1 : 3] & 1ull) : hO;
+					const uint64_t As = (A[k] >> 1) | (nA << 63), Os = (O[k] >> 1) | (nO << 63);
+					act[k] = rowvalid ? (~((A[k] & As) | ~(O[k] | Os)) & valid[k]) : 0ull;
+				}
 			}
 			const uint32_t cnt = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
 			uint32_t incl = cnt;
@@ -165,44 +188,128 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				if (lane == 0) base = atomicAdd(&a.ctr->entry_cursor, total);
 				base = __shfl(base, 0);
 			}
-			const uint32_t y = y0 + lane;
 			const uint64_t sidx = ((uint64_t)(z - P.zs) * P.ny + y) * P.nseg + seg;
 			uint32_t idx = base + incl - cnt, nv_run = 0, nt_run = 0;
 			const uint32_t first = idx;
-			for (;;) {
-				const bool has = (act[0] | act[1] | act[2] | act[3]) != 0ull;
-				if (!__any(has)) break;
-				if (has) {
-					uint32_t xl;
-					if (act[0]) { xl = (uint32_t)__ffsll((long long)act[0]) - 1u; act[0] &= act[0] - 1; }
-					else if (act[1]) { xl = 64u + (uint32_t)__ffsll((long long)act[1]) - 1u; act[1] &= act[1] - 1; }
-					else if (act[2]) { xl = 128u + (uint32_t)__ffsll((long long)act[2]) - 1u; act[2] &= act[2] - 1; }
-					else { xl = 192u + (uint32_t)__ffsll((long long)act[3]) - 1u; act[3] &= act[3] - 1; }
-					const uint32_t x = xbase + xl;
-					const uint32_t i = load_cell(a.G, iso, x, y, z, v);
-					CellPlan pl;
-					plan_cell(pl, a.tab, P, a.G, x, y, z, i, v);
-					// Ghost cells only lend vertex ids to the slab above; their triangle count cancels out of
-					// every offset, so the identity test (which may read one more plane below) is skipped.
-					const uint32_t nt = z < a.z_emit ? pl.ntri : count_triangles(pl, a.tab, P, a.G, x, y, z, w);
-					if (idx < a.entry_cap) {
-						a.entries[idx] = make_entry(xl, i, pl, nv_run, nt_run);
-						a.entry_seg[idx] = (uint32_t)sidx;
+			bool dirty = false;
+			if (total) {  // wave-uniform
+				// rows whose cells cannot take the fast path: on the y = 0 / z = 0 faces (extra owned edges),
+				// or with a sample equal to the isovalue among the four sample rows of the cell row
+				const bool rowslow = y == 0 || z == 0 || ((prev_z | cur_z | __shfl_down(prev_z, 1) | __shfl_down(cur_z, 1)) != 0);
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					// the four bit rows of this word, and the same shifted by one sample (x+1)
+					const uint64_t q0 = prev[k], q1 = cur[k], q0n = shfl_down1(prev[k]), q1n = shfl_down1(cur[k]);
+					uint64_t n0, n1, n0n, n1n;  // bit 0 of the next word of each row
+					if (k < 3) {
+						n0 = prev[k < 3 ? k + 1 : 3] & 1ull; n1 = cur[k < 3 ? k + 1 : 3] & 1ull;
+						n0n = shfl_down1(prev[k < 3 ? k + 1 : 3]) & 1ull; n1n = shfl_down1(cur[k < 3 ? k + 1 : 3]) & 1ull;
+					} else { n0 = prev_h; n1 = cur_h; n0n = prev_hn; n1n = cur_hn; }
+					const uint64_t q0s = (q0 >> 1) | (n0 << 63), q1s = (q1 >> 1) | (n1 << 63);
+					const uint64_t q0ns = (q0n >> 1) | (n0n << 63), q1ns = (q1n >> 1) | (n1n << 63);
+					uint64_t todo = act[k];
+					for (;;) {
+						const bool has = todo != 0ull;
+						if (!__any(has)) break;
+						if (has) {
+							const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
+							todo &= todo - 1;
+							const uint32_t xl = 64u * k + j;
+							// sign index, bit 7-c = corner c (MC:1846-1859): corners 0..3 at x, 4..7 at x+1
+							const uint32_t i = (uint32_t)((q0 >> j) & 1) << 7 | (uint32_t)((q0n >> j) & 1) << 6 | (uint32_t)((q1n >> j) & 1) << 5 |
+							                   (uint32_t)((q1 >> j) & 1) << 4 | (uint32_t)((q0s >> j) & 1) << 3 | (uint32_t)((q0ns >> j) & 1) << 2 |
+							                   (uint32_t)((q1ns >> j) & 1) << 1 | (uint32_t)((q1s >> j) & 1);
+							const uint32_t f = s_fast[i];
+							Entry e;
+							if (!rowslow && f != FAST_NONE && (xbase + xl) != 0) {
+								e = make_fast_entry(xl, i, f, nv_run, nt_run);
+								nv_run += (f >> 16) & 15u;
+								nt_run += (f >> 12) & 15u;
+							} else {
+								e = make_pending_entry(xl, i);
+								dirty = true;
+								if (idx < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = idx;
+							}
+							if (idx < a.entry_cap) {
+								a.entries[idx] = e;
+								a.entry_seg[idx] = (uint32_t)sidx;
+							}
+							idx++;
+						}
 					}
-					idx++;
-					nv_run += pl.nnew;
-					nt_run += nt;
 				}
 			}
 			if (rowvalid) {
-				a.seg_cnt[sidx] = seg_pack(nv_run, nt_run);
-				a.seg_first[sidx] = first;
-				a.seg_nent[sidx] = cnt;
+				a.seg_cnt[sidx] = dirty ? 0u : seg_pack(nv_run, nt_run);
+				a.seg_ent[sidx] = SegEnt{first, cnt | (dirty ? SEG_DIRTY : 0u)};
+				if (dirty && first < a.entry_cap) a.dirty_list[atomicAdd(&a.ctr->dirty_cursor, 1u)] = (uint32_t)sidx;
 			}
 		}
 #pragma unroll
-		for (int k = 0; k < 4; k++) { prev_lo[k] = cur_lo[k]; prev_hi[k] = cur_hi[k]; }
+		for (int k = 0; k < 4; k++) prev[k] = cur[k];
 		prev_h = cur_h;
+		prev_z = cur_z;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_slow_plan: cells the sweep could not finish from the sign index (ambiguous MC33 cases: face and
+// interior tests MC:347-462; cells on the x/y/z = 0 faces; corners equal to the isovalue MC:788-1224)
+// ---------------------------------------------------------------------------------------------------
+struct SlowArgs {
+	GridView<sample_t> G;
+	Params P;
+	Tables tab;
+	uint32_t z_emit;  // slices below are ghosts of a z-slab
+	Entry *entries;
+	const uint32_t *entry_seg;
+	const uint32_t *slow_list;
+	uint32_t *seg_cnt;
+	const SegEnt *seg_ent;
+	const uint32_t *dirty_list;
+	uint32_t entry_cap;
+	Counters *ctr;
+};
+
+__global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
+	__shared__ float s_v[8][256];
+	__shared__ float s_w[8][256];
+	if (a.ctr->entry_cursor > a.entry_cap) return;  // the sweep is going to be repeated with more room
+	const uint32_t n = a.ctr->slow_cursor;
+	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
+	const Params &P = a.P;
+	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+		const uint32_t ei = a.slow_list[t];
+		const uint32_t s = a.entry_seg[ei];
+		const uint32_t xl = a.entries[ei].w0 & 0xFFu;
+		const uint32_t sx = s % P.nseg, row = s / P.nseg;
+		const uint32_t y = row % P.ny, z = row / P.ny + P.zs, x = sx * SEG_CELLS + xl;
+		const uint32_t i = load_cell(a.G, P.iso, x, y, z, v);
+		CellPlan pl;
+		plan_cell(pl, a.tab, P, a.G, x, y, z, i, v);
+		// Ghost cells only lend vertex ids to the slab above; their triangle count cancels out of every
+		// offset, so the identity test (which may read one more plane below) is skipped.
+		const uint32_t nt = z < a.z_emit ? pl.ntri : count_triangles(pl, a.tab, P, a.G, x, y, z, w);
+		a.entries[ei] = make_entry(xl, i, pl, nt, 0, 0, true);
+	}
+}
+
+// one thread per row segment that holds slow cells: running offsets of its records, segment totals
+__global__ __launch_bounds__(256) void k_seg_fix(const SlowArgs a) {
+	if (a.ctr->entry_cursor > a.entry_cap) return;
+	const uint32_t n = a.ctr->dirty_cursor;
+	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+		const uint32_t s = a.dirty_list[t];
+		const SegEnt se = a.seg_ent[s];
+		const uint32_t cnt = se.nent & ~SEG_DIRTY;
+		uint32_t nv = 0, nt = 0;
+		for (uint32_t k = 0; k < cnt; k++) {
+			Entry *e = a.entries + se.first + k;
+			e->w1 = nv | nt << 16;
+			nv += entry_nnew(*e);
+			nt += entry_ntri(*e);
+		}
+		a.seg_cnt[s] = seg_pack(nv, nt);
 	}
 }
 
@@ -256,7 +363,7 @@ __global__ __launch_bounds__(1024) void k_scan_spine(uint64_t *bsV, uint64_t *bs
 }
 
 __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uint64_t n, const uint64_t *bsV, const uint64_t *bsT,
-                                                    uint32_t *seg_vbase, uint32_t *seg_tbase, uint64_t ghost_segs, Counters *ctr) {
+                                                    SegBase *seg_base, uint64_t ghost_segs, Counters *ctr) {
 	__shared__ uint32_t sv[4], st[4];
 	const uint64_t q0 = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
 	uint32_t cv[SCAN_PER_THREAD], ct[SCAN_PER_THREAD], v = 0, t = 0;
@@ -280,7 +387,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uin
 #pragma unroll
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
 		if (q0 + k < n) {
-			seg_vbase[q0 + k] = ev; seg_tbase[q0 + k] = et;
+			seg_base[q0 + k] = SegBase{ev, et};
 			if (q0 + k == ghost_segs) { ctr->ghostV = ev; ctr->ghostT = et; }  // first segment of the emitted range
 		}
 		ev += cv[k]; et += ct[k];
@@ -288,36 +395,58 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uin
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_emit: one thread per work record
+// emit: one thread per work record.  k_emit_fast handles the records the sweep finished itself,
+// k_emit_slow the ones k_slow_plan planned (generic path: aliases, cells on the grid faces, ...)
 // ---------------------------------------------------------------------------------------------------
 struct EmitArgs {
 	EmitCtx<sample_t> c;
 	Counters *ctr;
+	const uint32_t *slow_list;
 	uint32_t entry_cap;
 	uint64_t capV, capT;
 	uint64_t ghost_segs;  // row segments of the ghost slice (0 without ghost)
 	uint32_t id_base;
 };
 
-__global__ __launch_bounds__(256) void k_emit(const EmitArgs a) {
-	__shared__ float s_v[8][256];
-	__shared__ float s_w[8][256];
-	__shared__ uint32_t s_id[13][256];
-	const Counters ctr = *a.ctr;
+// capacity / overflow check shared by both emit kernels; fills the slab offsets of the context
+__device__ __forceinline__ bool emit_prepare(const EmitArgs &a, EmitCtx<sample_t> &c, const Counters &ctr) {
 	const uint64_t gV = a.ghost_segs ? ctr.ghostV : 0, gT = a.ghost_segs ? ctr.ghostT : 0;
 	if (ctr.entry_cursor > a.entry_cap || ctr.totV - gV > a.capV || ctr.totT - gT > a.capT || ctr.totV > 0xFFFFFFFFull ||
 	    ctr.totT > 0xFFFFFFFFull || (uint64_t)a.id_base + (ctr.totV - gV) > 0xFFFFFFFFull) {
 		if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->emit_skipped = 1;
-		return;
+		return false;
 	}
-	EmitCtx<sample_t> c = a.c;
 	c.v_skip = (uint32_t)gV;
 	c.t_skip = (uint32_t)gT;
 	c.id_delta = a.id_base - (uint32_t)gV;
-	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
+	return true;
+}
+
+__global__ __launch_bounds__(256) void k_emit_fast(const EmitArgs a) {
+	__shared__ uint32_t s_id[12][256];
+	const Counters ctr = *a.ctr;
+	EmitCtx<sample_t> c = a.c;
+	if (!emit_prepare(a, c, ctr)) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
 	const uint32_t n = ctr.entry_cursor;
-	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) emit_cell(c, e, v, w, ids);
+	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+		const Entry en = c.entries[e];
+		if (en.w3 & ENTRY_SLOW) continue;
+		emit_fast_cell(c, en, c.entry_seg[e], ids);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_emit_slow(const EmitArgs a) {
+	__shared__ float s_v[8][256];
+	__shared__ float s_w[8][256];
+	__shared__ uint32_t s_id[13][256];
+	const Counters ctr = *a.ctr;
+	EmitCtx<sample_t> c = a.c;
+	if (!emit_prepare(a, c, ctr)) return;
+	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
+	const URef ids{&s_id[0][threadIdx.x], 256};
+	const uint32_t n = ctr.slow_cursor;
+	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) emit_cell(c, a.slow_list[t], v, w, ids);
 }
 
 // ===================================================================================================
@@ -350,12 +479,15 @@ struct mc33hip_ctx {
 	uint16_t *d_lut;
 	uint32_t *d_rules;
 	uint8_t *d_rule_index;
-	uint32_t *seg_cnt, *seg_first, *seg_nent, *seg_vbase, *seg_tbase;
+	uint32_t *d_fast;
+	uint32_t *seg_cnt;
+	SegEnt *seg_ent;
+	SegBase *seg_base;
 	uint64_t seg_cap;
 	uint64_t *bsV, *bsT;
 	uint64_t bs_cap;
 	Entry *entries;
-	uint32_t *entry_seg;
+	uint32_t *entry_seg, *slow_list, *dirty_list;
 	uint64_t entry_cap;
 	Counters *d_ctr, *h_ctr;
 	hipEvent_t ev[4];
@@ -407,6 +539,12 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	CREATE_TRY(hipMemcpy(c->d_lut, mc33_lut, sizeof mc33_lut, hipMemcpyHostToDevice));
 	CREATE_TRY(hipMemcpy(c->d_rules, mc33_rule_words, sizeof mc33_rule_words, hipMemcpyHostToDevice));
 	CREATE_TRY(hipMemcpy(c->d_rule_index, mc33_rule_index, sizeof mc33_rule_index, hipMemcpyHostToDevice));
+	{
+		uint32_t fast[256];
+		build_fast_table(mc33_lut, fast);
+		CREATE_TRY(hipMalloc(&c->d_fast, sizeof fast));
+		CREATE_TRY(hipMemcpy(c->d_fast, fast, sizeof fast, hipMemcpyHostToDevice));
+	}
 	CREATE_TRY(hipMalloc(&c->d_ctr, sizeof(Counters)));
 	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
 	for (int k = 0; k < 4; k++) CREATE_TRY(hipEventCreate(&c->ev[k]));
@@ -420,11 +558,10 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	else (void)hipDeviceSynchronize();
 	if (c->owns_grid) (void)hipFree(c->d_grid);
-	(void)hipFree(c->d_lut); (void)hipFree(c->d_rules); (void)hipFree(c->d_rule_index);
-	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_first); (void)hipFree(c->seg_nent);
-	(void)hipFree(c->seg_vbase); (void)hipFree(c->seg_tbase);
+	(void)hipFree(c->d_lut); (void)hipFree(c->d_rules); (void)hipFree(c->d_rule_index); (void)hipFree(c->d_fast);
+	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_ent); (void)hipFree(c->seg_base);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
-	(void)hipFree(c->entries); (void)hipFree(c->entry_seg);
+	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
@@ -548,14 +685,12 @@ static uint32_t env_u32(const char *name, uint32_t dflt) {
 
 static int ensure_workspaces(mc33hip_ctx *c) {
 	if (c->seg_cap < c->nsegs) {
-		(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_first); (void)hipFree(c->seg_nent); (void)hipFree(c->seg_vbase); (void)hipFree(c->seg_tbase);
-		c->seg_cnt = c->seg_first = c->seg_nent = c->seg_vbase = c->seg_tbase = nullptr;
+		(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_ent); (void)hipFree(c->seg_base);
+		c->seg_cnt = nullptr; c->seg_ent = nullptr; c->seg_base = nullptr;
 		c->seg_cap = 0;
 		HIP_TRY(hipMalloc(&c->seg_cnt, c->nsegs * 4));
-		HIP_TRY(hipMalloc(&c->seg_first, c->nsegs * 4));
-		HIP_TRY(hipMalloc(&c->seg_nent, c->nsegs * 4));
-		HIP_TRY(hipMalloc(&c->seg_vbase, c->nsegs * 4));
-		HIP_TRY(hipMalloc(&c->seg_tbase, c->nsegs * 4));
+		HIP_TRY(hipMalloc(&c->seg_ent, c->nsegs * sizeof(SegEnt)));
+		HIP_TRY(hipMalloc(&c->seg_base, c->nsegs * sizeof(SegBase)));
 		c->seg_cap = c->nsegs;
 	}
 	const uint64_t nb = (c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -574,24 +709,28 @@ static int ensure_workspaces(mc33hip_ctx *c) {
 		if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
 		HIP_TRY(hipMalloc(&c->entries, cap * sizeof(Entry)));
 		HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
+		HIP_TRY(hipMalloc(&c->slow_list, cap * 4));
+		HIP_TRY(hipMalloc(&c->dirty_list, cap * 4));
 		c->entry_cap = cap;
 	}
 	return 0;
 }
 
 static int grow_entries(mc33hip_ctx *c, uint64_t need) {
-	(void)hipFree(c->entries); (void)hipFree(c->entry_seg);
-	c->entries = nullptr; c->entry_seg = nullptr; c->entry_cap = 0;
+	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
+	c->entries = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr; c->entry_cap = 0;
 	uint64_t cap = need + need / 8 + 4096;
 	if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
 	if (cap < need) { set_err("more than 2^32 work records"); return MC33HIP_EOVERFLOW; }
 	HIP_TRY(hipMalloc(&c->entries, cap * sizeof(Entry)));
 	HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
+	HIP_TRY(hipMalloc(&c->slow_list, cap * 4));
+	HIP_TRY(hipMalloc(&c->dirty_list, cap * 4));
 	c->entry_cap = cap;
 	return 0;
 }
 
-// enqueue sweep + scans on the context's stream (no synchronisation)
+// enqueue sweep + slow-cell planning + scans on the context's stream (no synchronisation)
 static int enqueue_count(mc33hip_ctx *c) {
 	const Params &P = c->P;
 	hipStream_t st = c->stream;
@@ -599,15 +738,15 @@ static int enqueue_count(mc33hip_ctx *c) {
 	SweepArgs a;
 	a.G.p = c->d_grid; a.G.pitch = (uint32_t)c->pitch; a.G.z0 = c->desc.plane0; a.G.slice = c->slice;
 	a.P = P;
-	a.tab.lut = c->d_lut; a.tab.rule_words = c->d_rules; a.tab.rule_index = c->d_rule_index;
+	a.fast = c->d_fast;
 	a.ze = c->range.z_end;
-	a.z_emit = c->range.z_begin;
 	a.nXG = (P.nseg + 3) / 4;
 	a.nYT = (P.ny + 62) / 63;
 	a.rz = env_u32("MC33_HIP_RZ", 16);
 	const uint32_t nZC = (a.ze - P.zs + a.rz - 1) / a.rz;
-	a.seg_cnt = c->seg_cnt; a.seg_first = c->seg_first; a.seg_nent = c->seg_nent;
-	a.entries = c->entries; a.entry_seg = c->entry_seg; a.entry_cap = (uint32_t)c->entry_cap;
+	a.seg_cnt = c->seg_cnt; a.seg_ent = c->seg_ent;
+	a.entries = c->entries; a.entry_seg = c->entry_seg; a.slow_list = c->slow_list; a.dirty_list = c->dirty_list;
+	a.entry_cap = (uint32_t)c->entry_cap;
 	a.ctr = c->d_ctr;
 	const uint64_t blocks = (uint64_t)a.nXG * a.nYT * nZC;
 	if (blocks > 0x7FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
@@ -615,11 +754,21 @@ static int enqueue_count(mc33hip_ctx *c) {
 	hipLaunchKernelGGL(k_sweep, dim3((uint32_t)blocks), dim3(256), 0, st, a);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c->ev[1], st));
+	SlowArgs sa;
+	sa.G = a.G; sa.P = P;
+	sa.tab.lut = c->d_lut; sa.tab.rule_words = c->d_rules; sa.tab.rule_index = c->d_rule_index;
+	sa.z_emit = c->range.z_begin;
+	sa.entries = c->entries; sa.entry_seg = c->entry_seg; sa.slow_list = c->slow_list;
+	sa.seg_cnt = c->seg_cnt; sa.seg_ent = c->seg_ent; sa.dirty_list = c->dirty_list;
+	sa.entry_cap = (uint32_t)c->entry_cap; sa.ctr = c->d_ctr;
+	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);
+	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks), dim3(256), 0, st, sa);
+	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
 	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
 	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, c->bsV, c->bsT);
 	hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, c->bsV, c->bsT, nb, c->d_ctr);
-	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, c->bsV, c->bsT, c->seg_vbase, c->seg_tbase,
-	                   c->ghost_segs, c->d_ctr);
+	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, c->bsV, c->bsT, c->seg_base, c->ghost_segs,
+	                   c->d_ctr);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c->ev[2], st));
 	return 0;
@@ -630,17 +779,19 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.c.tab.lut = c->d_lut; a.c.tab.rule_words = c->d_rules; a.c.tab.rule_index = c->d_rule_index;
 	a.c.P = c->P;
 	a.c.G.p = c->d_grid; a.c.G.pitch = (uint32_t)c->pitch; a.c.G.z0 = c->desc.plane0; a.c.G.slice = c->slice;
-	a.c.seg_vbase = c->seg_vbase; a.c.seg_tbase = c->seg_tbase; a.c.seg_first = c->seg_first; a.c.seg_nent = c->seg_nent;
+	a.c.seg_base = c->seg_base; a.c.seg_ent = c->seg_ent;
 	a.c.entries = c->entries; a.c.entry_seg = c->entry_seg;
 	a.c.V = (float *)dV; a.c.N = (float *)dN; a.c.Tri = (uint32_t *)dT;
 	a.c.z_emit = c->range.z_begin; a.c.v_skip = a.c.t_skip = a.c.id_delta = 0;
 	a.ctr = c->d_ctr;
+	a.slow_list = c->slow_list;
 	a.entry_cap = (uint32_t)c->entry_cap;
 	a.capV = capV; a.capT = capT;
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
 	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 8u);
-	hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, c->stream, a);
+	hipLaunchKernelGGL(k_emit_fast, dim3(blocks), dim3(256), 0, c->stream, a);
+	hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, c->stream, a);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c->ev[3], c->stream));
 	return 0;

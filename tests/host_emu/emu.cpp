@@ -51,7 +51,13 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	Tables tab{mc33_lut, mc33_rule_words, &mc33_rule_index[0][0]};
 
 	const uint64_t nsegs = (uint64_t)(ze - P.zs) * P.ny * P.nseg;
-	std::vector<uint32_t> seg_cnt(nsegs, 0), seg_first(nsegs, 0), seg_nent(nsegs, 0), seg_vbase(nsegs), seg_tbase(nsegs);
+	std::vector<uint32_t> seg_cnt(nsegs, 0);
+	std::vector<SegEnt> seg_ent(nsegs, SegEnt{0, 0});
+	std::vector<SegBase> seg_base(nsegs);
+	uint32_t fast[256];
+	build_fast_table(mc33_lut, fast);
+	const char *force = getenv("MC33_EMU_FORCE_SLOW");  // "all": no fast path; "odd": cells with odd x go slow
+	const int force_mode = !force ? 0 : (force[0] == 'a' ? 1 : 2);
 	std::vector<Entry> entries;
 	std::vector<uint32_t> entry_seg;
 	float vbuf[8], wbuf[8];
@@ -64,36 +70,49 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 			for (uint32_t x = 0; x < P.nx; x++) {
 				const uint32_t i = load_cell(G, iso, x, y, z, v);
 				if (i == 0 || i == 0xFF) continue;
-				CellPlan p;
-				plan_cell(p, tab, P, G, x, y, z, i, v);
-				const uint32_t nt = z < z_emit ? p.ntri : count_triangles(p, tab, P, G, x, y, z, w);  // as k_sweep
 				const uint64_t s = segment_index(P, x, y, z);
-				if (seg_nent[s] == 0) seg_first[s] = (uint32_t)entries.size();
+				if (seg_ent[s].nent == 0) seg_ent[s].first = (uint32_t)entries.size();
 				const uint32_t voff = seg_cnt[s] & 0xFFFF, toff = seg_cnt[s] >> 16;
-				entries.push_back(make_entry(x % SEG_CELLS, i, p, voff, toff));
+				bool zero = false;
+				for (int k = 0; k < 8; k++) zero |= v[k] == 0;
+				bool is_fast = x && y && z && fast[i] != FAST_NONE && !zero;
+				if (force_mode == 1 || (force_mode == 2 && (x & 1))) is_fast = false;
+				if (is_fast) {  // as k_sweep: everything from the sign index
+					const uint32_t f = fast[i];
+					entries.push_back(make_fast_entry(x % SEG_CELLS, i, f, voff, toff));
+					seg_cnt[s] = seg_pack(voff + ((f >> 16) & 15u), toff + ((f >> 12) & 15u));
+				} else {        // as k_slow_plan + k_seg_fix
+					CellPlan p;
+					plan_cell(p, tab, P, G, x, y, z, i, v);
+					const uint32_t nt = z < z_emit ? p.ntri : count_triangles(p, tab, P, G, x, y, z, w);
+					entries.push_back(make_entry(x % SEG_CELLS, i, p, nt, voff, toff, true));
+					seg_cnt[s] = seg_pack(voff + p.nnew, toff + nt);
+				}
 				entry_seg.push_back((uint32_t)s);
-				seg_nent[s]++;
-				seg_cnt[s] = seg_pack(voff + p.nnew, toff + nt);
+				seg_ent[s].nent++;
 			}
 	// scan
 	uint64_t nV = 0, nT = 0;
 	for (uint64_t s = 0; s < nsegs; s++) {
-		seg_vbase[s] = (uint32_t)nV; seg_tbase[s] = (uint32_t)nT;
+		seg_base[s].vbase = (uint32_t)nV; seg_base[s].tbase = (uint32_t)nT;
 		nV += seg_cnt[s] & 0xFFFF; nT += seg_cnt[s] >> 16;
 	}
 	const uint64_t gseg = (uint64_t)(z_emit - P.zs) * P.ny * P.nseg;
-	const uint32_t gV = gseg ? seg_vbase[gseg] : 0, gT = gseg ? seg_tbase[gseg] : 0;
+	const uint32_t gV = gseg ? seg_base[gseg].vbase : 0, gT = gseg ? seg_base[gseg].tbase : 0;
 	nV -= gV; nT -= gT;
 	out->nV = (uint32_t)nV; out->nT = (uint32_t)nT;
 	out->V = (float *)malloc(nV * 12 + 16); out->N = (float *)malloc(nV * 12 + 16); out->T = (uint32_t *)malloc(nT * 12 + 16);
 	memset(out->T, 0xFF, nT * 12);
 	EmitCtx<T> c;
 	c.tab = tab; c.P = P; c.G = G;
-	c.seg_vbase = seg_vbase.data(); c.seg_tbase = seg_tbase.data(); c.seg_first = seg_first.data(); c.seg_nent = seg_nent.data();
+	c.seg_base = seg_base.data(); c.seg_ent = seg_ent.data();
 	c.entries = entries.data(); c.entry_seg = entry_seg.data();
 	c.V = out->V; c.N = out->N; c.Tri = out->T;
 	c.z_emit = z_emit; c.v_skip = gV; c.t_skip = gT; c.id_delta = id_base - gV;
-	for (size_t k = 0; k < entries.size(); k++) emit_cell(c, (uint32_t)k, v, w, ids);
+	for (size_t k = 0; k < entries.size(); k++) {
+		if (entries[k].w3 & ENTRY_SLOW) emit_cell(c, (uint32_t)k, v, w, ids);
+		else emit_fast_cell(c, entries[k], entry_seg[k], ids);
+	}
 	return 0;
 }
 
