@@ -592,10 +592,15 @@ inline void build_fast_table(const uint16_t *lut, uint32_t *fast /*[256]*/) {
 	}
 }
 
-// directory of the row segments
-struct SegEnt {
-	uint32_t first;  // first entry of the segment
-	uint32_t nent;   // number of entries (bit 31: the sweep left cells for the slow kernel)
+// Directory of the row segments.  A row segment = the cells (x in [256 s, 256 s + 256), y, z).  Records
+// are STORED in the order [z][s][y] (the 63 rows a wave handles are contiguous: coalesced writes), while
+// the prefix sums run over them in the reference's sweep order [z][y][s] (segment_sweep_to_store).
+struct SegDir {
+	uint32_t first;    // first work record of the segment
+	uint32_t nent;     // number of records (bit 31: the sweep left cells for the slow kernel)
+	uint32_t maskidx;  // seg_mask[4*maskidx .. +3]: which of the 256 cells are active, 64 per word
+	uint32_t pre;      // active cells in words 0 | 0..1 | 0..2 (one byte each): record index of a cell is
+	                   // first + (bytes of pre for its word) + popcount(lower bits of its word)
 };
 struct SegBase {
 	uint32_t vbase, tbase;  // exclusive scans of the per-segment counts, in sweep order
@@ -603,8 +608,26 @@ struct SegBase {
 constexpr uint32_t SEG_DIRTY = 1u << 31;
 
 MC33_HD uint64_t segment_index(const Params &P, uint32_t x, uint32_t y, uint32_t z) {
-	return ((uint64_t)(z - P.zs) * P.ny + y) * P.nseg + x / SEG_CELLS;
+	return ((uint64_t)(z - P.zs) * P.nseg + x / SEG_CELLS) * P.ny + y;
 }
+// position q in sweep order ([z][y][s]) -> storage index
+MC33_HD uint64_t segment_sweep_to_store(const Params &P, uint64_t q) {
+	const uint64_t zy = q / P.nseg, sg = q % P.nseg;
+	const uint64_t z = zy / P.ny, y = zy % P.ny;
+	return (z * P.nseg + sg) * P.ny + y;
+}
+struct SegCoord {
+	uint32_t xbase, y, z;
+};
+MC33_HD SegCoord segment_coord(const Params &P, uint32_t s) {
+	SegCoord c;
+	c.y = s % P.ny;
+	const uint32_t t = s / P.ny;
+	c.xbase = (t % P.nseg) * SEG_CELLS;
+	c.z = t / P.nseg + P.zs;
+	return c;
+}
+MC33_HD uint32_t pack_prefix(uint32_t n0, uint32_t n1, uint32_t n2) { return n0 | (n0 + n1) << 8 | (n0 + n1 + n2) << 16; }
 
 template <typename T>
 struct EmitCtx {
@@ -612,7 +635,8 @@ struct EmitCtx {
 	Params P;
 	GridView<T> G;
 	const SegBase *seg_base;
-	const SegEnt *seg_ent;
+	const SegDir *seg_dir;
+	const uint64_t *seg_mask;
 	const Entry *entries;
 	const uint32_t *entry_seg;  // row segment of each entry
 	float *V, *N;
@@ -626,24 +650,30 @@ struct EmitCtx {
 // per-segment counts packed in one word: vertices (<= 13*256) | triangles (<= 12*256) << 16
 MC33_HD uint32_t seg_pack(uint32_t nv, uint32_t nt) { return nv | nt << 16; }
 
+// work record of the active cell (x,y,z), through the directory (no search: the segment's activity mask
+// gives the rank of the cell among the segment's records)
+MC33_HD uint32_t record_rank(const SegDir &d, uint64_t word, uint32_t xl) {
+	const uint32_t k = xl >> 6;
+	const uint32_t before = k ? (d.pre >> (8 * (k - 1))) & 0xFFu : 0u;
+	return d.first + before + (uint32_t)__builtin_popcountll(word & ((1ull << (xl & 63u)) - 1ull));
+}
+template <typename T>
+MC33_HD uint32_t find_record(const EmitCtx<T> &c, uint64_t s, uint32_t xl) {
+	const SegDir d = c.seg_dir[s];
+	const uint64_t word = c.seg_mask[4ull * d.maskidx + (xl >> 6)];
+	if (!((word >> (xl & 63u)) & 1ull)) return NO_ID;
+	return record_rank(d, word, xl);
+}
+
 // id of the vertex on a grid edge, through the owner's entry (emit pass).  w: scratch for 8 values.
 template <typename T>
 MC33_HD uint32_t edge_vertex_id(const EmitCtx<T> &c, GridEdge g, const VRef &w) {
 	for (int hop = 0; hop < 64; hop++) {
 		const OwnerRef o = owner_of(g.axis, g.x, g.y, g.z);
 		const uint64_t s = segment_index(c.P, o.x, o.y, o.z);
-		const SegEnt se = c.seg_ent[s];
-		const uint32_t first = se.first, n = se.nent & ~SEG_DIRTY, xl = o.x % SEG_CELLS;
-		// entries of a segment are sorted by x: binary search
-		uint32_t lo = 0, hi = n;
-		while (lo < hi) {
-			const uint32_t mid = (lo + hi) >> 1;
-			if ((c.entries[first + mid].w0 & 0xFFu) < xl) lo = mid + 1;
-			else hi = mid;
-		}
-		if (lo >= n) return NO_ID;
-		const Entry e = c.entries[first + lo];
-		if ((e.w0 & 0xFFu) != xl) return NO_ID;
+		const uint32_t ri = find_record(c, s, o.x % SEG_CELLS);
+		if (ri == NO_ID) return NO_ID;
+		const Entry e = c.entries[ri];
 		const uint32_t r = entry_rank(e, o.e);
 		if (r != 15u) return c.seg_base[s].vbase + (e.w1 & 0xFFFFu) + r;
 		// the owner itself took the id from another grid edge: recompute its plan to learn which
@@ -662,10 +692,10 @@ template <typename T>
 MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v, const VRef &w, const URef &ids) {
 	const Entry en = c.entries[entry_index];
 	const uint32_t s = c.entry_seg[entry_index];
-	const uint32_t sx = s % c.P.nseg, row = s / c.P.nseg;
-	const uint32_t y = row % c.P.ny, z = row / c.P.ny + c.P.zs;
+	const SegCoord sc = segment_coord(c.P, s);
+	const uint32_t y = sc.y, z = sc.z;
 	if (z < c.z_emit) return;
-	const uint32_t x = sx * SEG_CELLS + (en.w0 & 0xFFu);
+	const uint32_t x = sc.xbase + (en.w0 & 0xFFu);
 	const SegBase sb = c.seg_base[s];
 	const uint32_t vbase = sb.vbase + (en.w1 & 0xFFFFu);
 	uint32_t tpos = sb.tbase + (en.w1 >> 16) - c.t_skip;
@@ -706,28 +736,6 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 }
 
 // --- fast emit ---------------------------------------------------------------------------------------
-// id of the vertex on edge `oe` of the FAST cell's neighbour (ox,oy,oz).  The edge has no end point equal to
-// the isovalue (it is an edge of a fast cell too), so its owner created a regular vertex: no alias to follow.
-template <typename T>
-MC33_HD uint32_t owner_edge_id(const EmitCtx<T> &c, uint32_t ox, uint32_t oy, uint32_t oz, uint32_t e0, uint32_t e1,
-                               uint32_t &id1) {
-	const uint64_t s = segment_index(c.P, ox, oy, oz);
-	const SegEnt se = c.seg_ent[s];
-	const uint32_t vb = c.seg_base[s].vbase;
-	const uint32_t n = se.nent & ~SEG_DIRTY, xl = ox % SEG_CELLS;
-	if (!n) { id1 = NO_ID; return NO_ID; }  // cannot happen for a cut edge; never read past the records
-	uint32_t lo = 0, hi = n;
-	while (lo < hi) {
-		const uint32_t mid = (lo + hi) >> 1;
-		if ((c.entries[se.first + mid].w0 & 0xFFu) < xl) lo = mid + 1;
-		else hi = mid;
-	}
-	const Entry e = c.entries[se.first + (lo < n ? lo : n - 1)];
-	const uint32_t base = vb + (e.w1 & 0xFFFFu);
-	id1 = base + entry_rank(e, e1);
-	return base + entry_rank(e, e0);
-}
-
 // vertex of one of the three owned edges (5: z-edge, 6: y-edge, 10: x-edge, all through corner 6) of an
 // interior cell; same arithmetic as vertex_on_edge, written out so that every index is static
 template <typename T, int E>
@@ -771,48 +779,66 @@ MC33_HD void fast_owned_vertex(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint
 }
 
 // Emit pass for one FAST entry (see make_fast_entry).  ids: 12-slot scratch.
+// The six neighbours that own the other nine edges are looked up TOGETHER: all
+// directory records first, then all mask words, then all work records - three dependent round trips to
+// memory in total instead of three per neighbour.  A neighbour that is not needed is redirected to this
+// cell's own records (valid addresses, cached), so the loads carry no control flow.  The edges have no end
+// point equal to the isovalue (they are edges of a fast cell), so their owners created regular vertices:
+// no alias to follow.
 template <typename T>
-MC33_HD void emit_fast_cell(const EmitCtx<T> &c, const Entry &en, uint32_t s, const URef &ids) {
-	const uint32_t sx = s % c.P.nseg, row = s / c.P.nseg;
-	const uint32_t y = row % c.P.ny, z = row / c.P.ny + c.P.zs;
+MC33_HD void emit_fast_cell(const EmitCtx<T> &c, const Entry &en, uint32_t s, uint32_t self_index, const URef &ids) {
+	const SegCoord sc = segment_coord(c.P, s);
+	const uint32_t y = sc.y, z = sc.z;
 	if (z < c.z_emit) return;
-	const uint32_t x = sx * SEG_CELLS + (en.w0 & 0xFFu);
-	const SegBase sb = c.seg_base[s];
-	const uint32_t vbase = sb.vbase + (en.w1 & 0xFFFFu);
-	uint32_t tpos = sb.tbase + (en.w1 >> 16) - c.t_skip;
+	const uint32_t xl = en.w0 & 0xFFu, x = sc.xbase + xl;
 	const uint32_t i = (en.w0 >> 8) & 0xFFu;
+#define MC33_SIDE(k) ((i >> (7 - (k))) & 1u)
+	// edge k of this cell is edge k' of its owner:
+	//   o=0 (x-1,y,z-1): 0->6 | o=1 (x-1,y,z): 1->5, 2->6 | o=2 (x-1,y-1,z): 3->5 |
+	//   o=3 (x,y,z-1): 4->6, 9->10 | o=4 (x,y-1,z): 7->5, 11->10 | o=5 (x,y-1,z-1): 8->10
+	const bool cut0 = MC33_SIDE(0) != MC33_SIDE(1), cut1 = MC33_SIDE(1) != MC33_SIDE(2), cut2 = MC33_SIDE(3) != MC33_SIDE(2);
+	const bool cut3 = MC33_SIDE(0) != MC33_SIDE(3), cut4 = MC33_SIDE(4) != MC33_SIDE(5), cut9 = MC33_SIDE(1) != MC33_SIDE(5);
+	const bool cut7 = MC33_SIDE(4) != MC33_SIDE(7), cut11 = MC33_SIDE(3) != MC33_SIDE(7), cut8 = MC33_SIDE(0) != MC33_SIDE(4);
+#undef MC33_SIDE
+	const bool need[6] = {cut0, cut1 || cut2, cut3, cut4 || cut9, cut7 || cut11, cut8};
+	const uint32_t odx[6] = {1, 1, 1, 0, 0, 0}, ody[6] = {0, 0, 1, 0, 1, 1}, odz[6] = {1, 0, 0, 1, 0, 1};
+	uint64_t os[6];
+	uint32_t oxl[6];
+	SegDir od[6];
+	uint32_t ovb[6];
+	for (int o = 0; o < 6; o++) {  // round trip 1: directory + vertex bases (plus this cell's own bases and corners)
+		const uint32_t ox = x - odx[o];
+		os[o] = need[o] ? segment_index(c.P, ox, y - ody[o], z - odz[o]) : (uint64_t)s;
+		oxl[o] = need[o] ? ox % SEG_CELLS : xl;
+		od[o] = c.seg_dir[os[o]];
+		ovb[o] = c.seg_base[os[o]].vbase;
+	}
+	const SegBase sb = c.seg_base[s];
 	float v[8];
 	v[0] = c.P.iso - (float)c.G.at(x, y, z);         v[1] = c.P.iso - (float)c.G.at(x, y + 1, z);
 	v[2] = c.P.iso - (float)c.G.at(x, y + 1, z + 1); v[3] = c.P.iso - (float)c.G.at(x, y, z + 1);
 	v[4] = c.P.iso - (float)c.G.at(x + 1, y, z);     v[5] = c.P.iso - (float)c.G.at(x + 1, y + 1, z);
 	v[6] = c.P.iso - (float)c.G.at(x + 1, y + 1, z + 1); v[7] = c.P.iso - (float)c.G.at(x + 1, y, z + 1);
-	// cut edges: end points on different sides (bit 7-k of i is the side of corner k)
-	const uint32_t b = i;
-#define MC33_SIDE(k) ((b >> (7 - (k))) & 1u)
+	uint64_t ow[6];
+	for (int o = 0; o < 6; o++) ow[o] = c.seg_mask[4ull * od[o].maskidx + (oxl[o] >> 6)];  // round trip 2: activity masks
+	Entry oe[6];
+	for (int o = 0; o < 6; o++) oe[o] = c.entries[need[o] ? record_rank(od[o], ow[o], oxl[o]) : self_index];  // round trip 3
+	uint32_t ob[6];
+	for (int o = 0; o < 6; o++) ob[o] = ovb[o] + (oe[o].w1 & 0xFFFFu);
+	ids[0] = ob[0] + entry_rank(oe[0], 6);
+	ids[1] = ob[1] + entry_rank(oe[1], 5);  ids[2] = ob[1] + entry_rank(oe[1], 6);
+	ids[3] = ob[2] + entry_rank(oe[2], 5);
+	ids[4] = ob[3] + entry_rank(oe[3], 6);  ids[9] = ob[3] + entry_rank(oe[3], 10);
+	ids[7] = ob[4] + entry_rank(oe[4], 5);  ids[11] = ob[4] + entry_rank(oe[4], 10);
+	ids[8] = ob[5] + entry_rank(oe[5], 10);
+	// this cell's own vertices
+	const uint32_t vbase = sb.vbase + (en.w1 & 0xFFFFu);
+	uint32_t tpos = sb.tbase + (en.w1 >> 16) - c.t_skip;
 	const uint32_t r5 = (en.w2 >> 20) & 15u, r6 = (en.w2 >> 24) & 15u, r10 = (en.w3 >> 8) & 15u;
-	if (r5 != 15u) { ids[5] = vbase + r5; fast_owned_vertex<T, 5>(c, x, y, z, v, vbase + r5); }
-	if (r6 != 15u) { ids[6] = vbase + r6; fast_owned_vertex<T, 6>(c, x, y, z, v, vbase + r6); }
-	if (r10 != 15u) { ids[10] = vbase + r10; fast_owned_vertex<T, 10>(c, x, y, z, v, vbase + r10); }
-	uint32_t t1;
-	// the six neighbours that own the other nine edges: edge k of this cell is
-	// edge k' of the owner - (x-1,y,z-1): 0->6 | (x-1,y,z): 1->5, 2->6 | (x-1,y-1,z): 3->5 |
-	// (x,y,z-1): 4->6, 9->10 | (x,y-1,z): 7->5, 11->10 | (x,y-1,z-1): 8->10
-	if (MC33_SIDE(0) != MC33_SIDE(1)) ids[0] = owner_edge_id(c, x - 1, y, z - 1, 6, 6, t1);
-	if ((MC33_SIDE(1) != MC33_SIDE(2)) || (MC33_SIDE(3) != MC33_SIDE(2))) {
-		const uint32_t a = owner_edge_id(c, x - 1, y, z, 5, 6, t1);
-		ids[1] = a; ids[2] = t1;
-	}
-	if (MC33_SIDE(0) != MC33_SIDE(3)) ids[3] = owner_edge_id(c, x - 1, y - 1, z, 5, 5, t1);
-	if ((MC33_SIDE(4) != MC33_SIDE(5)) || (MC33_SIDE(1) != MC33_SIDE(5))) {
-		const uint32_t a = owner_edge_id(c, x, y, z - 1, 6, 10, t1);
-		ids[4] = a; ids[9] = t1;
-	}
-	if ((MC33_SIDE(4) != MC33_SIDE(7)) || (MC33_SIDE(3) != MC33_SIDE(7))) {
-		const uint32_t a = owner_edge_id(c, x, y - 1, z, 5, 10, t1);
-		ids[7] = a; ids[11] = t1;
-	}
-	if (MC33_SIDE(0) != MC33_SIDE(4)) ids[8] = owner_edge_id(c, x, y - 1, z - 1, 10, 10, t1);
-#undef MC33_SIDE
+	ids[5] = vbase + r5; ids[6] = vbase + r6; ids[10] = vbase + r10;
+	if (r5 != 15u) fast_owned_vertex<T, 5>(c, x, y, z, v, vbase + r5);
+	if (r6 != 15u) fast_owned_vertex<T, 6>(c, x, y, z, v, vbase + r6);
+	if (r10 != 15u) fast_owned_vertex<T, 10>(c, x, y, z, v, vbase + r10);
 	// winding (MC:683-691): n = 1 swaps the first two indices
 	const uint32_t n = ((c.tab.lut[(i & 0x80) ? (i ^ 0xFF) : i] >> 11) ^ (i >> 7) ^ 1u) & 1u;
 	uint32_t pos = (en.w0 >> 16) & 0xFFFu, word;

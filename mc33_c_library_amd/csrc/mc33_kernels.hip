@@ -43,6 +43,8 @@ struct Counters {
 	uint32_t entry_cursor;  // work records requested by the sweep (may exceed the capacity)
 	uint32_t slow_cursor;   // records left to k_slow_plan
 	uint32_t dirty_cursor;  // row segments whose offsets k_seg_fix has to rebuild
+	uint32_t mask_cursor;   // activity-mask records handed out
+	uint32_t pad_;
 	uint32_t emit_skipped;  // set by the emit kernels when they refused to run (capacity / overflow)
 	uint64_t totV, totT;    // totals over all classified slices (ghost included)
 	uint64_t ghostV, ghostT;
@@ -51,17 +53,38 @@ struct Counters {
 struct SweepArgs {
 	GridView<sample_t> G;
 	Params P;
-	const uint32_t *fast;    // per sign index: everything about a FAST cell (mc33_cell.h build_fast_table)
+	const uint4 *fast;       // per sign index: record words of a FAST cell (fast_record_table below)
 	uint32_t ze;             // classify cell slices [P.zs, ze)
 	uint32_t nXG, nYT, rz;   // tiles: 4 segments wide, 63 cell rows high, rz slices deep
 	uint32_t *seg_cnt;
-	SegEnt *seg_ent;
+	SegDir *seg_dir;
+	uint64_t *seg_mask;
 	Entry *entries;
 	uint32_t *entry_seg;
 	uint32_t *slow_list, *dirty_list;
-	uint32_t entry_cap;
+	uint32_t *chunk_fill;    // records used in every ENTRY_CHUNK-sized piece of the record array
+	uint32_t entry_cap;      // multiple of ENTRY_CHUNK
+	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only, results are wrong): 1 skip the cell
+	                         // loop, 2 skip the whole cell stage
 	Counters *ctr;
 };
+
+// Work records are handed out to the waves in chunks: a wave sub-allocates from its open chunk without
+// touching global memory and takes a new chunk (one returning atomic) only when the cells of a tile
+// slice do not fit any more.  The emit kernels walk the chunks and their fill counts.
+constexpr uint32_t ENTRY_CHUNK = 256;
+constexpr uint32_t MASK_CHUNK = 64;  // activity-mask records are handed out the same way (<= 63 per tile slice)
+
+// fast[i] of mc33_cell.h unpacked into the record words the sweep writes for a FAST cell:
+// x = w0 without the cell's x, y = w2, z = w3, w = new vertices | triangles << 8   (x == FAST_NONE: not fast)
+static void fast_record_table(const uint32_t *fast, uint4 *out) {
+	for (uint32_t i = 0; i < 256; i++) {
+		const uint32_t f = fast[i];
+		if (f == FAST_NONE) { out[i] = uint4{FAST_NONE, 0, 0, 0}; continue; }
+		const Entry e = make_fast_entry(0, i, f, 0, 0);
+		out[i] = uint4{e.w0, e.w2, e.w3, ((f >> 16) & 15u) | ((f >> 12) & 15u) << 8};
+	}
+}
 
 __device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return (uint64_t)hi << 32 | lo; }
 __device__ __forceinline__ uint64_t shfl_down1(uint64_t x) {
@@ -80,8 +103,13 @@ __device__ __forceinline__ uint64_t shfl_down1(uint64_t x) {
 // Cell part: only cells cut by the surface are touched.  FAST cells (see mc33_cell.h) are finished here
 // from their sign index alone; the others get a placeholder record for k_slow_plan.
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t row_above(uint32_t v) {  // lane r <- lane r+1 (lane 63 <- 0): DPP wave_shl:1
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint64_t row_above(uint64_t v) { return u64(row_above((uint32_t)v), row_above((uint32_t)(v >> 32))); }
+
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
-	__shared__ uint32_t s_fast[256];
+	__shared__ uint4 s_fast[256];  // per sign index: record words of a FAST cell (see fast_record_table)
 	s_fast[threadIdx.x] = a.fast[threadIdx.x];
 	__syncthreads();  // the only block-level barrier (before any wave can leave)
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -97,12 +125,12 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	const uint32_t z_lo = P.zs + zc * a.rz, z_hi = min(z_lo + a.rz, a.ze);
 	const float iso = P.iso;
 
-	// per-lane x offsets of its four samples (clamped into the row: bits of samples beyond the grid
-	// belong to cells that the valid masks remove)
+	// per-lane byte offsets of its four samples inside a row (clamped into the row: bits of samples
+	// beyond the grid belong to cells that the valid masks remove)
+	const uint32_t rowbytes = a.G.pitch * (uint32_t)sizeof(sample_t);
 	uint32_t xo[4];
 #pragma unroll
-	for (int k = 0; k < 4; k++) xo[k] = min(xbase + 64u * k + lane, P.nx);
-	const uint32_t xh = min(xbase + SEG_CELLS, P.nx);  // halo sample (first sample of the next segment)
+	for (int k = 0; k < 4; k++) xo[k] = min(xbase + 64u * k + lane, P.nx) * (uint32_t)sizeof(sample_t);
 	uint64_t valid[4];
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
@@ -112,59 +140,99 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	}
 	const uint32_t y = y0 + lane;
 	const bool rowvalid = lane < 63u && y < P.ny;
-	const uint32_t rowclamp = min(lane, nrows - 1);
+	// halo column: lane r needs the first sample of the next segment in row r; it is fetched by the batch
+	// that holds row r (4 lanes per batch; the other lanes aim outside the descriptor: no memory access)
+	const uint32_t xh = min(lane, nrows - 1) * rowbytes + min(xbase + SEG_CELLS, P.nx) * (uint32_t)sizeof(sample_t);
 
 	// sign bits of the tile: word k of sample row r lives in lane r.  *_h: the halo sample's bit;
-	// *_z: "some sample of this row (this segment + halo) equals the isovalue"
+	// *_z (wave-uniform): "some sample of this plane of the tile (halo included) equals the isovalue"
 	uint64_t cur[4], prev[4] = {0, 0, 0, 0};
-	uint32_t cur_h = 0, prev_h = 0, cur_z = 0, prev_z = 0;
+	uint32_t c_lo[4] = {0, 0, 0, 0}, c_hi[4] = {0, 0, 0, 0};
+	uint32_t cur_h = 0, prev_h = 0;
+	bool cur_z = false, prev_z = false;
+	float zmin = 1.0f;  // min |iso - F| over the lane's samples of the plane being assembled
+	uint32_t ch_pos = 0, ch_end = 0;  // free part [ch_pos, ch_end) of the wave's open chunk of work records
+	uint32_t mk_pos = 0, mk_end = 0;  // the same for activity-mask records
 
-	for (uint32_t p = z_lo; p <= z_hi; ++p) {
-		const sample_t *plane = a.G.p + (uint64_t)(p - a.G.z0) * a.G.slice + (uint64_t)y0 * a.G.pitch;
-		uint32_t c_lo[4] = {0, 0, 0, 0}, c_hi[4] = {0, 0, 0, 0};
-		cur_z = 0;
-		for (uint32_t r = 0; r < nrows; r += 4) {
-			float d[4][4];
+	// The tile is consumed as a linear stream of batches of 4 sample rows (16 coalesced 256-byte loads per
+	// wave), plane after plane.  Two register buffers: the loads of batch t+1 are in flight while batch t
+	// is turned into bit rows, so HBM requests stay outstanding during the cell stage as well.
+	// Loads go through a buffer descriptor per plane (scalar base + 32-bit offsets, hardware range check).
+	const uint32_t NB = (nrows + 3u) / 4u;
+	const uint32_t T = (z_hi - z_lo + 1u) * NB;
+	const uint32_t tile_bytes = nrows * rowbytes;
+#ifdef MC33_GRD_U16
+#define MC33_LOAD(rs, vo, so) ((float)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0))
+#else
+#define MC33_LOAD(rs, vo, so) (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0)))
+#endif
+	// every batch is exactly 17 loads, whatever the position in the tile (the wait counts the compiler
+	// derives are then exact and the prefetched batch really stays in flight)
+	auto issue = [&](float (&d)[16], float &hv, uint32_t p, uint32_t bi) {
+		const sample_t *base = a.G.p + (uint64_t)(p - a.G.z0) * a.G.slice + (uint64_t)y0 * a.G.pitch;
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, tile_bytes, 0x00020000);
+		const uint32_t r = bi * 4u;
 #pragma unroll
-			for (int rr = 0; rr < 4; rr++) {
-				const sample_t *row = plane + (uint64_t)min(r + rr, nrows - 1) * a.G.pitch;
+		for (int rr = 0; rr < 4; rr++) {
+			const uint32_t so = min(r + rr, nrows - 1) * rowbytes;
 #pragma unroll
-				for (int k = 0; k < 4; k++) d[rr][k] = iso - (float)row[xo[k]];  // MC:1852-1855
-			}
-#pragma unroll
-			for (int rr = 0; rr < 4; rr++) {
-				const bool mine = lane == r + rr;  // the bit row of sample row r+rr is parked in lane r+rr
-				uint64_t zany = 0;
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const uint64_t m = __ballot(__float_as_uint(d[rr][k]) >> 31);  // MC:1856-1859
-					c_lo[k] = mine ? (uint32_t)m : c_lo[k];
-					c_hi[k] = mine ? (uint32_t)(m >> 32) : c_hi[k];
-					zany |= __ballot(d[rr][k] == 0.0f);
-				}
-				cur_z = (mine && zany) ? 1u : cur_z;
-			}
+			for (int k = 0; k < 4; k++) d[rr * 4 + k] = MC33_LOAD(rs, xo[k], so);
 		}
-#pragma unroll
-		for (int k = 0; k < 4; k++) cur[k] = u64(c_lo[k], c_hi[k]);
-		{  // halo column: lane r reads sample xh of row r
-			const float dh = iso - (float)plane[(uint64_t)rowclamp * a.G.pitch + xh];
-			cur_h = __float_as_uint(dh) >> 31;
-			cur_z |= (dh == 0.0f) ? 1u : 0u;
-		}
+		hv = MC33_LOAD(rs, (lane >> 2) == bi ? xh : 0xFFFFFFF0u, 0u);
+	};
 
-		if (p > z_lo) {
+	float halo = 0.f;  // lane r: halo sample of row r of the plane being assembled
+	auto process = [&](const float (&dd)[16], const float &hv, uint32_t p, uint32_t bi) {
+		const uint32_t r = bi * 4u;
+		halo = (lane >> 2) == bi ? hv : halo;
+#pragma unroll
+		for (int rr = 0; rr < 4; rr++) {
+			uint32_t m[8];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const float d = iso - dd[rr * 4 + k];                    // MC:1852-1855
+				const uint64_t bb = __ballot(__float_as_int(d) < 0);      // MC:1856-1859 (sign bit)
+				m[2 * k] = (uint32_t)bb; m[2 * k + 1] = (uint32_t)(bb >> 32);
+				zmin = fminf(zmin, fabsf(d));
+			}
+			// park the bit row of sample row r+rr in lane r+rr: v_writelane takes its lane select from M0
+			// when the data operand is an SGPR too (one SGPR per VOP3 on gfx9-class encodings)
+			asm volatile(
+			    "s_mov_b32 m0, %16\n\t"
+			    "v_writelane_b32 %0, %8, m0\n\tv_writelane_b32 %1, %9, m0\n\t"
+			    "v_writelane_b32 %2, %10, m0\n\tv_writelane_b32 %3, %11, m0\n\t"
+			    "v_writelane_b32 %4, %12, m0\n\tv_writelane_b32 %5, %13, m0\n\t"
+			    "v_writelane_b32 %6, %14, m0\n\tv_writelane_b32 %7, %15, m0"
+			    : "+v"(c_lo[0]), "+v"(c_hi[0]), "+v"(c_lo[1]), "+v"(c_hi[1]), "+v"(c_lo[2]), "+v"(c_hi[2]), "+v"(c_lo[3]), "+v"(c_hi[3])
+			    : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), "s"(r + rr)
+			    : "m0");
+		}
+		if (bi != NB - 1) return;
+		// ---- the plane is complete ----
+#pragma unroll
+		for (int k = 0; k < 4; k++) { cur[k] = u64(c_lo[k], c_hi[k]); c_lo[k] = c_hi[k] = 0; }
+		{
+			const float dh = iso - halo;
+			cur_h = (uint32_t)(__float_as_int(dh) < 0);
+			zmin = fminf(zmin, fabsf(dh));
+			cur_z = __ballot(zmin == 0.0f) != 0ull;  // some sample of this plane of the tile equals the isovalue
+			zmin = 1.0f;
+		}
+		if (p > z_lo && !(a.debug & 2u)) {
 			const uint32_t z = p - 1;
-			const uint32_t prev_hn = __shfl_down(prev_h, 1), cur_hn = __shfl_down(cur_h, 1);
+			// bit rows of the sample row above (y+1) come from the neighbour lane
+			uint64_t prev_n[4], cur_n[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) { prev_n[k] = row_above(prev[k]); cur_n[k] = row_above(cur[k]); }
+			const uint32_t prev_hn = row_above(prev_h), cur_hn = row_above(cur_h);
 			// cells cut by the surface: NOT (all 8 sign bits one) and NOT (all zero)  (MC:1860)
 			uint64_t act[4];
 			{
 				uint64_t A[4], O[4];
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
-					const uint64_t q0n = shfl_down1(prev[k]), q1n = shfl_down1(cur[k]);
-					A[k] = prev[k] & q0n & cur[k] & q1n;
-					O[k] = prev[k] | q0n | cur[k] | q1n;
+					A[k] = prev[k] & prev_n[k] & cur[k] & cur_n[k];
+					O[k] = prev[k] | prev_n[k] | cur[k] | cur_n[k];
 				}
 				const uint64_t hA = prev_h & prev_hn & cur_h & cur_hn, hO = prev_h | prev_hn | cur_h | cur_hn;
 #pragma unroll
@@ -175,35 +243,60 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 					act[k] = rowvalid ? (~((A[k] & As) | ~(O[k] | Os)) & valid[k]) : 0ull;
 				}
 			}
-			const uint32_t cnt = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
-			uint32_t incl = cnt;
+			const uint32_t c0 = __popcll(act[0]), c1 = __popcll(act[1]), c2 = __popcll(act[2]), c3 = __popcll(act[3]);
+			const uint32_t cnt = c0 + c1 + c2 + c3;
+			const uint64_t sidx = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y;  // storage order [z][segment][y]
+			const uint64_t havem = __ballot(cnt != 0);
+			if (havem && !(a.debug & 1u)) {  // wave-uniform: some row of the tile slice has active cells
+				// exclusive prefix of the per-row counts over the lanes
+				uint32_t incl = cnt;
 #pragma unroll
-			for (int dlt = 1; dlt < 64; dlt <<= 1) {
-				const uint32_t t = __shfl_up(incl, dlt);
-				if ((int)lane >= dlt) incl += t;
-			}
-			const uint32_t total = __shfl(incl, 63);
-			uint32_t base = 0;
-			if (total) {
-				if (lane == 0) base = atomicAdd(&a.ctr->entry_cursor, total);
-				base = __shfl(base, 0);
-			}
-			const uint64_t sidx = ((uint64_t)(z - P.zs) * P.ny + y) * P.nseg + seg;
-			uint32_t idx = base + incl - cnt, nv_run = 0, nt_run = 0;
-			const uint32_t first = idx;
-			bool dirty = false;
-			if (total) {  // wave-uniform
+				for (int dlt = 1; dlt < 64; dlt <<= 1) {
+					const uint32_t t = __shfl_up(incl, dlt);
+					if ((int)lane >= dlt) incl += t;
+				}
+				const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+				if (ch_pos + total > ch_end) {
+					// close the open chunk, take ceil(total / chunk) new ones (the last of them stays open)
+					if (ch_end && lane == 0 && ch_end <= a.entry_cap) a.chunk_fill[ch_end / ENTRY_CHUNK - 1] = ENTRY_CHUNK - (ch_end - ch_pos);
+					const uint32_t n = (total + ENTRY_CHUNK - 1) / ENTRY_CHUNK;
+					uint32_t got = 0;
+					if (lane == 0) got = atomicAdd(&a.ctr->entry_cursor, n * ENTRY_CHUNK);
+					got = __builtin_amdgcn_readfirstlane(got);
+					for (uint32_t q = lane; q + 1 < n; q += 64)
+						if (got + (q + 1) * ENTRY_CHUNK <= a.entry_cap) a.chunk_fill[got / ENTRY_CHUNK + q] = ENTRY_CHUNK;
+					ch_pos = got;
+					ch_end = got + n * ENTRY_CHUNK;
+				}
+				const uint32_t first = ch_pos + incl - cnt;
+				ch_pos += total;
+				// activity-mask records: one per row with active cells
+				const uint32_t nm = (uint32_t)__popcll(havem);
+				if (mk_pos + nm > mk_end) {
+					uint32_t got = 0;
+					if (lane == 0) got = atomicAdd(&a.ctr->mask_cursor, MASK_CHUNK);
+					mk_pos = __builtin_amdgcn_readfirstlane(got);
+					mk_end = mk_pos + MASK_CHUNK;
+				}
+				const uint32_t maskidx = mk_pos + (uint32_t)__popcll(havem & ((1ull << lane) - 1ull));
+				mk_pos += nm;
+				if (cnt && maskidx < a.entry_cap) {
+					uint64_t *mr = a.seg_mask + 4ull * maskidx;
+					mr[0] = act[0]; mr[1] = act[1]; mr[2] = act[2]; mr[3] = act[3];
+				}
+				uint32_t idx = first, nv_run = 0, nt_run = 0;
+				bool dirty = false;
 				// rows whose cells cannot take the fast path: on the y = 0 / z = 0 faces (extra owned edges),
-				// or with a sample equal to the isovalue among the four sample rows of the cell row
-				const bool rowslow = y == 0 || z == 0 || ((prev_z | cur_z | __shfl_down(prev_z, 1) | __shfl_down(cur_z, 1)) != 0);
+				// or in a tile plane pair that holds a sample equal to the isovalue
+				const bool rowslow = y == 0 || z == 0 || prev_z || cur_z;
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
 					// the four bit rows of this word, and the same shifted by one sample (x+1)
-					const uint64_t q0 = prev[k], q1 = cur[k], q0n = shfl_down1(prev[k]), q1n = shfl_down1(cur[k]);
+					const uint64_t q0 = prev[k], q1 = cur[k], q0n = prev_n[k], q1n = cur_n[k];
 					uint64_t n0, n1, n0n, n1n;  // bit 0 of the next word of each row
 					if (k < 3) {
 						n0 = prev[k < 3 ? k + 1 : 3] & 1ull; n1 = cur[k < 3 ? k + 1 : 3] & 1ull;
-						n0n = shfl_down1(prev[k < 3 ? k + 1 : 3]) & 1ull; n1n = shfl_down1(cur[k < 3 ? k + 1 : 3]) & 1ull;
+						n0n = prev_n[k < 3 ? k + 1 : 3] & 1ull; n1n = cur_n[k < 3 ? k + 1 : 3] & 1ull;
 					} else { n0 = prev_h; n1 = cur_h; n0n = prev_hn; n1n = cur_hn; }
 					const uint64_t q0s = (q0 >> 1) | (n0 << 63), q1s = (q1 >> 1) | (n1 << 63);
 					const uint64_t q0ns = (q0n >> 1) | (n0n << 63), q1ns = (q1n >> 1) | (n1n << 63);
@@ -219,12 +312,12 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 							const uint32_t i = (uint32_t)((q0 >> j) & 1) << 7 | (uint32_t)((q0n >> j) & 1) << 6 | (uint32_t)((q1n >> j) & 1) << 5 |
 							                   (uint32_t)((q1 >> j) & 1) << 4 | (uint32_t)((q0s >> j) & 1) << 3 | (uint32_t)((q0ns >> j) & 1) << 2 |
 							                   (uint32_t)((q1ns >> j) & 1) << 1 | (uint32_t)((q1s >> j) & 1);
-							const uint32_t f = s_fast[i];
+							const uint4 f = s_fast[i];
 							Entry e;
-							if (!rowslow && f != FAST_NONE && (xbase + xl) != 0) {
-								e = make_fast_entry(xl, i, f, nv_run, nt_run);
-								nv_run += (f >> 16) & 15u;
-								nt_run += (f >> 12) & 15u;
+							if (!rowslow && f.x != FAST_NONE && (xbase + xl) != 0) {
+								e.w0 = f.x | xl; e.w1 = nv_run | nt_run << 16; e.w2 = f.y; e.w3 = f.z;
+								nv_run += f.w & 0xFFu;
+								nt_run += f.w >> 8;
 							} else {
 								e = make_pending_entry(xl, i);
 								dirty = true;
@@ -238,18 +331,38 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 						}
 					}
 				}
-			}
-			if (rowvalid) {
-				a.seg_cnt[sidx] = dirty ? 0u : seg_pack(nv_run, nt_run);
-				a.seg_ent[sidx] = SegEnt{first, cnt | (dirty ? SEG_DIRTY : 0u)};
-				if (dirty && first < a.entry_cap) a.dirty_list[atomicAdd(&a.ctr->dirty_cursor, 1u)] = (uint32_t)sidx;
-			}
+				if (rowvalid) {
+					a.seg_cnt[sidx] = dirty ? 0u : seg_pack(nv_run, nt_run);
+					if (cnt) {
+						a.seg_dir[sidx] = SegDir{first, cnt | (dirty ? SEG_DIRTY : 0u), maskidx, pack_prefix(c0, c1, c2)};
+						if (dirty && first < a.entry_cap) a.dirty_list[atomicAdd(&a.ctr->dirty_cursor, 1u)] = (uint32_t)sidx;
+					}
+				}
+			} else if (rowvalid)
+				a.seg_cnt[sidx] = 0u;
 		}
 #pragma unroll
 		for (int k = 0; k < 4; k++) prev[k] = cur[k];
 		prev_h = cur_h;
 		prev_z = cur_z;
+	};
+
+	float dA[16], dB[16], hA = 0.f, hB = 0.f;
+	uint32_t ip = z_lo, ib = 0, pp = z_lo, pb = 0;  // (plane, batch) of the next issue / of the next process
+	// past the end of the tile the prefetch simply re-reads the last batch (it is never processed)
+#define MC33_ADV(p_, b_) do { if (++(b_) == NB) { (b_) = 0; ++(p_); } } while (0)
+#define MC33_ADV_ISSUE() do { if (ip != z_hi || ib + 1 != NB) MC33_ADV(ip, ib); } while (0)
+	issue(dA, hA, ip, ib); MC33_ADV_ISSUE();
+	for (uint32_t t = 0; t < T; t += 2) {
+		issue(dB, hB, ip, ib); MC33_ADV_ISSUE();
+		process(dA, hA, pp, pb); MC33_ADV(pp, pb);
+		issue(dA, hA, ip, ib); MC33_ADV_ISSUE();
+		if (t + 1 < T) { process(dB, hB, pp, pb); MC33_ADV(pp, pb); }
 	}
+	if (ch_end && lane == 0 && ch_end <= a.entry_cap) a.chunk_fill[ch_end / ENTRY_CHUNK - 1] = ENTRY_CHUNK - (ch_end - ch_pos);
+#undef MC33_ADV_ISSUE
+#undef MC33_ADV
+#undef MC33_LOAD
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -265,7 +378,7 @@ struct SlowArgs {
 	const uint32_t *entry_seg;
 	const uint32_t *slow_list;
 	uint32_t *seg_cnt;
-	const SegEnt *seg_ent;
+	const SegDir *seg_dir;
 	const uint32_t *dirty_list;
 	uint32_t entry_cap;
 	Counters *ctr;
@@ -274,7 +387,7 @@ struct SlowArgs {
 __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 	__shared__ float s_v[8][256];
 	__shared__ float s_w[8][256];
-	if (a.ctr->entry_cursor > a.entry_cap) return;  // the sweep is going to be repeated with more room
+	if (a.ctr->entry_cursor > a.entry_cap || a.ctr->mask_cursor > a.entry_cap) return;  // the sweep will be repeated with more room
 	const uint32_t n = a.ctr->slow_cursor;
 	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
 	const Params &P = a.P;
@@ -282,8 +395,8 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 		const uint32_t ei = a.slow_list[t];
 		const uint32_t s = a.entry_seg[ei];
 		const uint32_t xl = a.entries[ei].w0 & 0xFFu;
-		const uint32_t sx = s % P.nseg, row = s / P.nseg;
-		const uint32_t y = row % P.ny, z = row / P.ny + P.zs, x = sx * SEG_CELLS + xl;
+		const SegCoord sc = segment_coord(P, s);
+		const uint32_t y = sc.y, z = sc.z, x = sc.xbase + xl;
 		const uint32_t i = load_cell(a.G, P.iso, x, y, z, v);
 		CellPlan pl;
 		plan_cell(pl, a.tab, P, a.G, x, y, z, i, v);
@@ -296,11 +409,11 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 
 // one thread per row segment that holds slow cells: running offsets of its records, segment totals
 __global__ __launch_bounds__(256) void k_seg_fix(const SlowArgs a) {
-	if (a.ctr->entry_cursor > a.entry_cap) return;
+	if (a.ctr->entry_cursor > a.entry_cap || a.ctr->mask_cursor > a.entry_cap) return;
 	const uint32_t n = a.ctr->dirty_cursor;
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
 		const uint32_t s = a.dirty_list[t];
-		const SegEnt se = a.seg_ent[s];
+		const SegDir se = a.seg_dir[s];
 		const uint32_t cnt = se.nent & ~SEG_DIRTY;
 		uint32_t nv = 0, nt = 0;
 		for (uint32_t k = 0; k < cnt; k++) {
@@ -324,13 +437,16 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t x) {
 	return x;
 }
 
-__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, uint64_t n, uint64_t *bsV, uint64_t *bsT) {
+// The records are stored [z][segment][y]; the scan runs over them in sweep order [z][y][segment]: a chunk of
+// SCAN_CHUNK consecutive sweep positions is the same set of records whatever the order inside it only
+// when it covers whole (y, all segments) groups - so the mapping is applied per element.
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, uint64_t n, Params P, uint64_t *bsV, uint64_t *bsT) {
 	__shared__ uint64_t sv[4], st[4];
 	const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
 	uint64_t v = 0, t = 0;
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
 		const uint64_t q = base + (uint64_t)k * 256 + threadIdx.x;
-		if (q < n) { const uint32_t c = seg_cnt[q]; v += c & 0xFFFFu; t += c >> 16; }
+		if (q < n) { const uint32_t c = seg_cnt[segment_sweep_to_store(P, q)]; v += c & 0xFFFFu; t += c >> 16; }
 	}
 	v = wave_sum(v); t = wave_sum(t);
 	if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; st[threadIdx.x >> 6] = t; }
@@ -362,14 +478,16 @@ __global__ __launch_bounds__(1024) void k_scan_spine(uint64_t *bsV, uint64_t *bs
 	if (threadIdx.x == 1023) { ctr->totV = pv[1023]; ctr->totT = pt[1023]; }
 }
 
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uint64_t n, const uint64_t *bsV, const uint64_t *bsT,
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uint64_t n, Params P, const uint64_t *bsV, const uint64_t *bsT,
                                                     SegBase *seg_base, uint64_t ghost_segs, Counters *ctr) {
 	__shared__ uint32_t sv[4], st[4];
 	const uint64_t q0 = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
 	uint32_t cv[SCAN_PER_THREAD], ct[SCAN_PER_THREAD], v = 0, t = 0;
+	uint64_t st_idx[SCAN_PER_THREAD];
 #pragma unroll
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
-		const uint32_t c = (q0 + k < n) ? seg_cnt[q0 + k] : 0u;
+		st_idx[k] = (q0 + k < n) ? segment_sweep_to_store(P, q0 + k) : 0;
+		const uint32_t c = (q0 + k < n) ? seg_cnt[st_idx[k]] : 0u;
 		cv[k] = c & 0xFFFFu; ct[k] = c >> 16;
 		v += cv[k]; t += ct[k];
 	}
@@ -387,7 +505,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uin
 #pragma unroll
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
 		if (q0 + k < n) {
-			seg_base[q0 + k] = SegBase{ev, et};
+			seg_base[st_idx[k]] = SegBase{ev, et};
 			if (q0 + k == ghost_segs) { ctr->ghostV = ev; ctr->ghostT = et; }  // first segment of the emitted range
 		}
 		ev += cv[k]; et += ct[k];
@@ -402,6 +520,7 @@ struct EmitArgs {
 	EmitCtx<sample_t> c;
 	Counters *ctr;
 	const uint32_t *slow_list;
+	const uint32_t *chunk_fill;
 	uint32_t entry_cap;
 	uint64_t capV, capT;
 	uint64_t ghost_segs;  // row segments of the ghost slice (0 without ghost)
@@ -411,7 +530,7 @@ struct EmitArgs {
 // capacity / overflow check shared by both emit kernels; fills the slab offsets of the context
 __device__ __forceinline__ bool emit_prepare(const EmitArgs &a, EmitCtx<sample_t> &c, const Counters &ctr) {
 	const uint64_t gV = a.ghost_segs ? ctr.ghostV : 0, gT = a.ghost_segs ? ctr.ghostT : 0;
-	if (ctr.entry_cursor > a.entry_cap || ctr.totV - gV > a.capV || ctr.totT - gT > a.capT || ctr.totV > 0xFFFFFFFFull ||
+	if (ctr.entry_cursor > a.entry_cap || ctr.mask_cursor > a.entry_cap || ctr.totV - gV > a.capV || ctr.totT - gT > a.capT || ctr.totV > 0xFFFFFFFFull ||
 	    ctr.totT > 0xFFFFFFFFull || (uint64_t)a.id_base + (ctr.totV - gV) > 0xFFFFFFFFull) {
 		if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->emit_skipped = 1;
 		return false;
@@ -428,11 +547,14 @@ __global__ __launch_bounds__(256) void k_emit_fast(const EmitArgs a) {
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
-	const uint32_t n = ctr.entry_cursor;
-	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+	const uint32_t nchunks = ctr.entry_cursor / ENTRY_CHUNK;
+	static_assert(ENTRY_CHUNK == 256, "one record per thread");
+	for (uint32_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+		if (threadIdx.x >= a.chunk_fill[ch]) continue;
+		const uint32_t e = ch * ENTRY_CHUNK + threadIdx.x;
 		const Entry en = c.entries[e];
 		if (en.w3 & ENTRY_SLOW) continue;
-		emit_fast_cell(c, en, c.entry_seg[e], ids);
+		emit_fast_cell(c, en, c.entry_seg[e], e, ids);
 	}
 }
 
@@ -479,15 +601,16 @@ struct mc33hip_ctx {
 	uint16_t *d_lut;
 	uint32_t *d_rules;
 	uint8_t *d_rule_index;
-	uint32_t *d_fast;
+	uint4 *d_fast;
 	uint32_t *seg_cnt;
-	SegEnt *seg_ent;
+	SegDir *seg_dir;
 	SegBase *seg_base;
+	uint64_t *seg_mask;
 	uint64_t seg_cap;
 	uint64_t *bsV, *bsT;
 	uint64_t bs_cap;
 	Entry *entries;
-	uint32_t *entry_seg, *slow_list, *dirty_list;
+	uint32_t *entry_seg, *slow_list, *dirty_list, *chunk_fill;
 	uint64_t entry_cap;
 	Counters *d_ctr, *h_ctr;
 	hipEvent_t ev[4];
@@ -541,9 +664,11 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	CREATE_TRY(hipMemcpy(c->d_rule_index, mc33_rule_index, sizeof mc33_rule_index, hipMemcpyHostToDevice));
 	{
 		uint32_t fast[256];
+		uint4 rec[256];
 		build_fast_table(mc33_lut, fast);
-		CREATE_TRY(hipMalloc(&c->d_fast, sizeof fast));
-		CREATE_TRY(hipMemcpy(c->d_fast, fast, sizeof fast, hipMemcpyHostToDevice));
+		fast_record_table(fast, rec);
+		CREATE_TRY(hipMalloc(&c->d_fast, sizeof rec));
+		CREATE_TRY(hipMemcpy(c->d_fast, rec, sizeof rec, hipMemcpyHostToDevice));
 	}
 	CREATE_TRY(hipMalloc(&c->d_ctr, sizeof(Counters)));
 	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
@@ -559,9 +684,10 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	else (void)hipDeviceSynchronize();
 	if (c->owns_grid) (void)hipFree(c->d_grid);
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_rules); (void)hipFree(c->d_rule_index); (void)hipFree(c->d_fast);
-	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_ent); (void)hipFree(c->seg_base);
+	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base); (void)hipFree(c->seg_mask);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
 	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
+	(void)hipFree(c->chunk_fill);
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
@@ -683,13 +809,31 @@ static uint32_t env_u32(const char *name, uint32_t dflt) {
 	return v > 0 ? (uint32_t)v : dflt;
 }
 
+static int alloc_entries(mc33hip_ctx *c, uint64_t cap) {
+	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
+	(void)hipFree(c->chunk_fill); (void)hipFree(c->seg_mask);
+	c->entries = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr; c->chunk_fill = nullptr;
+	c->seg_mask = nullptr;
+	c->entry_cap = 0;
+	if (cap > 0xFFFFFF00ull) cap = 0xFFFFFF00ull;
+	cap = (cap + ENTRY_CHUNK - 1) / ENTRY_CHUNK * ENTRY_CHUNK;
+	HIP_TRY(hipMalloc(&c->entries, cap * sizeof(Entry)));
+	HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
+	HIP_TRY(hipMalloc(&c->slow_list, cap * 4));
+	HIP_TRY(hipMalloc(&c->dirty_list, cap * 4));
+	HIP_TRY(hipMalloc(&c->chunk_fill, cap / ENTRY_CHUNK * 4));
+	HIP_TRY(hipMalloc(&c->seg_mask, cap * 32));  // one 256-bit activity mask per row segment with records
+	c->entry_cap = cap;
+	return 0;
+}
+
 static int ensure_workspaces(mc33hip_ctx *c) {
 	if (c->seg_cap < c->nsegs) {
-		(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_ent); (void)hipFree(c->seg_base);
-		c->seg_cnt = nullptr; c->seg_ent = nullptr; c->seg_base = nullptr;
+		(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base);
+		c->seg_cnt = nullptr; c->seg_dir = nullptr; c->seg_base = nullptr;
 		c->seg_cap = 0;
 		HIP_TRY(hipMalloc(&c->seg_cnt, c->nsegs * 4));
-		HIP_TRY(hipMalloc(&c->seg_ent, c->nsegs * sizeof(SegEnt)));
+		HIP_TRY(hipMalloc(&c->seg_dir, c->nsegs * sizeof(SegDir)));
 		HIP_TRY(hipMalloc(&c->seg_base, c->nsegs * sizeof(SegBase)));
 		c->seg_cap = c->nsegs;
 	}
@@ -705,29 +849,15 @@ static int ensure_workspaces(mc33hip_ctx *c) {
 	if (!c->entries) {
 		// first guess: one cell in 32 is cut (BASELINE fields: 0.4-6 % of the cells); grown on demand
 		const uint64_t cells = (uint64_t)c->P.nx * c->P.ny * (c->range.z_end - c->P.zs);
-		uint64_t cap = cells / 32 + 4096;
-		if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
-		HIP_TRY(hipMalloc(&c->entries, cap * sizeof(Entry)));
-		HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
-		HIP_TRY(hipMalloc(&c->slow_list, cap * 4));
-		HIP_TRY(hipMalloc(&c->dirty_list, cap * 4));
-		c->entry_cap = cap;
+		return alloc_entries(c, cells / 32 + 65536);
 	}
 	return 0;
 }
 
 static int grow_entries(mc33hip_ctx *c, uint64_t need) {
-	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
-	c->entries = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr; c->entry_cap = 0;
-	uint64_t cap = need + need / 8 + 4096;
-	if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
-	if (cap < need) { set_err("more than 2^32 work records"); return MC33HIP_EOVERFLOW; }
-	HIP_TRY(hipMalloc(&c->entries, cap * sizeof(Entry)));
-	HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
-	HIP_TRY(hipMalloc(&c->slow_list, cap * 4));
-	HIP_TRY(hipMalloc(&c->dirty_list, cap * 4));
-	c->entry_cap = cap;
-	return 0;
+	const uint64_t cap = need + need / 8 + 65536;
+	if (cap > 0xFFFFFF00ull) { set_err("more than 2^32 work records"); return MC33HIP_EOVERFLOW; }
+	return alloc_entries(c, cap);
 }
 
 // enqueue sweep + slow-cell planning + scans on the context's stream (no synchronisation)
@@ -735,6 +865,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	const Params &P = c->P;
 	hipStream_t st = c->stream;
 	HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
+	HIP_TRY(hipMemsetAsync(c->chunk_fill, 0, c->entry_cap / ENTRY_CHUNK * 4, st));
 	SweepArgs a;
 	a.G.p = c->d_grid; a.G.pitch = (uint32_t)c->pitch; a.G.z0 = c->desc.plane0; a.G.slice = c->slice;
 	a.P = P;
@@ -744,9 +875,11 @@ static int enqueue_count(mc33hip_ctx *c) {
 	a.nYT = (P.ny + 62) / 63;
 	a.rz = env_u32("MC33_HIP_RZ", 16);
 	const uint32_t nZC = (a.ze - P.zs + a.rz - 1) / a.rz;
-	a.seg_cnt = c->seg_cnt; a.seg_ent = c->seg_ent;
+	a.seg_cnt = c->seg_cnt; a.seg_dir = c->seg_dir; a.seg_mask = c->seg_mask;
 	a.entries = c->entries; a.entry_seg = c->entry_seg; a.slow_list = c->slow_list; a.dirty_list = c->dirty_list;
+	a.chunk_fill = c->chunk_fill;
 	a.entry_cap = (uint32_t)c->entry_cap;
+	a.debug = env_u32("MC33_HIP_DEBUG", 0);
 	a.ctr = c->d_ctr;
 	const uint64_t blocks = (uint64_t)a.nXG * a.nYT * nZC;
 	if (blocks > 0x7FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
@@ -759,16 +892,16 @@ static int enqueue_count(mc33hip_ctx *c) {
 	sa.tab.lut = c->d_lut; sa.tab.rule_words = c->d_rules; sa.tab.rule_index = c->d_rule_index;
 	sa.z_emit = c->range.z_begin;
 	sa.entries = c->entries; sa.entry_seg = c->entry_seg; sa.slow_list = c->slow_list;
-	sa.seg_cnt = c->seg_cnt; sa.seg_ent = c->seg_ent; sa.dirty_list = c->dirty_list;
+	sa.seg_cnt = c->seg_cnt; sa.seg_dir = c->seg_dir; sa.dirty_list = c->dirty_list;
 	sa.entry_cap = (uint32_t)c->entry_cap; sa.ctr = c->d_ctr;
 	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);
 	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks), dim3(256), 0, st, sa);
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
 	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
-	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, c->bsV, c->bsT);
+	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT);
 	hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, c->bsV, c->bsT, nb, c->d_ctr);
-	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, c->bsV, c->bsT, c->seg_base, c->ghost_segs,
-	                   c->d_ctr);
+	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, c->seg_base,
+	                   c->ghost_segs, c->d_ctr);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c->ev[2], st));
 	return 0;
@@ -779,17 +912,18 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.c.tab.lut = c->d_lut; a.c.tab.rule_words = c->d_rules; a.c.tab.rule_index = c->d_rule_index;
 	a.c.P = c->P;
 	a.c.G.p = c->d_grid; a.c.G.pitch = (uint32_t)c->pitch; a.c.G.z0 = c->desc.plane0; a.c.G.slice = c->slice;
-	a.c.seg_base = c->seg_base; a.c.seg_ent = c->seg_ent;
+	a.c.seg_base = c->seg_base; a.c.seg_dir = c->seg_dir; a.c.seg_mask = c->seg_mask;
 	a.c.entries = c->entries; a.c.entry_seg = c->entry_seg;
 	a.c.V = (float *)dV; a.c.N = (float *)dN; a.c.Tri = (uint32_t *)dT;
 	a.c.z_emit = c->range.z_begin; a.c.v_skip = a.c.t_skip = a.c.id_delta = 0;
 	a.ctr = c->d_ctr;
 	a.slow_list = c->slow_list;
+	a.chunk_fill = c->chunk_fill;
 	a.entry_cap = (uint32_t)c->entry_cap;
 	a.capV = capV; a.capT = capT;
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
-	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 8u);
+	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 32u);
 	hipLaunchKernelGGL(k_emit_fast, dim3(blocks), dim3(256), 0, c->stream, a);
 	hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, c->stream, a);
 	HIP_TRY(hipGetLastError());
@@ -843,8 +977,8 @@ extern "C" int mc33hip_count(mc33hip_ctx *c, float iso, const mc33hip_range *ran
 		if ((rc = enqueue_count(c))) return rc;
 		launches++;
 		if ((rc = fetch_counters(c))) return rc;
-		if (c->h_ctr->entry_cursor <= c->entry_cap) break;
-		if ((rc = grow_entries(c, c->h_ctr->entry_cursor))) return rc;
+		if (c->h_ctr->entry_cursor <= c->entry_cap && c->h_ctr->mask_cursor <= c->entry_cap) break;
+		if ((rc = grow_entries(c, c->h_ctr->entry_cursor > c->h_ctr->mask_cursor ? c->h_ctr->entry_cursor : c->h_ctr->mask_cursor))) return rc;
 	}
 	read_timing(c, false, launches);
 	if ((rc = finish_counts(c, out))) return rc;
@@ -883,8 +1017,8 @@ extern "C" int mc33hip_extract(mc33hip_ctx *c, float iso, const mc33hip_range *r
 		launches++;
 		if ((rc = enqueue_emit(c, dV, dN, dT, capV, capT))) return rc;  // checks capacities on the device
 		if ((rc = fetch_counters(c))) return rc;
-		if (c->h_ctr->entry_cursor <= c->entry_cap) break;
-		if ((rc = grow_entries(c, c->h_ctr->entry_cursor))) return rc;
+		if (c->h_ctr->entry_cursor <= c->entry_cap && c->h_ctr->mask_cursor <= c->entry_cap) break;
+		if ((rc = grow_entries(c, c->h_ctr->entry_cursor > c->h_ctr->mask_cursor ? c->h_ctr->entry_cursor : c->h_ctr->mask_cursor))) return rc;
 	}
 	read_timing(c, true, launches);
 	if ((rc = finish_counts(c, out))) return rc;
