@@ -116,7 +116,7 @@ def main():
         caps = torch.tensor([capV, capT], dtype=torch.int64, device=dev)
         dist.all_reduce(caps, op=dist.ReduceOp.MAX)
         capV, capT = (int(x) for x in caps.tolist())
-        counts_all = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+        counts_all = torch.zeros(world * 2, dtype=torch.int64, device=dev)
         gV = torch.empty((world, capV, 3), dtype=torch.float32, device=dev)
         gN = torch.empty_like(gV)
         gT = torch.empty((world, capT, 3), dtype=torch.int32, device=dev)
@@ -140,12 +140,12 @@ def main():
         t = grid.timing()
         mine = torch.tensor([c.nV, c.nT], dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(counts_all, mine)
-        id_base = int(counts_all[:rank, 0].sum().item()) if rank else 0
+        id_base = int(counts_all.view(world, 2)[:rank, 0].sum().item()) if rank else 0
         grid.emit_into(V, N, T, id_base)
         ev[0].record()
-        dist.all_gather_into_tensor(gV, V)
-        dist.all_gather_into_tensor(gN, N)
-        dist.all_gather_into_tensor(gT, T)
+        dist.all_gather_into_tensor(gV.view(-1), V.view(-1))
+        dist.all_gather_into_tensor(gN.view(-1), N.view(-1))
+        dist.all_gather_into_tensor(gT.view(-1), T.view(-1))
         ev[1].record()
         if record:
             ev[1].synchronize()

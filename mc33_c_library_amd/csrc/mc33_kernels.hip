@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				}
 				const uint32_t maskidx = mk_pos + (uint32_t)__popcll(havem & ((1ull << lane) - 1ull));
 				mk_pos += nm;
-				if (cnt && maskidx < a.entry_cap) {
+				if (cnt && maskidx < a.entry_cap && !(a.debug & 8u)) {
 					uint64_t *mr = a.seg_mask + 4ull * maskidx;
 					mr[0] = act[0]; mr[1] = act[1]; mr[2] = act[2]; mr[3] = act[3];
 				}
@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				const bool rowslow = y == 0 || z == 0 || prev_z || cur_z;
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
+					if (a.debug & 16u) break;
 					// the four bit rows of this word, and the same shifted by one sample (x+1)
 					const uint64_t q0 = prev[k], q1 = cur[k], q0n = prev_n[k], q1n = cur_n[k];
 					uint64_t n0, n1, n0n, n1n;  // bit 0 of the next word of each row
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 								dirty = true;
 								if (idx < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = idx;
 							}
-							if (idx < a.entry_cap) {
+							if (idx < a.entry_cap && !(a.debug & 4u)) {
 								a.entries[idx] = e;
 								a.entry_seg[idx] = (uint32_t)sidx;
 							}
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 						}
 					}
 				}
-				if (rowvalid) {
+				if (rowvalid && !(a.debug & 8u)) {
 					a.seg_cnt[sidx] = dirty ? 0u : seg_pack(nv_run, nt_run);
 					if (cnt) {
 						a.seg_dir[sidx] = SegDir{first, cnt | (dirty ? SEG_DIRTY : 0u), maskidx, pack_prefix(c0, c1, c2)};

@@ -1,0 +1,68 @@
+"""CPU tests: the oracle (plain-C restatement, oracle/mc33_oracle.c) is pinned against
+  (1) the committed golden vectors produced by the unmodified reference (tests/golden/), and
+  (2) the reference itself when oracle/_ref has been built in this container."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+from golden_cases import GENERATORS, GOLDEN, check_against_golden
+from parity import bits_equal
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_oracle_matches_golden(oracles, name):
+    data, r0, d = GENERATORS[name]()
+    o = oracles[GOLDEN[name]["dtype"]]
+    check_against_golden(name, o.isosurface(data, GOLDEN[name]["iso"], r0, d), o.fnv, data)
+
+
+def _same(a, b):
+    return (a.nV, a.nT) == (b.nV, b.nT) and np.array_equal(a.T, b.T) and bits_equal(a.V, b.V) and bits_equal(a.N, b.N)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 7])
+def test_oracle_bit_exact_vs_reference_noise(oracles, reflibs, seed):
+    for data, iso in ((fx.noise_f32(24, seed), 0.0), (fx.noise_quant(24, seed), 0.0), (fx.noise_quant(24, seed), 1.0),
+                      (fx.noise_quant(0, seed, L=3, shape=(5, 6, 40)), 0.0)):
+        assert _same(oracles["f32"].isosurface(data, iso), reflibs["f32"].isosurface(data, iso))
+    for data, iso in ((fx.noise_u16(24, seed), 32768.0), (fx.noise_u16(24, seed, 7), 3.0), (fx.noise_u16(24, seed, 7), 2.5)):
+        assert _same(oracles["u16"].isosurface(data, iso), reflibs["u16"].isosurface(data, iso))
+
+
+def test_oracle_bit_exact_vs_reference_single_cells(oracles, reflibs):
+    """2x2x2 grids over all 256 sign patterns x random magnitudes (+ exact zeros): pins the case selection
+    per configuration with no neighbour effects."""
+    rng = np.random.default_rng(1234)
+    for i in range(256):
+        for rep in range(3):
+            mag = rng.uniform(0.05, 1.0, 8).astype(np.float32)
+            sign = np.array([1.0 if (i >> k) & 1 else -1.0 for k in range(8)], np.float32)
+            v = (mag * sign)
+            if rep == 2:
+                v[rng.integers(0, 8)] = 0.0
+            data = v.reshape(2, 2, 2)
+            assert _same(oracles["f32"].isosurface(data, 0.0), reflibs["f32"].isosurface(data, 0.0)), (i, rep)
+
+
+def test_oracle_classify_covers_all_mc33_groups(oracles):
+    """The noise fixture exercises every group of the lookup table (simple, 3, 4, 6, 7, 10, 12, 13):
+    parity on it therefore checks face and interior tests, unlike the BASELINE cos field."""
+    idx, pat = oracles["f32"].classify(fx.noise_f32(32, 1), 0.0)
+    active = (idx != 0) & (idx != 255)
+    assert active.sum() == 29547
+    import ctypes  # table words through the oracle's own copy of the data
+    from mc33_oracle import oracle_path  # noqa: F401
+    cos_idx, cos_pat = oracles["f32"].classify(fx.cos_field(64)[0], 0.0)
+    assert ((cos_idx != 0) & (cos_idx != 255)).sum() == 14708
+    assert len(np.unique(pat[active])) > 300  # many distinct sub-case patterns are reached
+
+
+def test_oracle_readme_known_answers(oracles):
+    data, r0, d = fx.sphere_field()
+    s = oracles["f32"].isosurface(data, 1.0, r0, d)
+    assert (s.nV, s.nT) == (21030, 42056)
+    # closed 2-manifold: Euler characteristic 2 (V - E + F with E = 3F/2)
+    assert s.nV - 3 * s.nT // 2 + s.nT == 2
+    e = np.sort(np.concatenate([s.T[:, [0, 1]], s.T[:, [1, 2]], s.T[:, [2, 0]]]), axis=1)
+    _, counts = np.unique(e, axis=0, return_counts=True)
+    assert np.all(counts == 2) and s.T.max() == s.nV - 1
