@@ -64,8 +64,9 @@ struct SweepArgs {
 	uint32_t *slow_list, *dirty_list;
 	uint32_t *chunk_fill;    // records used in every ENTRY_CHUNK-sized piece of the record array
 	uint32_t entry_cap;      // multiple of ENTRY_CHUNK
-	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only, results are wrong): 1 skip the cell
-	                         // loop, 2 skip the whole cell stage
+	uint32_t horiz_cost;     // cost of one row processed across the lanes, in vertical-loop iterations (tunable)
+	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only; the emit kernels are not launched):
+	                         // 1 stop after counting the active cells, 2 skip the whole cell stage
 	Counters *ctr;
 };
 
@@ -73,7 +74,8 @@ struct SweepArgs {
 // touching global memory and takes a new chunk (one returning atomic) only when the cells of a tile
 // slice do not fit any more.  The emit kernels walk the chunks and their fill counts.
 constexpr uint32_t ENTRY_CHUNK = 256;
-constexpr uint32_t MASK_CHUNK = 64;  // activity-mask records are handed out the same way (<= 63 per tile slice)
+constexpr uint32_t MASK_CHUNK = 64;
+constexpr uint32_t HORIZ_COST = 5;   // cost of one row processed across the lanes, in vertical-loop iterations  // activity-mask records are handed out the same way (<= 63 per tile slice)
 
 // fast[i] of mc33_cell.h unpacked into the record words the sweep writes for a FAST cell:
 // x = w0 without the cell's x, y = w2, z = w3, w = new vertices | triangles << 8   (x == FAST_NONE: not fast)
@@ -105,6 +107,9 @@ __device__ __forceinline__ uint64_t shfl_down1(uint64_t x) {
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t row_above(uint32_t v) {  // lane r <- lane r+1 (lane 63 <- 0): DPP wave_shl:1
 	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
+	return u64(__builtin_amdgcn_readlane((uint32_t)v, l), __builtin_amdgcn_readlane((uint32_t)(v >> 32), l));
 }
 __device__ __forceinline__ uint64_t row_above(uint64_t v) { return u64(row_above((uint32_t)v), row_above((uint32_t)(v >> 32))); }
 
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				}
 				const uint32_t maskidx = mk_pos + (uint32_t)__popcll(havem & ((1ull << lane) - 1ull));
 				mk_pos += nm;
-				if (cnt && maskidx < a.entry_cap && !(a.debug & 8u)) {
+				if (cnt && maskidx < a.entry_cap) {
 					uint64_t *mr = a.seg_mask + 4ull * maskidx;
 					mr[0] = act[0]; mr[1] = act[1]; mr[2] = act[2]; mr[3] = act[3];
 				}
@@ -288,10 +293,27 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				bool dirty = false;
 				// rows whose cells cannot take the fast path: on the y = 0 / z = 0 faces (extra owned edges),
 				// or in a tile plane pair that holds a sample equal to the isovalue
-				const bool rowslow = y == 0 || z == 0 || prev_z || cur_z;
+				const bool planeslow = z == 0 || prev_z || cur_z;  // wave-uniform
+				const bool rowslow = y == 0 || planeslow;
+				// Two ways through the active cells of the tile slice.  VERTICAL: every lane walks the cells of
+				// its own row (good when rows hold few cells: 63 rows advance together).  HORIZONTAL: one row
+				// at a time, lane L takes cell x = 64k+L (good for rows where the surface runs along x: a run of
+				// 50 cells costs 1-2 passes instead of 50 iterations with one lane busy).  Rows with more than
+				// The split threshold is chosen per tile slice from a cost model in units of one vertical
+				// iteration: vertical = min(largest row, T) iterations, horizontal = ~HORIZ_COST per row above T.
+				uint32_t maxcnt = cnt;
+#pragma unroll
+				for (int dlt = 32; dlt; dlt >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor(maxcnt, dlt));
+				uint32_t long_T = 256u, best = maxcnt;
+#pragma unroll
+				for (uint32_t T2 = 8; T2 <= 64; T2 <<= 1) {
+					const uint32_t c2 = T2 + a.horiz_cost * (uint32_t)__popcll(__ballot(cnt > T2));
+					if (maxcnt > T2 && c2 < best) { best = c2; long_T = T2; }
+				}
+				const bool longrow = cnt > long_T;
+				uint64_t longrows = __ballot(longrow);
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
-					if (a.debug & 16u) break;
 					// the four bit rows of this word, and the same shifted by one sample (x+1)
 					const uint64_t q0 = prev[k], q1 = cur[k], q0n = prev_n[k], q1n = cur_n[k];
 					uint64_t n0, n1, n0n, n1n;  // bit 0 of the next word of each row
@@ -301,7 +323,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 					} else { n0 = prev_h; n1 = cur_h; n0n = prev_hn; n1n = cur_hn; }
 					const uint64_t q0s = (q0 >> 1) | (n0 << 63), q1s = (q1 >> 1) | (n1 << 63);
 					const uint64_t q0ns = (q0n >> 1) | (n0n << 63), q1ns = (q1n >> 1) | (n1n << 63);
-					uint64_t todo = act[k];
+					uint64_t todo = longrow ? 0ull : act[k];
 					for (;;) {
 						const bool has = todo != 0ull;
 						if (!__any(has)) break;
@@ -324,7 +346,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 								dirty = true;
 								if (idx < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = idx;
 							}
-							if (idx < a.entry_cap && !(a.debug & 4u)) {
+							if (idx < a.entry_cap) {
 								a.entries[idx] = e;
 								a.entry_seg[idx] = (uint32_t)sidx;
 							}
@@ -332,7 +354,65 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 						}
 					}
 				}
-				if (rowvalid && !(a.debug & 8u)) {
+				while (longrows) {  // wave-uniform loop over the long rows
+					const uint32_t r = (uint32_t)__ffsll((long long)longrows) - 1u;
+					longrows &= longrows - 1;
+					const uint32_t first_r = __builtin_amdgcn_readlane(first, r);
+					const bool slow_r = (y0 + r) == 0 || planeslow;
+					const uint64_t sidx_r = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + (y0 + r);
+					uint32_t run = 0, pre = 0;  // new vertices | triangles << 16 so far in the row; records so far
+					bool dirty_r = false;
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const uint64_t a_k = readlane64(act[k], r);
+						if (!a_k) continue;
+						const uint64_t q0 = readlane64(prev[k], r), q1 = readlane64(cur[k], r);
+						const uint64_t q0n = readlane64(prev_n[k], r), q1n = readlane64(cur_n[k], r);
+						uint64_t n0, n1, n0n, n1n;
+						if (k < 3) {
+							n0 = readlane64(prev[k < 3 ? k + 1 : 3], r) & 1ull; n1 = readlane64(cur[k < 3 ? k + 1 : 3], r) & 1ull;
+							n0n = readlane64(prev_n[k < 3 ? k + 1 : 3], r) & 1ull; n1n = readlane64(cur_n[k < 3 ? k + 1 : 3], r) & 1ull;
+						} else {
+							n0 = __builtin_amdgcn_readlane(prev_h, r); n1 = __builtin_amdgcn_readlane(cur_h, r);
+							n0n = __builtin_amdgcn_readlane(prev_hn, r); n1n = __builtin_amdgcn_readlane(cur_hn, r);
+						}
+						const uint64_t q0s = (q0 >> 1) | (n0 << 63), q1s = (q1 >> 1) | (n1 << 63);
+						const uint64_t q0ns = (q0n >> 1) | (n0n << 63), q1ns = (q1n >> 1) | (n1n << 63);
+						const bool on = (a_k >> lane) & 1ull;
+						const uint32_t xl = 64u * k + lane;
+						const uint32_t i = (uint32_t)((q0 >> lane) & 1) << 7 | (uint32_t)((q0n >> lane) & 1) << 6 | (uint32_t)((q1n >> lane) & 1) << 5 |
+						                   (uint32_t)((q1 >> lane) & 1) << 4 | (uint32_t)((q0s >> lane) & 1) << 3 | (uint32_t)((q0ns >> lane) & 1) << 2 |
+						                   (uint32_t)((q1ns >> lane) & 1) << 1 | (uint32_t)((q1s >> lane) & 1);
+						const uint4 f = s_fast[i];
+						const bool fastcell = on && !slow_r && f.x != FAST_NONE && (xbase + xl) != 0;
+						const uint32_t val = fastcell ? ((f.w & 0xFFu) | (f.w >> 8) << 16) : 0u;
+						uint32_t inc = val;  // inclusive scan over the lanes (cells in x order)
+#pragma unroll
+						for (int dlt = 1; dlt < 64; dlt <<= 1) {
+							const uint32_t t = __shfl_up(inc, dlt);
+							if ((int)lane >= dlt) inc += t;
+						}
+						const uint32_t off = run + inc - val;
+						const uint32_t ri = first_r + pre + (uint32_t)__popcll(a_k & ((1ull << lane) - 1ull));
+						if (on) {
+							Entry e;
+							if (fastcell) { e.w0 = f.x | xl; e.w1 = off; e.w2 = f.y; e.w3 = f.z; }
+							else {
+								e = make_pending_entry(xl, i);
+								if (ri < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = ri;
+							}
+							if (ri < a.entry_cap) {
+								a.entries[ri] = e;
+								a.entry_seg[ri] = (uint32_t)sidx_r;
+							}
+						}
+						dirty_r = dirty_r || (__ballot(on && !fastcell) != 0ull);
+						run += __builtin_amdgcn_readlane(inc, 63);
+						pre += (uint32_t)__popcll(a_k);
+					}
+					if (lane == r) { nv_run = run & 0xFFFFu; nt_run = run >> 16; dirty = dirty_r; }
+				}
+				if (rowvalid) {
 					a.seg_cnt[sidx] = dirty ? 0u : seg_pack(nv_run, nt_run);
 					if (cnt) {
 						a.seg_dir[sidx] = SegDir{first, cnt | (dirty ? SEG_DIRTY : 0u), maskidx, pack_prefix(c0, c1, c2)};
@@ -881,6 +961,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	a.chunk_fill = c->chunk_fill;
 	a.entry_cap = (uint32_t)c->entry_cap;
 	a.debug = env_u32("MC33_HIP_DEBUG", 0);
+	a.horiz_cost = env_u32("MC33_HIP_HCOST", HORIZ_COST);
 	a.ctr = c->d_ctr;
 	const uint64_t blocks = (uint64_t)a.nXG * a.nYT * nZC;
 	if (blocks > 0x7FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
@@ -909,6 +990,10 @@ static int enqueue_count(mc33hip_ctx *c) {
 }
 
 static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t capV, uint64_t capT) {
+	if (env_u32("MC33_HIP_DEBUG", 0)) {  // timing experiment: the work records are incomplete, never read them
+		HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+		return 0;
+	}
 	EmitArgs a;
 	a.c.tab.lut = c->d_lut; a.c.tab.rule_words = c->d_rules; a.c.tab.rule_index = c->d_rule_index;
 	a.c.P = c->P;
