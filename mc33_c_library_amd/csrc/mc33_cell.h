@@ -778,51 +778,88 @@ MC33_HD void fast_owned_vertex(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint
 	store_vertex(P, r, c.V, c.N, id - c.v_skip);
 }
 
-// Emit pass for one FAST entry (see make_fast_entry).  ids: 12-slot scratch.
-// The six neighbours that own the other nine edges are looked up TOGETHER: all
-// directory records first, then all mask words, then all work records - three dependent round trips to
-// memory in total instead of three per neighbour.  A neighbour that is not needed is redirected to this
-// cell's own records (valid addresses, cached), so the loads carry no control flow.  The edges have no end
-// point equal to the isovalue (they are edges of a fast cell), so their owners created regular vertices:
-// no alias to follow.
+// ---- fast emit, split in two passes so that each has a short dependency chain and few registers -------
+// Vertices of one FAST record: 8 corners, then per owned cut edge 8 more samples for the normal.
 template <typename T>
-MC33_HD void emit_fast_cell(const EmitCtx<T> &c, const Entry &en, uint32_t s, uint32_t self_index, const URef &ids) {
+MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s) {
+	const uint32_t r5 = (en.w2 >> 20) & 15u, r6 = (en.w2 >> 24) & 15u, r10 = (en.w3 >> 8) & 15u;
+	if ((r5 & r6 & r10) == 15u) return;  // the cell creates no vertex
+	const SegCoord sc = segment_coord(c.P, s);
+	const uint32_t y = sc.y, z = sc.z;
+	if (z < c.z_emit) return;
+	const uint32_t x = sc.xbase + (en.w0 & 0xFFu);
+	const uint32_t vbase = c.seg_base[s].vbase + (en.w1 & 0xFFFFu);
+	float v[8];
+	v[0] = c.P.iso - (float)c.G.at(x, y, z);         v[1] = c.P.iso - (float)c.G.at(x, y + 1, z);
+	v[2] = c.P.iso - (float)c.G.at(x, y + 1, z + 1); v[3] = c.P.iso - (float)c.G.at(x, y, z + 1);
+	v[4] = c.P.iso - (float)c.G.at(x + 1, y, z);     v[5] = c.P.iso - (float)c.G.at(x + 1, y + 1, z);
+	v[6] = c.P.iso - (float)c.G.at(x + 1, y + 1, z + 1); v[7] = c.P.iso - (float)c.G.at(x + 1, y, z + 1);
+	if (r5 != 15u) fast_owned_vertex<T, 5>(c, x, y, z, v, vbase + r5);
+	if (r6 != 15u) fast_owned_vertex<T, 6>(c, x, y, z, v, vbase + r6);
+	if (r10 != 15u) fast_owned_vertex<T, 10>(c, x, y, z, v, vbase + r10);
+}
+
+// Triangles of one FAST record.  ids: 12-slot scratch.
+// The other nine edges belong to six neighbours; edge k of this cell is edge k' of
+// its owner:  o0 (x-1,y,z-1): 0->6 | o1 (x-1,y,z): 1->5, 2->6 | o2 (x-1,y-1,z): 3->5 |
+//             o3 (x,y,z-1): 4->6, 9->10 | o4 (x,y-1,z): 7->5, 11->10 | o5 (x,y-1,z-1): 8->10
+// They sit in three other row segments - A = (y, z-1): o3 and, one record before it, o0; B = (y-1, z): o4, o2;
+// C = (y-1, z-1): o5 - and o1 is the record right before this cell's own.  All directory records are fetched
+// together, then the three activity-mask words, then the (at most five) work records: three dependent
+// round trips.  Neighbours that are not needed are redirected to this cell's own records (valid, cached
+// addresses), so the loads carry no control flow.  The edges have no end point equal to the isovalue (they
+// are edges of a fast cell), so their owners created regular vertices: no alias to follow.
+template <typename T>
+MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t s, uint32_t self_index, const URef &ids) {
 	const SegCoord sc = segment_coord(c.P, s);
 	const uint32_t y = sc.y, z = sc.z;
 	if (z < c.z_emit) return;
 	const uint32_t xl = en.w0 & 0xFFu, x = sc.xbase + xl;
 	const uint32_t i = (en.w0 >> 8) & 0xFFu;
 #define MC33_SIDE(k) ((i >> (7 - (k))) & 1u)
-	// edge k of this cell is edge k' of its owner:
-	//   o=0 (x-1,y,z-1): 0->6 | o=1 (x-1,y,z): 1->5, 2->6 | o=2 (x-1,y-1,z): 3->5 |
-	//   o=3 (x,y,z-1): 4->6, 9->10 | o=4 (x,y-1,z): 7->5, 11->10 | o=5 (x,y-1,z-1): 8->10
 	const bool cut0 = MC33_SIDE(0) != MC33_SIDE(1), cut1 = MC33_SIDE(1) != MC33_SIDE(2), cut2 = MC33_SIDE(3) != MC33_SIDE(2);
 	const bool cut3 = MC33_SIDE(0) != MC33_SIDE(3), cut4 = MC33_SIDE(4) != MC33_SIDE(5), cut9 = MC33_SIDE(1) != MC33_SIDE(5);
 	const bool cut7 = MC33_SIDE(4) != MC33_SIDE(7), cut11 = MC33_SIDE(3) != MC33_SIDE(7), cut8 = MC33_SIDE(0) != MC33_SIDE(4);
 #undef MC33_SIDE
 	const bool need[6] = {cut0, cut1 || cut2, cut3, cut4 || cut9, cut7 || cut11, cut8};
-	const uint32_t odx[6] = {1, 1, 1, 0, 0, 0}, ody[6] = {0, 0, 1, 0, 1, 1}, odz[6] = {1, 0, 0, 1, 0, 1};
-	uint64_t os[6];
-	uint32_t oxl[6];
-	SegDir od[6];
-	uint32_t ovb[6];
-	for (int o = 0; o < 6; o++) {  // round trip 1: directory + vertex bases (plus this cell's own bases and corners)
-		const uint32_t ox = x - odx[o];
-		os[o] = need[o] ? segment_index(c.P, ox, y - ody[o], z - odz[o]) : (uint64_t)s;
-		oxl[o] = need[o] ? ox % SEG_CELLS : xl;
-		od[o] = c.seg_dir[os[o]];
-		ovb[o] = c.seg_base[os[o]].vbase;
-	}
 	const SegBase sb = c.seg_base[s];
-	float v[8];
-	v[0] = c.P.iso - (float)c.G.at(x, y, z);         v[1] = c.P.iso - (float)c.G.at(x, y + 1, z);
-	v[2] = c.P.iso - (float)c.G.at(x, y + 1, z + 1); v[3] = c.P.iso - (float)c.G.at(x, y, z + 1);
-	v[4] = c.P.iso - (float)c.G.at(x + 1, y, z);     v[5] = c.P.iso - (float)c.G.at(x + 1, y + 1, z);
-	v[6] = c.P.iso - (float)c.G.at(x + 1, y + 1, z + 1); v[7] = c.P.iso - (float)c.G.at(x + 1, y, z + 1);
-	uint64_t ow[6];
-	for (int o = 0; o < 6; o++) ow[o] = c.seg_mask[4ull * od[o].maskidx + (oxl[o] >> 6)];  // round trip 2: activity masks
 	Entry oe[6];
-	for (int o = 0; o < 6; o++) oe[o] = c.entries[need[o] ? record_rank(od[o], ow[o], oxl[o]) : self_index];  // round trip 3
+	uint32_t ovb[6];
+	if (xl != 0) {
+		// segments A, B, C (index 0..2); x-1 lies in the same segments as x
+		const bool needseg[3] = {need[0] || need[3], need[2] || need[4], need[5]};
+		const uint32_t sdy[3] = {0, 1, 1}, sdz[3] = {1, 0, 1};
+		SegDir sd[3];
+		uint32_t svb[3];
+		for (int g = 0; g < 3; g++) {  // round trip 1
+			const uint64_t gs = needseg[g] ? segment_index(c.P, x, y - sdy[g], z - sdz[g]) : (uint64_t)s;
+			sd[g] = c.seg_dir[gs];
+			svb[g] = c.seg_base[gs].vbase;
+		}
+		const Entry prev = c.entries[need[1] ? self_index - 1 : self_index];  // o1: the cell x-1 is active whenever needed
+		uint32_t below[3];
+		for (int g = 0; g < 3; g++)  // round trip 2: records of the segment below x
+			below[g] = record_rank(sd[g], c.seg_mask[4ull * sd[g].maskidx + (xl >> 6)], xl);
+		// round trip 3: the records (x-1 is the record before x's position, it is active whenever needed)
+		oe[3] = c.entries[need[3] ? below[0] : self_index];
+		oe[0] = c.entries[need[0] ? below[0] - 1 : self_index];
+		oe[4] = c.entries[need[4] ? below[1] : self_index];
+		oe[2] = c.entries[need[2] ? below[1] - 1 : self_index];
+		oe[5] = c.entries[need[5] ? below[2] : self_index];
+		oe[1] = prev;
+		ovb[0] = ovb[3] = svb[0]; ovb[2] = ovb[4] = svb[1]; ovb[5] = svb[2]; ovb[1] = sb.vbase;
+	} else {
+		// first cell of a row segment: the x-1 neighbours live in the previous segment - six plain lookups
+		const uint32_t odx[6] = {1, 1, 1, 0, 0, 0}, ody[6] = {0, 0, 1, 0, 1, 1}, odz[6] = {1, 0, 0, 1, 0, 1};
+		for (int o = 0; o < 6; o++) {
+			const uint32_t ox = x - odx[o];
+			const uint64_t os = need[o] ? segment_index(c.P, ox, y - ody[o], z - odz[o]) : (uint64_t)s;
+			const uint32_t oxl = need[o] ? ox % SEG_CELLS : xl;
+			const SegDir d = c.seg_dir[os];
+			ovb[o] = c.seg_base[os].vbase;
+			oe[o] = c.entries[need[o] ? record_rank(d, c.seg_mask[4ull * d.maskidx + (oxl >> 6)], oxl) : self_index];
+		}
+	}
 	uint32_t ob[6];
 	for (int o = 0; o < 6; o++) ob[o] = ovb[o] + (oe[o].w1 & 0xFFFFu);
 	ids[0] = ob[0] + entry_rank(oe[0], 6);
@@ -831,14 +868,9 @@ MC33_HD void emit_fast_cell(const EmitCtx<T> &c, const Entry &en, uint32_t s, ui
 	ids[4] = ob[3] + entry_rank(oe[3], 6);  ids[9] = ob[3] + entry_rank(oe[3], 10);
 	ids[7] = ob[4] + entry_rank(oe[4], 5);  ids[11] = ob[4] + entry_rank(oe[4], 10);
 	ids[8] = ob[5] + entry_rank(oe[5], 10);
-	// this cell's own vertices
 	const uint32_t vbase = sb.vbase + (en.w1 & 0xFFFFu);
 	uint32_t tpos = sb.tbase + (en.w1 >> 16) - c.t_skip;
-	const uint32_t r5 = (en.w2 >> 20) & 15u, r6 = (en.w2 >> 24) & 15u, r10 = (en.w3 >> 8) & 15u;
-	ids[5] = vbase + r5; ids[6] = vbase + r6; ids[10] = vbase + r10;
-	if (r5 != 15u) fast_owned_vertex<T, 5>(c, x, y, z, v, vbase + r5);
-	if (r6 != 15u) fast_owned_vertex<T, 6>(c, x, y, z, v, vbase + r6);
-	if (r10 != 15u) fast_owned_vertex<T, 10>(c, x, y, z, v, vbase + r10);
+	ids[5] = vbase + ((en.w2 >> 20) & 15u); ids[6] = vbase + ((en.w2 >> 24) & 15u); ids[10] = vbase + ((en.w3 >> 8) & 15u);
 	// winding (MC:683-691): n = 1 swaps the first two indices
 	const uint32_t n = ((c.tab.lut[(i & 0x80) ? (i ^ 0xFF) : i] >> 11) ^ (i >> 7) ^ 1u) & 1u;
 	uint32_t pos = (en.w0 >> 16) & 0xFFFu, word;

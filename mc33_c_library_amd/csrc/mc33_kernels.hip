@@ -73,7 +73,7 @@ struct SweepArgs {
 // Work records are handed out to the waves in chunks: a wave sub-allocates from its open chunk without
 // touching global memory and takes a new chunk (one returning atomic) only when the cells of a tile
 // slice do not fit any more.  The emit kernels walk the chunks and their fill counts.
-constexpr uint32_t ENTRY_CHUNK = 256;
+constexpr uint32_t ENTRY_CHUNK = 1024;  // ~ the records of one wave tile: a chunk is spatially compact (one emit block walks it)
 constexpr uint32_t MASK_CHUNK = 64;
 constexpr uint32_t HORIZ_COST = 5;   // cost of one row processed across the lanes, in vertical-loop iterations  // activity-mask records are handed out the same way (<= 63 per tile slice)
 
@@ -594,8 +594,8 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uin
 }
 
 // ---------------------------------------------------------------------------------------------------
-// emit: one thread per work record.  k_emit_fast handles the records the sweep finished itself,
-// k_emit_slow the ones k_slow_plan planned (generic path: aliases, cells on the grid faces, ...)
+// emit: one thread per work record.  k_emit_fast_vertices / k_emit_fast_triangles handle the records the
+// sweep finished itself, k_emit_slow the ones k_slow_plan planned (generic path: aliases, cells on the grid faces, ...)
 // ---------------------------------------------------------------------------------------------------
 struct EmitArgs {
 	EmitCtx<sample_t> c;
@@ -622,20 +622,39 @@ __device__ __forceinline__ bool emit_prepare(const EmitArgs &a, EmitCtx<sample_t
 	return true;
 }
 
-__global__ __launch_bounds__(256) void k_emit_fast(const EmitArgs a) {
+// vertices of the fast records (positions + normals)
+__global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
+	const Counters ctr = *a.ctr;
+	EmitCtx<sample_t> c = a.c;
+	if (!emit_prepare(a, c, ctr)) return;
+	const uint32_t nchunks = ctr.entry_cursor / ENTRY_CHUNK;
+	for (uint32_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+		const uint32_t fill = a.chunk_fill[ch];
+		for (uint32_t q = threadIdx.x; q < fill; q += 256u) {
+			const uint32_t e = ch * ENTRY_CHUNK + q;
+			const Entry en = c.entries[e];
+			if (en.w3 & ENTRY_SLOW) continue;
+			emit_fast_vertices(c, en, c.entry_seg[e]);
+		}
+	}
+}
+
+// triangles of the fast records (ids of shared edges through the owners' records)
+__global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	__shared__ uint32_t s_id[12][256];
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
 	const uint32_t nchunks = ctr.entry_cursor / ENTRY_CHUNK;
-	static_assert(ENTRY_CHUNK == 256, "one record per thread");
 	for (uint32_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-		if (threadIdx.x >= a.chunk_fill[ch]) continue;
-		const uint32_t e = ch * ENTRY_CHUNK + threadIdx.x;
-		const Entry en = c.entries[e];
-		if (en.w3 & ENTRY_SLOW) continue;
-		emit_fast_cell(c, en, c.entry_seg[e], e, ids);
+		const uint32_t fill = a.chunk_fill[ch];
+		for (uint32_t q = threadIdx.x; q < fill; q += 256u) {
+			const uint32_t e = ch * ENTRY_CHUNK + q;
+			const Entry en = c.entries[e];
+			if (en.w3 & ENTRY_SLOW) continue;
+			emit_fast_triangles(c, en, c.entry_seg[e], e, ids);
+		}
 	}
 }
 
@@ -695,6 +714,8 @@ struct mc33hip_ctx {
 	uint64_t entry_cap;
 	Counters *d_ctr, *h_ctr;
 	hipEvent_t ev[4];
+	hipStream_t aux;          // the vertex pass runs beside the triangle passes (both wait for the scans)
+	hipEvent_t ev_fork, ev_join;
 	// state of the last count
 	bool counted;
 	Params P;
@@ -754,6 +775,9 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	CREATE_TRY(hipMalloc(&c->d_ctr, sizeof(Counters)));
 	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
 	for (int k = 0; k < 4; k++) CREATE_TRY(hipEventCreate(&c->ev[k]));
+	CREATE_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+	CREATE_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 #undef CREATE_TRY
 	return MC33HIP_OK;
 }
@@ -772,6 +796,9 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
+	if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	free(c);
 }
 
@@ -930,7 +957,7 @@ static int ensure_workspaces(mc33hip_ctx *c) {
 	if (!c->entries) {
 		// first guess: one cell in 32 is cut (BASELINE fields: 0.4-6 % of the cells); grown on demand
 		const uint64_t cells = (uint64_t)c->P.nx * c->P.ny * (c->range.z_end - c->P.zs);
-		return alloc_entries(c, cells / 32 + 65536);
+		return alloc_entries(c, cells / 24 + 4u * 65536);
 	}
 	return 0;
 }
@@ -1010,9 +1037,21 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
 	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 32u);
-	hipLaunchKernelGGL(k_emit_fast, dim3(blocks), dim3(256), 0, c->stream, a);
+	// The three emit passes are independent (V/N vs T, fast vs slow records) and each is bound by the
+	// latency of scattered reads, not by bandwidth: the vertex pass runs on a second stream beside the
+	// two triangle passes and joins before the end-of-call event.
+	const bool fork = !env_u32("MC33_HIP_NO_FORK", 0);
+	hipStream_t sv = fork ? c->aux : c->stream;
+	if (fork) {
+		HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+		HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+	}
+	hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, sv, a);
+	if (fork) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
+	hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, c->stream, a);
 	hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, c->stream, a);
 	HIP_TRY(hipGetLastError());
+	if (fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
 	HIP_TRY(hipEventRecord(c->ev[3], c->stream));
 	return 0;
 }

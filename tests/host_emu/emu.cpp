@@ -124,7 +124,10 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	c.z_emit = z_emit; c.v_skip = gV; c.t_skip = gT; c.id_delta = id_base - gV;
 	for (size_t k = 0; k < entries.size(); k++) {
 		if (entries[k].w3 & ENTRY_SLOW) emit_cell(c, (uint32_t)k, v, w, ids);
-		else emit_fast_cell(c, entries[k], entry_seg[k], (uint32_t)k, ids);
+		else {
+			emit_fast_vertices(c, entries[k], entry_seg[k]);
+			emit_fast_triangles(c, entries[k], entry_seg[k], (uint32_t)k, ids);
+		}
 	}
 	return 0;
 }
