@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=int(os.environ.get("MC33_BENCH_N", "1024")), help="points per axis per GPU slab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("MC33_BENCH_CPU_N", "640")),
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("MC33_BENCH_CPU_N", "1024")),
                     help="points per axis of the sub-grid the CPU reference is timed on")
     return ap.parse_args()
 
@@ -50,7 +50,7 @@ def cpu_baseline(field_cpu, r0, d, iso):
     G, keep = lib.make_grid(field_cpu, r0, d)
     M = lib.lib.create_MC33(G)
     best, nT = None, 0
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
         S = lib.lib.calculate_isosurface(M, C.c_float(iso))
         dt = time.perf_counter() - t0
@@ -70,7 +70,7 @@ def cpu_baseline(field_cpu, r0, d, iso):
     except OSError:
         pass
     return {"value": cells / best / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": kind,
-            "sample": "corner %d^3-point sub-grid of the same field, calculate_isosurface best of 2, %.2f s, %d triangles"
+            "sample": "%d^3-point grid of the same field, calculate_isosurface best of 3, %.2f s per call, %d triangles"
                       % (n, best, nT),
             "host_cores_available": os.cpu_count(), "cpu": model, "mtris_per_s": nT / best / 1e6}
 
@@ -87,11 +87,35 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+    # MC33_BENCH_REHEARSAL=1: rehearse the N>1 orchestration on a ONE-GPU box - all ranks share cuda:0, the
+    # collectives go through gloo on host copies (NCCL refuses two ranks on one device).  Never used by the driver.
+    rehearsal = os.environ.get("MC33_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def all_gather_flat(out, inp):
+        if rehearsal:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.cpu())
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp)
+
+    def all_reduce(t, op=None):
+        if rehearsal:
+            c = t.cpu()
+            dist.all_reduce(c, op=op or dist.ReduceOp.SUM)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
 
     n = args.n
     iso = 0.0
@@ -112,49 +136,72 @@ def main():
     # capacity from one count pass (all ranks use the same capacity so the gather is a plain all-gather)
     cnt = grid.count(iso, rng())
     capV, capT = int(cnt.nV * 1.05) + 1024, int(cnt.nT * 1.05) + 1024
+    overlap = world > 1 and not rehearsal and os.environ.get("MC33_BENCH_NO_OVERLAP", "0") != "1"
+    nbuf = 2 if overlap else 1
     if world > 1:
         caps = torch.tensor([capV, capT], dtype=torch.int64, device=dev)
-        dist.all_reduce(caps, op=dist.ReduceOp.MAX)
+        all_reduce(caps, dist.ReduceOp.MAX)
         capV, capT = (int(x) for x in caps.tolist())
         counts_all = torch.zeros(world * 2, dtype=torch.int64, device=dev)
-        gV = torch.empty((world, capV, 3), dtype=torch.float32, device=dev)
-        gN = torch.empty_like(gV)
-        gT = torch.empty((world, capT, 3), dtype=torch.int32, device=dev)
-    V = torch.empty((capV, 3), dtype=torch.float32, device=dev)
-    N = torch.empty_like(V)
-    T = torch.empty((capT, 3), dtype=torch.int32, device=dev)
+        gV = [torch.empty((world, capV, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        gN = [torch.empty_like(gV[0]) for _ in range(nbuf)]
+        gT = [torch.empty((world, capT, 3), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+        # the tiny count exchange gets its own communicator: it must not queue behind the surface gathers
+        small_group = dist.new_group() if overlap else None
+    V = [torch.empty((capV, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    N = [torch.empty_like(V[0]) for _ in range(nbuf)]
+    T = [torch.empty((capT, 3), dtype=torch.int32, device=dev) for _ in range(nbuf)]
 
     sweep_ms, scan_ms, emit_ms, gather_ms = [], [], [], []
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    pending = [[] for _ in range(nbuf)]
+    step_no = [0]
 
     def step(record):
         if world == 1:
-            c, ok = grid.extract_into(iso, V, N, T, rng())
+            c, ok = grid.extract_into(iso, V[0], N[0], T[0], rng())
             assert ok
             if record:
                 t = grid.timing()
                 sweep_ms.append(t.sweep_ms); scan_ms.append(t.scan_ms); emit_ms.append(t.emit_ms)
             return c
-        # z-slabs: count -> exchange counts -> emit with the global id base -> all-gather the surface arrays
+        # z-slabs: count -> exchange counts -> emit with the global id base -> all-gather the surface arrays.
+        # With overlap, the gather of step k runs on RCCL's stream while step k+1 is being extracted
+        # (two sets of buffers; a buffer is reused only after its previous gather has completed).
+        b = step_no[0] % nbuf
+        step_no[0] += 1
+        for w in pending[b]:
+            w.wait()
+        pending[b] = []
         c = grid.count(iso, rng())
         t = grid.timing()
         mine = torch.tensor([c.nV, c.nT], dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(counts_all, mine)
+        if overlap:
+            dist.all_gather_into_tensor(counts_all, mine, group=small_group)
+        else:
+            all_gather_flat(counts_all, mine)
         id_base = int(counts_all.view(world, 2)[:rank, 0].sum().item()) if rank else 0
-        grid.emit_into(V, N, T, id_base)
-        ev[0].record()
-        dist.all_gather_into_tensor(gV.view(-1), V.view(-1))
-        dist.all_gather_into_tensor(gN.view(-1), N.view(-1))
-        dist.all_gather_into_tensor(gT.view(-1), T.view(-1))
-        ev[1].record()
+        grid.emit_into(V[b], N[b], T[b], id_base)
+        if overlap:
+            pending[b] = [dist.all_gather_into_tensor(gV[b].view(-1), V[b].view(-1), async_op=True),
+                          dist.all_gather_into_tensor(gN[b].view(-1), N[b].view(-1), async_op=True),
+                          dist.all_gather_into_tensor(gT[b].view(-1), T[b].view(-1), async_op=True)]
+        else:
+            all_gather_flat(gV[b].view(-1), V[b].view(-1))
+            all_gather_flat(gN[b].view(-1), N[b].view(-1))
+            all_gather_flat(gT[b].view(-1), T[b].view(-1))
         if record:
-            ev[1].synchronize()
-            gather_ms.append(ev[0].elapsed_time(ev[1]))
             sweep_ms.append(t.sweep_ms); scan_ms.append(t.scan_ms)
         return c
 
+    def drain():
+        for lst in pending:
+            for w in lst:
+                w.wait()
+            lst.clear()
+
     for _ in range(args.warmup):
         step(False)
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -162,20 +209,44 @@ def main():
     last = None
     for _ in range(args.steps):
         last = step(True)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gather_alone_ms = None
+    if world > 1:  # outside the timed region: what one un-overlapped surface all-gather costs
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        all_gather_flat(gV[0].view(-1), V[0].view(-1))
+        all_gather_flat(gN[0].view(-1), N[0].view(-1))
+        all_gather_flat(gT[0].view(-1), T[0].view(-1))
+        e1.record()
+        torch.cuda.synchronize()
+        gather_alone_ms = e0.elapsed_time(e1)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce(tmax, dist.ReduceOp.MAX)
         dt = float(tmax.item())
         tot = torch.tensor([cells_rank, last.nV, last.nT], dtype=torch.int64, device=dev)
-        dist.all_reduce(tot)
+        all_reduce(tot)
         cells_all, nV_all, nT_all = (int(x) for x in tot.tolist())
     else:
         cells_all, nV_all, nT_all = cells_rank, last.nV, last.nT
 
+    if world > 1 and os.environ.get("MC33_BENCH_VERIFY", "0") == "1":
+        # concatenated gathered surface == whole-volume extraction by one context (small n only)
+        gV, gT = gV[(step_no[0] - 1) % nbuf], gT[(step_no[0] - 1) % nbuf]
+        host_counts = counts_all.view(world, 2).cpu()
+        whole_field = cos_field_slab(n, nz_total + 1, h, lo, dev, z_first=0)
+        wg = DeviceGrid(whole_field, r0=(lo, lo, lo), d=(h, h, h))
+        Vw, Nw, Tw, cw = wg.extract(iso)
+        Vc = torch.cat([gV[r, :int(host_counts[r, 0])] for r in range(world)])
+        Tc = torch.cat([gT[r, :int(host_counts[r, 1])] for r in range(world)])
+        ok = bool(torch.equal(Tc, Tw) and torch.equal(Vc.view(torch.int32), Vw.contiguous().view(torch.int32)))
+        print("[rank %d] slab concatenation equals whole-volume result: %s (nV %d nT %d)" % (rank, ok, cw.nV, cw.nT), file=sys.stderr)
+        assert ok
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         avg = lambda a: (sum(a) / len(a)) if a else 0.0
@@ -209,7 +280,8 @@ def main():
                "mtris_per_s": nT_all / (dt / args.steps) / 1e6,
                "roofline": roof}
         if world > 1:
-            res["gather_ms"] = avg(gather_ms)
+            res["gather_ms"] = gather_alone_ms
+            res["gather_overlapped_with_next_extraction"] = bool(overlap)
         if not args.no_cpu_baseline and world == 1:
             m = min(args.cpu_sample, n)
             sub = field[:m, :m, :m].contiguous().cpu().numpy()

@@ -95,7 +95,7 @@ int mc33hip_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long lon
 int mc33hip_extract(mc33hip_ctx *c, float iso, const mc33hip_range *range, void *dV, void *dN, void *dT,
                     unsigned long long capV, unsigned long long capT, mc33hip_counts *out);
 
-int mc33hip_last_timing(const mc33hip_ctx *c, mc33hip_timing *t);
+int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t);  /* waits for a pending mc33hip_emit */
 
 /* Device-to-host copy helper for callers without a HIP runtime of their own (blocking). */
 int mc33hip_download(mc33hip_ctx *c, void *host_dst, const void *device_src, size_t bytes);

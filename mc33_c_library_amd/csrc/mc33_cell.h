@@ -51,6 +51,11 @@ struct Tables {
 };
 
 template <typename T>
+struct __attribute__((packed, aligned(sizeof(T)))) SamplePair {  // two consecutive samples: one 8-byte (4-byte) load
+	T a, b;
+};
+
+template <typename T>
 struct GridView {  // pitched copy of _GRD.F in HBM: sample (x,y,z) at p[(z-z0)*slice + y*pitch + x]
 	const T *p;
 	uint32_t pitch;  // samples per row (>= nx+1)
@@ -61,6 +66,12 @@ struct GridView {  // pitched copy of _GRD.F in HBM: sample (x,y,z) at p[(z-z0)*
 		MC33_BOUNDS_HOOK(x, y, z);
 #endif
 		return p[(uint64_t)(z - z0) * slice + (uint64_t)y * pitch + x];
+	}
+	MC33_HD SamplePair<T> pair(uint32_t x, uint32_t y, uint32_t z) const {  // samples x and x+1 of a row
+#ifdef MC33_BOUNDS_HOOK
+		MC33_BOUNDS_HOOK(x + 1, y, z);
+#endif
+		return *(const SamplePair<T> *)(p + ((uint64_t)(z - z0) * slice + (uint64_t)y * pitch + x));
 	}
 };
 
@@ -779,7 +790,10 @@ MC33_HD void fast_owned_vertex(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint
 }
 
 // ---- fast emit, split in two passes so that each has a short dependency chain and few registers -------
-// Vertices of one FAST record: 8 corners, then per owned cut edge 8 more samples for the normal.
+// Vertices of one FAST record.  All samples the (up to three) owned vertices need are fetched up front as
+// short runs along x - the 2x2 rows of the cell (x..x+2) and the four rows one step outside it (y+2 on both
+// planes, plane z+2 on both rows) - instead of 8 + 8 per vertex scattered single loads.  The arithmetic and
+// its order are those of vertex_on_edge (MC:990-1000, 1029-1039, 1175-1185).
 template <typename T>
 MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s) {
 	const uint32_t r5 = (en.w2 >> 20) & 15u, r6 = (en.w2 >> 24) & 15u, r10 = (en.w3 >> 8) & 15u;
@@ -788,15 +802,60 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 	const uint32_t y = sc.y, z = sc.z;
 	if (z < c.z_emit) return;
 	const uint32_t x = sc.xbase + (en.w0 & 0xFFu);
+	const Params &P = c.P;
+	const GridView<T> &G = c.G;
 	const uint32_t vbase = c.seg_base[s].vbase + (en.w1 & 0xFFFFu);
-	float v[8];
-	v[0] = c.P.iso - (float)c.G.at(x, y, z);         v[1] = c.P.iso - (float)c.G.at(x, y + 1, z);
-	v[2] = c.P.iso - (float)c.G.at(x, y + 1, z + 1); v[3] = c.P.iso - (float)c.G.at(x, y, z + 1);
-	v[4] = c.P.iso - (float)c.G.at(x + 1, y, z);     v[5] = c.P.iso - (float)c.G.at(x + 1, y + 1, z);
-	v[6] = c.P.iso - (float)c.G.at(x + 1, y + 1, z + 1); v[7] = c.P.iso - (float)c.G.at(x + 1, y, z + 1);
-	if (r5 != 15u) fast_owned_vertex<T, 5>(c, x, y, z, v, vbase + r5);
-	if (r6 != 15u) fast_owned_vertex<T, 6>(c, x, y, z, v, vbase + r6);
-	if (r10 != 15u) fast_owned_vertex<T, 10>(c, x, y, z, v, vbase + r10);
+	const bool xin = x + 1 < P.nx, yin = y + 1 < P.ny, zin = z + 1 < P.nz;  // the outer neighbours exist
+	// F[row][col]: rows 0..3 = (y,z) (y+1,z) (y,z+1) (y+1,z+1); col = x, x+1, x+2
+	T F[4][3];
+	for (int r = 0; r < 4; r++) {
+		const uint32_t yy = y + (r & 1), zz = z + (r >> 1);
+		const SamplePair<T> q = G.pair(x, yy, zz);
+		F[r][0] = q.a;
+		F[r][1] = q.b;
+		F[r][2] = xin ? G.at(x + 2, yy, zz) : q.b;
+	}
+	// rows outside the cell: Y2[p][col] = (y+2, z+p), Z2[q][col] = (y+q, z+2); col = x, x+1
+	T Y2[2][2], Z2[2][2];
+	for (int q = 0; q < 2; q++) {
+		const SamplePair<T> yq = G.pair(x, yin ? y + 2 : y, z + q), zq = G.pair(x, y + q, zin ? z + 2 : z);
+		Y2[q][0] = yq.a; Y2[q][1] = yq.b;
+		Z2[q][0] = zq.a; Z2[q][1] = zq.b;
+	}
+	const float iso = P.iso;
+	const float v1 = iso - (float)F[1][0], v2 = iso - (float)F[3][0], v3 = iso - (float)F[2][0];
+	const float v4 = iso - (float)F[0][1], v5 = iso - (float)F[1][1], v6 = iso - (float)F[3][1], v7 = iso - (float)F[2][1];
+	float r[6];
+	if (r5 != 15u) {  // edge 5: (x+1, y+1, z) -> (x+1, y+1, z+1)
+		const float t = v5 / (v5 - v6);
+		r[0] = (float)(x + 1); r[1] = (float)(y + 1); r[2] = (float)z + t;
+		r[3] = xin ? 0.5f * (sample_diff(F[1][0], F[1][2]) * (1 - t) + sample_diff(F[3][0], F[3][2]) * t)
+		           : (v5 - v1) * (1 - t) + (v6 - v2) * t;
+		r[4] = yin ? 0.5f * (sample_diff(F[0][1], Y2[0][1]) * (1 - t) + sample_diff(F[2][1], Y2[1][1]) * t)
+		           : (v5 - v4) * (1 - t) + (v6 - v7) * t;
+		r[5] = v6 - v5;
+		store_vertex(P, r, c.V, c.N, vbase + r5 - c.v_skip);
+	}
+	if (r6 != 15u) {  // edge 6: (x+1, y, z+1) -> (x+1, y+1, z+1)
+		const float t = v7 / (v7 - v6);
+		r[0] = (float)(x + 1); r[1] = (float)y + t; r[2] = (float)(z + 1);
+		r[3] = xin ? 0.5f * (sample_diff(F[2][0], F[2][2]) * (1 - t) + sample_diff(F[3][0], F[3][2]) * t)
+		           : (v7 - v3) * (1 - t) + (v6 - v2) * t;
+		r[4] = v6 - v7;
+		r[5] = zin ? 0.5f * (sample_diff(F[0][1], Z2[0][1]) * (1 - t) + sample_diff(F[1][1], Z2[1][1]) * t)
+		           : (v7 - v4) * (1 - t) + (v6 - v5) * t;
+		store_vertex(P, r, c.V, c.N, vbase + r6 - c.v_skip);
+	}
+	if (r10 != 15u) {  // edge 10: (x, y+1, z+1) -> (x+1, y+1, z+1)
+		const float t = v2 / (v2 - v6);
+		r[0] = (float)x + t; r[1] = (float)(y + 1); r[2] = (float)(z + 1);
+		r[3] = v6 - v2;
+		r[4] = yin ? 0.5f * (sample_diff(F[2][0], Y2[1][0]) * (1 - t) + sample_diff(F[2][1], Y2[1][1]) * t)
+		           : (v2 - v3) * (1 - t) + (v6 - v7) * t;
+		r[5] = zin ? 0.5f * (sample_diff(F[1][0], Z2[1][0]) * (1 - t) + sample_diff(F[1][1], Z2[1][1]) * t)
+		           : (v2 - v1) * (1 - t) + (v6 - v5) * t;
+		store_vertex(P, r, c.V, c.N, vbase + r10 - c.v_skip);
+	}
 }
 
 // Triangles of one FAST record.  ids: 12-slot scratch.

@@ -714,8 +714,9 @@ struct mc33hip_ctx {
 	uint64_t entry_cap;
 	Counters *d_ctr, *h_ctr;
 	hipEvent_t ev[4];
-	hipStream_t aux;          // the vertex pass runs beside the triangle passes (both wait for the scans)
-	hipEvent_t ev_fork, ev_join;
+	hipStream_t aux, aux2;    // the vertex pass and the slow-record pass run beside the fast triangle pass
+	hipEvent_t ev_fork, ev_join, ev_join2;
+	bool emit_pending;        // an emit was enqueued after the last timing read
 	// state of the last count
 	bool counted;
 	Params P;
@@ -776,8 +777,10 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
 	for (int k = 0; k < 4; k++) CREATE_TRY(hipEventCreate(&c->ev[k]));
 	CREATE_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+	CREATE_TRY(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
 #undef CREATE_TRY
 	return MC33HIP_OK;
 }
@@ -797,8 +800,10 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
 	if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+	if (c->aux2) { (void)hipStreamSynchronize(c->aux2); (void)hipStreamDestroy(c->aux2); }
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+	if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
 	free(c);
 }
 
@@ -1003,7 +1008,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	sa.entries = c->entries; sa.entry_seg = c->entry_seg; sa.slow_list = c->slow_list;
 	sa.seg_cnt = c->seg_cnt; sa.seg_dir = c->seg_dir; sa.dirty_list = c->dirty_list;
 	sa.entry_cap = (uint32_t)c->entry_cap; sa.ctr = c->d_ctr;
-	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);
+	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 256);
 	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks), dim3(256), 0, st, sa);
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
 	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
@@ -1041,18 +1046,24 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	// latency of scattered reads, not by bandwidth: the vertex pass runs on a second stream beside the
 	// two triangle passes and joins before the end-of-call event.
 	const bool fork = !env_u32("MC33_HIP_NO_FORK", 0);
-	hipStream_t sv = fork ? c->aux : c->stream;
+	hipStream_t sv = fork ? c->aux : c->stream, ss = fork ? c->aux2 : c->stream;
 	if (fork) {
 		HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
 		HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+		HIP_TRY(hipStreamWaitEvent(c->aux2, c->ev_fork, 0));
 	}
+	hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 256)), dim3(256), 0, ss, a);
+	if (fork) HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
 	hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, sv, a);
 	if (fork) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
 	hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, c->stream, a);
-	hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, c->stream, a);
 	HIP_TRY(hipGetLastError());
-	if (fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+	if (fork) {
+		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+	}
 	HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+	c->emit_pending = true;
 	return 0;
 }
 
@@ -1078,6 +1089,7 @@ static int finish_counts(mc33hip_ctx *c, mc33hip_counts *out) {
 
 static void read_timing(mc33hip_ctx *c, bool with_emit, unsigned launches) {
 	mc33hip_timing &t = c->timing;
+	c->emit_pending = false;
 	t.sweep_ms = t.scan_ms = t.emit_ms = t.total_ms = 0.f;
 	(void)hipEventElapsedTime(&t.sweep_ms, c->ev[0], c->ev[1]);
 	(void)hipEventElapsedTime(&t.scan_ms, c->ev[1], c->ev[2]);
@@ -1152,8 +1164,15 @@ extern "C" int mc33hip_extract(mc33hip_ctx *c, float iso, const mc33hip_range *r
 	return MC33HIP_OK;
 }
 
-extern "C" int mc33hip_last_timing(const mc33hip_ctx *c, mc33hip_timing *t) {
+extern "C" int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t) {
 	if (!c || !t) return MC33HIP_EINVAL;
+	if (c->emit_pending) {  // a separate mc33hip_emit: wait for it and add its time
+		if (hipEventSynchronize(c->ev[3]) == hipSuccess) {
+			(void)hipEventElapsedTime(&c->timing.emit_ms, c->ev[2], c->ev[3]);
+			(void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[3]);
+		}
+		c->emit_pending = false;
+	}
 	*t = c->timing;
 	return MC33HIP_OK;
 }

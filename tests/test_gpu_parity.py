@@ -124,3 +124,26 @@ def test_repeatable_and_reusable_context(products):
         assert np.array_equal(a.T, b.T) and np.array_equal(a.V.view(np.uint32), b.V.view(np.uint32))
     lib.lib.free_MC33(M)
     lib.lib.free_memory_grd(G)
+
+
+def test_config2_cos1024_full_size(products, reflibs):
+    """BASELINE.json configs[2] at full size through the reference C API: 1024^3 float grid (4 GiB upload),
+    iso 0 - counts as published in SURVEY.md section 6, triangles identical to the reference run on this host,
+    positions / normals within 1e-5 (bit-identical in practice)."""
+    data, r0, d = fx.cos_field(1024)
+    got = products["f32"].isosurface(data, 0.0, r0, d)
+    assert (got.nV, got.nT) == (3903888, 7795976)
+    ref = reflibs["f32"].isosurface(data, 0.0, r0, d)
+    ev, en, vb, nb = assert_surface_parity(got, ref, 4.0, "cos1024")
+    print("cos1024 nV %d nT %d maxrel V %.2e N %.2e bit-exact V %s N %s" % (got.nV, got.nT, ev, en, vb, nb))
+    # size-independent properties: closed level set away from the box faces -> every interior edge is shared by
+    # exactly two triangles; ids are dense
+    assert got.T.max() == got.nV - 1 and np.all(got.color == got.color[0])
+
+
+def test_config4_u16_wide_rows(products, reflibs):
+    """Scaled BASELINE.json configs[4]: ushort grid with 2048-point rows (8 row segments, two blocks per row),
+    half-integer isovalues."""
+    data = fx.cos_field_u16(2048, 96, 40)
+    for k in (0, 3, 7):
+        check(products, reflibs, "u16", data, 15268.5 + 5000.0 * k, label="u16 2048-wide iso#%d" % k)
