@@ -225,10 +225,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		}
 		if (p > z_lo && !(a.debug & 2u)) {
 			const uint32_t z = p - 1;
-			// bit rows of the sample row above (y+1) come from the neighbour lane
-			uint64_t prev_n[4], cur_n[4];
-#pragma unroll
-			for (int k = 0; k < 4; k++) { prev_n[k] = row_above(prev[k]); cur_n[k] = row_above(cur[k]); }
+			// bit rows of the sample row above (y+1) come from the neighbour lane (one DPP move per dword;
+			// recomputed where needed rather than kept in registers)
 			const uint32_t prev_hn = row_above(prev_h), cur_hn = row_above(cur_h);
 			// cells cut by the surface: NOT (all 8 sign bits one) and NOT (all zero)  (MC:1860)
 			uint64_t act[4];
@@ -236,8 +234,9 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				uint64_t A[4], O[4];
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
-					A[k] = prev[k] & prev_n[k] & cur[k] & cur_n[k];
-					O[k] = prev[k] | prev_n[k] | cur[k] | cur_n[k];
+					const uint64_t pn = row_above(prev[k]), cn = row_above(cur[k]);
+					A[k] = prev[k] & pn & cur[k] & cn;
+					O[k] = prev[k] | pn | cur[k] | cn;
 				}
 				const uint64_t hA = prev_h & prev_hn & cur_h & cur_hn, hO = prev_h | prev_hn | cur_h | cur_hn;
 #pragma unroll
@@ -315,11 +314,11 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
 					// the four bit rows of this word, and the same shifted by one sample (x+1)
-					const uint64_t q0 = prev[k], q1 = cur[k], q0n = prev_n[k], q1n = cur_n[k];
+					const uint64_t q0 = prev[k], q1 = cur[k], q0n = row_above(prev[k]), q1n = row_above(cur[k]);
 					uint64_t n0, n1, n0n, n1n;  // bit 0 of the next word of each row
 					if (k < 3) {
 						n0 = prev[k < 3 ? k + 1 : 3] & 1ull; n1 = cur[k < 3 ? k + 1 : 3] & 1ull;
-						n0n = prev_n[k < 3 ? k + 1 : 3] & 1ull; n1n = cur_n[k < 3 ? k + 1 : 3] & 1ull;
+						n0n = row_above((uint32_t)prev[k < 3 ? k + 1 : 3]) & 1u; n1n = row_above((uint32_t)cur[k < 3 ? k + 1 : 3]) & 1u;
 					} else { n0 = prev_h; n1 = cur_h; n0n = prev_hn; n1n = cur_hn; }
 					const uint64_t q0s = (q0 >> 1) | (n0 << 63), q1s = (q1 >> 1) | (n1 << 63);
 					const uint64_t q0ns = (q0n >> 1) | (n0n << 63), q1ns = (q1n >> 1) | (n1n << 63);
@@ -366,12 +365,13 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 					for (int k = 0; k < 4; k++) {
 						const uint64_t a_k = readlane64(act[k], r);
 						if (!a_k) continue;
+						// r <= 62 here (row 63 of a tile is never a cell row), so row r+1 is lane r+1
 						const uint64_t q0 = readlane64(prev[k], r), q1 = readlane64(cur[k], r);
-						const uint64_t q0n = readlane64(prev_n[k], r), q1n = readlane64(cur_n[k], r);
+						const uint64_t q0n = readlane64(prev[k], r + 1), q1n = readlane64(cur[k], r + 1);
 						uint64_t n0, n1, n0n, n1n;
 						if (k < 3) {
 							n0 = readlane64(prev[k < 3 ? k + 1 : 3], r) & 1ull; n1 = readlane64(cur[k < 3 ? k + 1 : 3], r) & 1ull;
-							n0n = readlane64(prev_n[k < 3 ? k + 1 : 3], r) & 1ull; n1n = readlane64(cur_n[k < 3 ? k + 1 : 3], r) & 1ull;
+							n0n = readlane64(prev[k < 3 ? k + 1 : 3], r + 1) & 1ull; n1n = readlane64(cur[k < 3 ? k + 1 : 3], r + 1) & 1ull;
 						} else {
 							n0 = __builtin_amdgcn_readlane(prev_h, r); n1 = __builtin_amdgcn_readlane(cur_h, r);
 							n0n = __builtin_amdgcn_readlane(prev_hn, r); n1n = __builtin_amdgcn_readlane(cur_hn, r);
@@ -518,6 +518,23 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t x) {
 	return x;
 }
 
+// position in sweep order -> storage index, advanced incrementally (one division per thread, not per element)
+struct SweepWalk {
+	uint32_t sg, y, nseg, ny;
+	uint64_t zbase;  // z * nseg * ny
+	__device__ SweepWalk(const Params &P, uint64_t q) : nseg(P.nseg), ny(P.ny) {
+		const uint64_t zy = q / P.nseg;
+		sg = (uint32_t)(q % P.nseg);
+		const uint64_t z = zy / P.ny;
+		y = (uint32_t)(zy % P.ny);
+		zbase = z * P.nseg * P.ny;
+	}
+	__device__ uint64_t store() const { return zbase + (uint64_t)sg * ny + y; }
+	__device__ void next() {
+		if (++sg == nseg) { sg = 0; if (++y == ny) { y = 0; zbase += (uint64_t)nseg * ny; } }
+	}
+};
+
 // The records are stored [z][segment][y]; the scan runs over them in sweep order [z][y][segment]: a chunk of
 // SCAN_CHUNK consecutive sweep positions is the same set of records whatever the order inside it only
 // when it covers whole (y, all segments) groups - so the mapping is applied per element.
@@ -525,9 +542,12 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, ui
 	__shared__ uint64_t sv[4], st[4];
 	const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
 	uint64_t v = 0, t = 0;
+	// (the sum of a chunk does not depend on the order inside it: each thread takes 8 consecutive positions)
+	const uint64_t q0 = base + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+	SweepWalk walk(P, q0);
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
-		const uint64_t q = base + (uint64_t)k * 256 + threadIdx.x;
-		if (q < n) { const uint32_t c = seg_cnt[segment_sweep_to_store(P, q)]; v += c & 0xFFFFu; t += c >> 16; }
+		if (q0 + k < n) { const uint32_t c = seg_cnt[walk.store()]; v += c & 0xFFFFu; t += c >> 16; }
+		walk.next();
 	}
 	v = wave_sum(v); t = wave_sum(t);
 	if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; st[threadIdx.x >> 6] = t; }
@@ -565,9 +585,11 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uin
 	const uint64_t q0 = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
 	uint32_t cv[SCAN_PER_THREAD], ct[SCAN_PER_THREAD], v = 0, t = 0;
 	uint64_t st_idx[SCAN_PER_THREAD];
+	SweepWalk walk(P, q0);
 #pragma unroll
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
-		st_idx[k] = (q0 + k < n) ? segment_sweep_to_store(P, q0 + k) : 0;
+		st_idx[k] = (q0 + k < n) ? walk.store() : 0;
+		walk.next();
 		const uint32_t c = (q0 + k < n) ? seg_cnt[st_idx[k]] : 0u;
 		cv[k] = c & 0xFFFFu; ct[k] = c >> 16;
 		v += cv[k]; t += ct[k];
