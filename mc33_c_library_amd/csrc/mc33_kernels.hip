@@ -40,44 +40,42 @@ typedef float sample_t;
 // device-side bookkeeping
 // ---------------------------------------------------------------------------------------------------
 struct Counters {
-	uint32_t entry_cursor;  // work records requested by the sweep (may exceed the capacity)
+	uint32_t entry_cursor;  // work records requested (may exceed the capacity)
 	uint32_t slow_cursor;   // records left to k_slow_plan
 	uint32_t dirty_cursor;  // row segments whose offsets k_seg_fix has to rebuild
 	uint32_t mask_cursor;   // activity-mask records handed out
-	uint32_t pad_;
 	uint32_t emit_skipped;  // set by the emit kernels when they refused to run (capacity / overflow)
+	uint32_t pad_;
 	uint64_t totV, totT;    // totals over all classified slices (ghost included)
 	uint64_t ghostV, ghostT;
 };
 
+// One record per (wave tile, cell slice) of the sweep: the sign-bit rows of the two planes of the slice,
+// exactly as the wave held them (word k of sample row r in lane r).  k_sweep fills the records of slices
+// that hold at least one cut cell; k_cells turns them into work records.
+struct SliceHeader {
+	uint32_t flags;       // bit 0: record valid (the slice holds cut cells); bit 1: a sample of the two tile
+	                      // planes equals the isovalue (no fast path for this slice)
+	uint32_t prevh_lo, prevh_hi, curh_lo, curh_hi;  // halo-column bits of the 64 sample rows (ballots)
+	uint32_t pad_[3];
+};
+constexpr uint32_t SLICE_VALID = 1u, SLICE_HAS_ISO = 2u;
+
 struct SweepArgs {
 	GridView<sample_t> G;
 	Params P;
-	const uint4 *fast;       // per sign index: record words of a FAST cell (fast_record_table below)
 	uint32_t ze;             // classify cell slices [P.zs, ze)
 	uint32_t nXG, nYT, rz;   // tiles: 4 segments wide, 63 cell rows high, rz slices deep
-	uint32_t *seg_cnt;
-	SegDir *seg_dir;
-	uint64_t *seg_mask;
-	Entry *entries;
-	uint32_t *entry_seg;
-	uint32_t *slow_list, *dirty_list;
-	uint32_t *chunk_fill;    // records used in every ENTRY_CHUNK-sized piece of the record array
-	uint32_t entry_cap;      // multiple of ENTRY_CHUNK
-	uint32_t horiz_cost;     // cost of one row processed across the lanes, in vertical-loop iterations (tunable)
-	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only; the emit kernels are not launched):
-	                         // 1 stop after counting the active cells, 2 skip the whole cell stage
-	Counters *ctr;
+	SliceHeader *slice_hdr;  // [block][wave][slice of the tile]
+	uint4 *slice_bits;       // [slot][k][lane]: {prev[k].lo, prev[k].hi, cur[k].lo, cur[k].hi}
+	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz)
+	uint32_t *dbg_cells;     // MC33_HIP_VERBOSE: cut cells counted by the sweep itself (cross-check of k_cells)
+	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only; the later passes are not launched): 2 = stream only
 };
 
-// Work records are handed out to the waves in chunks: a wave sub-allocates from its open chunk without
-// touching global memory and takes a new chunk (one returning atomic) only when the cells of a tile
-// slice do not fit any more.  The emit kernels walk the chunks and their fill counts.
-constexpr uint32_t ENTRY_CHUNK = 1024;  // ~ the records of one wave tile: a chunk is spatially compact (one emit block walks it)
-constexpr uint32_t MASK_CHUNK = 64;
-constexpr uint32_t HORIZ_COST = 5;   // cost of one row processed across the lanes, in vertical-loop iterations  // activity-mask records are handed out the same way (<= 63 per tile slice)
+constexpr uint32_t HORIZ_COST = 5;   // cost of one row processed across the lanes, in vertical-loop iterations
 
-// fast[i] of mc33_cell.h unpacked into the record words the sweep writes for a FAST cell:
+// fast[i] of mc33_cell.h unpacked into the record words written for a FAST cell:
 // x = w0 without the cell's x, y = w2, z = w3, w = new vertices | triangles << 8   (x == FAST_NONE: not fast)
 static void fast_record_table(const uint32_t *fast, uint4 *out) {
 	for (uint32_t i = 0; i < 256; i++) {
@@ -89,34 +87,61 @@ static void fast_record_table(const uint32_t *fast, uint4 *out) {
 }
 
 __device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return (uint64_t)hi << 32 | lo; }
-__device__ __forceinline__ uint64_t shfl_down1(uint64_t x) {
-	return u64(__shfl_down((uint32_t)x, 1), __shfl_down((uint32_t)(x >> 32), 1));
+__device__ __forceinline__ uint32_t row_above(uint32_t v) {  // lane r <- lane r+1 (lane 63 <- 0): DPP wave_shl:1
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint64_t row_above(uint64_t v) { return u64(row_above((uint32_t)v), row_above((uint32_t)(v >> 32))); }
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
+	return u64(__builtin_amdgcn_readlane((uint32_t)v, l), __builtin_amdgcn_readlane((uint32_t)(v >> 32), l));
+}
+
+// cells of a tile slice cut by the surface: NOT (all 8 sign bits one) and NOT (all zero)  (MC:1860).
+// prev/cur: bit rows of planes z / z+1 (lane = sample row), *_h: halo-column bits.
+__device__ __forceinline__ void active_cells(const uint64_t (&prev)[4], const uint64_t (&cur)[4], uint32_t prev_h, uint32_t cur_h,
+                                             const uint64_t (&valid)[4], bool rowvalid, uint64_t (&act)[4]) {
+	const uint32_t prev_hn = row_above(prev_h), cur_hn = row_above(cur_h);
+	uint64_t A[4], O[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const uint64_t pn = row_above(prev[k]), cn = row_above(cur[k]);
+		A[k] = prev[k] & pn & cur[k] & cn;
+		O[k] = prev[k] | pn | cur[k] | cn;
+	}
+	const uint64_t hA = prev_h & prev_hn & cur_h & cur_hn, hO = prev_h | prev_hn | cur_h | cur_hn;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const uint64_t nA = (k < 3) ? (A[k < 3 ? k + 1 : 3] & 1ull) : hA;
+		const uint64_t nO = (k < 3) ? (O[k < 3 ? k + 1 : 3] & 1ull) : hO;
+		const uint64_t As = (A[k] >> 1) | (nA << 63), Os = (O[k] >> 1) | (nO << 63);
+		act[k] = rowvalid ? (~((A[k] & As) | ~(O[k] | Os)) & valid[k]) : 0ull;
+	}
+}
+
+// cells of the segment piece [xbase + 64k, +64) that exist.  Signed arithmetic on purpose: the unsigned form
+// "first >= nx ? 0 : min(64, nx - first)" is miscompiled by this toolchain (the guarded subtraction is
+// hoisted with its no-wrap flag and ConstraintElimination then takes nx >= xbase + 192 for a fact).
+__device__ __forceinline__ void valid_masks(uint32_t xbase, uint32_t nx, uint64_t (&valid)[4]) {
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const int64_t rem = (int64_t)nx - (int64_t)(xbase + 64u * k);
+		valid[k] = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------
 // k_sweep: one wave per tile column (256 samples in x, 64 sample rows, rz+1 planes), 4 waves per block
 // side by side in x so that a block reads whole 1024-sample (4 KiB) row pieces.
 //
-// Streaming part: every lane loads 4 samples of a row (x = xbase + 64k + lane: fully coalesced 256-byte
-// requests), v = iso - F, the sign bits of the 64 lanes are collected by ballot into one 64-bit word
-// per k, and the 4 words of sample row r are parked in lane r.  After a plane is in, lane r holds the
-// bits of row r for planes z and z+1 and gets row r+1 from its neighbour lane: the "all 8 corners on
-// the same side" test (MC:1860) of the 63 x 256 cells of the tile slice is ~100 logic ops per wave.
-// Cell part: only cells cut by the surface are touched.  FAST cells (see mc33_cell.h) are finished here
-// from their sign index alone; the others get a placeholder record for k_slow_plan.
+// Every lane loads 4 samples of a row (x = xbase + 64k + lane: fully coalesced 256-byte requests),
+// v = iso - F, the sign bits of the 64 lanes are collected by ballot into one 64-bit word per k, and the
+// 4 words of sample row r are parked in lane r.  After a plane is in, lane r holds the bits of row r for
+// planes z and z+1 and gets row r+1 from its neighbour lane: the "all 8 corners on the same side" test
+// (MC:1860) of the 63 x 256 cells of the tile slice is ~100 logic ops per wave.  Slices with cut cells
+// have their bit rows written out (4 KiB) for k_cells; nothing else is stored, nothing is allocated:
+// the wave only streams.  (Doing the per-cell work here made the kernel end on a long tail of a few
+// waves whose tiles hold most of the surface.)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t row_above(uint32_t v) {  // lane r <- lane r+1 (lane 63 <- 0): DPP wave_shl:1
-	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
-}
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
-	return u64(__builtin_amdgcn_readlane((uint32_t)v, l), __builtin_amdgcn_readlane((uint32_t)(v >> 32), l));
-}
-__device__ __forceinline__ uint64_t row_above(uint64_t v) { return u64(row_above((uint32_t)v), row_above((uint32_t)(v >> 32))); }
-
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
-	__shared__ uint4 s_fast[256];  // per sign index: record words of a FAST cell (see fast_record_table)
-	s_fast[threadIdx.x] = a.fast[threadIdx.x];
-	__syncthreads();  // the only block-level barrier (before any wave can leave)
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	uint32_t b = blockIdx.x;
 	const uint32_t xg = b % a.nXG;
@@ -125,10 +150,12 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	const uint32_t seg = xg * 4 + wv;
 	const Params &P = a.P;
 	if (seg >= P.nseg) return;
+	const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
 	const uint32_t nrows = min(64u, P.ny + 1 - y0);  // sample rows of this tile
 	const uint32_t z_lo = P.zs + zc * a.rz, z_hi = min(z_lo + a.rz, a.ze);
 	const float iso = P.iso;
+	const uint64_t slot0 = ((uint64_t)blockIdx.x * 4 + wv) * a.rz;
 
 	// per-lane byte offsets of its four samples inside a row (clamped into the row: bits of samples
 	// beyond the grid belong to cells that the valid masks remove)
@@ -137,14 +164,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 #pragma unroll
 	for (int k = 0; k < 4; k++) xo[k] = min(xbase + 64u * k + lane, P.nx) * (uint32_t)sizeof(sample_t);
 	uint64_t valid[4];
-#pragma unroll
-	for (int k = 0; k < 4; k++) {
-		const uint32_t first = xbase + 64u * k;
-		const uint32_t n = first >= P.nx ? 0u : min(64u, P.nx - first);
-		valid[k] = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
-	}
-	const uint32_t y = y0 + lane;
-	const bool rowvalid = lane < 63u && y < P.ny;
+	valid_masks(xbase, P.nx, valid);
+	const bool rowvalid = lane < 63u && y0 + lane < P.ny;
 	// halo column: lane r needs the first sample of the next segment in row r; it is fetched by the batch
 	// that holds row r (4 lanes per batch; the other lanes aim outside the descriptor: no memory access)
 	const uint32_t xh = min(lane, nrows - 1) * rowbytes + min(xbase + SEG_CELLS, P.nx) * (uint32_t)sizeof(sample_t);
@@ -156,13 +177,11 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	uint32_t cur_h = 0, prev_h = 0;
 	bool cur_z = false, prev_z = false;
 	float zmin = 1.0f;  // min |iso - F| over the lane's samples of the plane being assembled
-	uint32_t ch_pos = 0, ch_end = 0;  // free part [ch_pos, ch_end) of the wave's open chunk of work records
-	uint32_t mk_pos = 0, mk_end = 0;  // the same for activity-mask records
 
 	// The tile is consumed as a linear stream of batches of 4 sample rows (16 coalesced 256-byte loads per
 	// wave), plane after plane.  Two register buffers: the loads of batch t+1 are in flight while batch t
-	// is turned into bit rows, so HBM requests stay outstanding during the cell stage as well.
-	// Loads go through a buffer descriptor per plane (scalar base + 32-bit offsets, hardware range check).
+	// is turned into bit rows.  Loads go through a buffer descriptor per plane (scalar base + 32-bit
+	// offsets, hardware range check).
 	const uint32_t NB = (nrows + 3u) / 4u;
 	const uint32_t T = (z_hi - z_lo + 1u) * NB;
 	const uint32_t tile_bytes = nrows * rowbytes;
@@ -219,208 +238,34 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		{
 			const float dh = iso - halo;
 			cur_h = (uint32_t)(__float_as_int(dh) < 0);
-			zmin = fminf(zmin, fabsf(dh));
+			if (lane < nrows) zmin = fminf(zmin, fabsf(dh));  // lanes past the tile never loaded a halo sample
 			cur_z = __ballot(zmin == 0.0f) != 0ull;  // some sample of this plane of the tile equals the isovalue
 			zmin = 1.0f;
 		}
 		if (p > z_lo && !(a.debug & 2u)) {
-			const uint32_t z = p - 1;
-			// bit rows of the sample row above (y+1) come from the neighbour lane (one DPP move per dword;
-			// recomputed where needed rather than kept in registers)
-			const uint32_t prev_hn = row_above(prev_h), cur_hn = row_above(cur_h);
-			// cells cut by the surface: NOT (all 8 sign bits one) and NOT (all zero)  (MC:1860)
 			uint64_t act[4];
-			{
-				uint64_t A[4], O[4];
+			active_cells(prev, cur, prev_h, cur_h, valid, rowvalid, act);
+			if (a.dbg_cells) {
+				uint32_t n = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
+				for (int dlt = 32; dlt; dlt >>= 1) n += __shfl_xor(n, dlt);
+				if (lane == 0 && n) atomicAdd(a.dbg_cells, n);
+			}
+			if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull)) {  // wave-uniform: hand the slice to k_cells
+				const uint64_t slot = slot0 + (p - 1 - z_lo);
+				uint4 *bits = a.slice_bits + slot * 256u + lane;
 #pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const uint64_t pn = row_above(prev[k]), cn = row_above(cur[k]);
-					A[k] = prev[k] & pn & cur[k] & cn;
-					O[k] = prev[k] | pn | cur[k] | cn;
-				}
-				const uint64_t hA = prev_h & prev_hn & cur_h & cur_hn, hO = prev_h | prev_hn | cur_h | cur_hn;
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const uint64_t nA = (k < 3) ? (A[k < 3 ? k + 1 : 3] & 1ull) : hA;
-					const uint64_t nO = (k < 3) ? (O[k < 3 ? k + 1 : 3] & 1ull) : hO;
-					const uint64_t As = (A[k] >> 1) | (nA << 63), Os = (O[k] >> 1) | (nO << 63);
-					act[k] = rowvalid ? (~((A[k] & As) | ~(O[k] | Os)) & valid[k]) : 0ull;
+				for (int k = 0; k < 4; k++)
+					bits[64 * k] = uint4{(uint32_t)prev[k], (uint32_t)(prev[k] >> 32), (uint32_t)cur[k], (uint32_t)(cur[k] >> 32)};
+				const uint64_t bp = __ballot(prev_h != 0), bc = __ballot(cur_h != 0);
+				if (lane == 0) {
+					SliceHeader h;
+					h.flags = SLICE_VALID | ((prev_z || cur_z) ? SLICE_HAS_ISO : 0u);
+					h.prevh_lo = (uint32_t)bp; h.prevh_hi = (uint32_t)(bp >> 32);
+					h.curh_lo = (uint32_t)bc; h.curh_hi = (uint32_t)(bc >> 32);
+					h.pad_[0] = h.pad_[1] = h.pad_[2] = 0;
+					a.slice_hdr[slot] = h;
 				}
 			}
-			const uint32_t c0 = __popcll(act[0]), c1 = __popcll(act[1]), c2 = __popcll(act[2]), c3 = __popcll(act[3]);
-			const uint32_t cnt = c0 + c1 + c2 + c3;
-			const uint64_t sidx = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y;  // storage order [z][segment][y]
-			const uint64_t havem = __ballot(cnt != 0);
-			if (havem && !(a.debug & 1u)) {  // wave-uniform: some row of the tile slice has active cells
-				// exclusive prefix of the per-row counts over the lanes
-				uint32_t incl = cnt;
-#pragma unroll
-				for (int dlt = 1; dlt < 64; dlt <<= 1) {
-					const uint32_t t = __shfl_up(incl, dlt);
-					if ((int)lane >= dlt) incl += t;
-				}
-				const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-				if (ch_pos + total > ch_end) {
-					// close the open chunk, take ceil(total / chunk) new ones (the last of them stays open)
-					if (ch_end && lane == 0 && ch_end <= a.entry_cap) a.chunk_fill[ch_end / ENTRY_CHUNK - 1] = ENTRY_CHUNK - (ch_end - ch_pos);
-					const uint32_t n = (total + ENTRY_CHUNK - 1) / ENTRY_CHUNK;
-					uint32_t got = 0;
-					if (lane == 0) got = atomicAdd(&a.ctr->entry_cursor, n * ENTRY_CHUNK);
-					got = __builtin_amdgcn_readfirstlane(got);
-					for (uint32_t q = lane; q + 1 < n; q += 64)
-						if (got + (q + 1) * ENTRY_CHUNK <= a.entry_cap) a.chunk_fill[got / ENTRY_CHUNK + q] = ENTRY_CHUNK;
-					ch_pos = got;
-					ch_end = got + n * ENTRY_CHUNK;
-				}
-				const uint32_t first = ch_pos + incl - cnt;
-				ch_pos += total;
-				// activity-mask records: one per row with active cells
-				const uint32_t nm = (uint32_t)__popcll(havem);
-				if (mk_pos + nm > mk_end) {
-					uint32_t got = 0;
-					if (lane == 0) got = atomicAdd(&a.ctr->mask_cursor, MASK_CHUNK);
-					mk_pos = __builtin_amdgcn_readfirstlane(got);
-					mk_end = mk_pos + MASK_CHUNK;
-				}
-				const uint32_t maskidx = mk_pos + (uint32_t)__popcll(havem & ((1ull << lane) - 1ull));
-				mk_pos += nm;
-				if (cnt && maskidx < a.entry_cap) {
-					uint64_t *mr = a.seg_mask + 4ull * maskidx;
-					mr[0] = act[0]; mr[1] = act[1]; mr[2] = act[2]; mr[3] = act[3];
-				}
-				uint32_t idx = first, nv_run = 0, nt_run = 0;
-				bool dirty = false;
-				// rows whose cells cannot take the fast path: on the y = 0 / z = 0 faces (extra owned edges),
-				// or in a tile plane pair that holds a sample equal to the isovalue
-				const bool planeslow = z == 0 || prev_z || cur_z;  // wave-uniform
-				const bool rowslow = y == 0 || planeslow;
-				// Two ways through the active cells of the tile slice.  VERTICAL: every lane walks the cells of
-				// its own row (good when rows hold few cells: 63 rows advance together).  HORIZONTAL: one row
-				// at a time, lane L takes cell x = 64k+L (good for rows where the surface runs along x: a run of
-				// 50 cells costs 1-2 passes instead of 50 iterations with one lane busy).  Rows with more than
-				// The split threshold is chosen per tile slice from a cost model in units of one vertical
-				// iteration: vertical = min(largest row, T) iterations, horizontal = ~HORIZ_COST per row above T.
-				uint32_t maxcnt = cnt;
-#pragma unroll
-				for (int dlt = 32; dlt; dlt >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor(maxcnt, dlt));
-				uint32_t long_T = 256u, best = maxcnt;
-#pragma unroll
-				for (uint32_t T2 = 8; T2 <= 64; T2 <<= 1) {
-					const uint32_t c2 = T2 + a.horiz_cost * (uint32_t)__popcll(__ballot(cnt > T2));
-					if (maxcnt > T2 && c2 < best) { best = c2; long_T = T2; }
-				}
-				const bool longrow = cnt > long_T;
-				uint64_t longrows = __ballot(longrow);
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					// the four bit rows of this word, and the same shifted by one sample (x+1)
-					const uint64_t q0 = prev[k], q1 = cur[k], q0n = row_above(prev[k]), q1n = row_above(cur[k]);
-					uint64_t n0, n1, n0n, n1n;  // bit 0 of the next word of each row
-					if (k < 3) {
-						n0 = prev[k < 3 ? k + 1 : 3] & 1ull; n1 = cur[k < 3 ? k + 1 : 3] & 1ull;
-						n0n = row_above((uint32_t)prev[k < 3 ? k + 1 : 3]) & 1u; n1n = row_above((uint32_t)cur[k < 3 ? k + 1 : 3]) & 1u;
-					} else { n0 = prev_h; n1 = cur_h; n0n = prev_hn; n1n = cur_hn; }
-					const uint64_t q0s = (q0 >> 1) | (n0 << 63), q1s = (q1 >> 1) | (n1 << 63);
-					const uint64_t q0ns = (q0n >> 1) | (n0n << 63), q1ns = (q1n >> 1) | (n1n << 63);
-					uint64_t todo = longrow ? 0ull : act[k];
-					for (;;) {
-						const bool has = todo != 0ull;
-						if (!__any(has)) break;
-						if (has) {
-							const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
-							todo &= todo - 1;
-							const uint32_t xl = 64u * k + j;
-							// sign index, bit 7-c = corner c (MC:1846-1859): corners 0..3 at x, 4..7 at x+1
-							const uint32_t i = (uint32_t)((q0 >> j) & 1) << 7 | (uint32_t)((q0n >> j) & 1) << 6 | (uint32_t)((q1n >> j) & 1) << 5 |
-							                   (uint32_t)((q1 >> j) & 1) << 4 | (uint32_t)((q0s >> j) & 1) << 3 | (uint32_t)((q0ns >> j) & 1) << 2 |
-							                   (uint32_t)((q1ns >> j) & 1) << 1 | (uint32_t)((q1s >> j) & 1);
-							const uint4 f = s_fast[i];
-							Entry e;
-							if (!rowslow && f.x != FAST_NONE && (xbase + xl) != 0) {
-								e.w0 = f.x | xl; e.w1 = nv_run | nt_run << 16; e.w2 = f.y; e.w3 = f.z;
-								nv_run += f.w & 0xFFu;
-								nt_run += f.w >> 8;
-							} else {
-								e = make_pending_entry(xl, i);
-								dirty = true;
-								if (idx < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = idx;
-							}
-							if (idx < a.entry_cap) {
-								a.entries[idx] = e;
-								a.entry_seg[idx] = (uint32_t)sidx;
-							}
-							idx++;
-						}
-					}
-				}
-				while (longrows) {  // wave-uniform loop over the long rows
-					const uint32_t r = (uint32_t)__ffsll((long long)longrows) - 1u;
-					longrows &= longrows - 1;
-					const uint32_t first_r = __builtin_amdgcn_readlane(first, r);
-					const bool slow_r = (y0 + r) == 0 || planeslow;
-					const uint64_t sidx_r = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + (y0 + r);
-					uint32_t run = 0, pre = 0;  // new vertices | triangles << 16 so far in the row; records so far
-					bool dirty_r = false;
-#pragma unroll
-					for (int k = 0; k < 4; k++) {
-						const uint64_t a_k = readlane64(act[k], r);
-						if (!a_k) continue;
-						// r <= 62 here (row 63 of a tile is never a cell row), so row r+1 is lane r+1
-						const uint64_t q0 = readlane64(prev[k], r), q1 = readlane64(cur[k], r);
-						const uint64_t q0n = readlane64(prev[k], r + 1), q1n = readlane64(cur[k], r + 1);
-						uint64_t n0, n1, n0n, n1n;
-						if (k < 3) {
-							n0 = readlane64(prev[k < 3 ? k + 1 : 3], r) & 1ull; n1 = readlane64(cur[k < 3 ? k + 1 : 3], r) & 1ull;
-							n0n = readlane64(prev[k < 3 ? k + 1 : 3], r + 1) & 1ull; n1n = readlane64(cur[k < 3 ? k + 1 : 3], r + 1) & 1ull;
-						} else {
-							n0 = __builtin_amdgcn_readlane(prev_h, r); n1 = __builtin_amdgcn_readlane(cur_h, r);
-							n0n = __builtin_amdgcn_readlane(prev_hn, r); n1n = __builtin_amdgcn_readlane(cur_hn, r);
-						}
-						const uint64_t q0s = (q0 >> 1) | (n0 << 63), q1s = (q1 >> 1) | (n1 << 63);
-						const uint64_t q0ns = (q0n >> 1) | (n0n << 63), q1ns = (q1n >> 1) | (n1n << 63);
-						const bool on = (a_k >> lane) & 1ull;
-						const uint32_t xl = 64u * k + lane;
-						const uint32_t i = (uint32_t)((q0 >> lane) & 1) << 7 | (uint32_t)((q0n >> lane) & 1) << 6 | (uint32_t)((q1n >> lane) & 1) << 5 |
-						                   (uint32_t)((q1 >> lane) & 1) << 4 | (uint32_t)((q0s >> lane) & 1) << 3 | (uint32_t)((q0ns >> lane) & 1) << 2 |
-						                   (uint32_t)((q1ns >> lane) & 1) << 1 | (uint32_t)((q1s >> lane) & 1);
-						const uint4 f = s_fast[i];
-						const bool fastcell = on && !slow_r && f.x != FAST_NONE && (xbase + xl) != 0;
-						const uint32_t val = fastcell ? ((f.w & 0xFFu) | (f.w >> 8) << 16) : 0u;
-						uint32_t inc = val;  // inclusive scan over the lanes (cells in x order)
-#pragma unroll
-						for (int dlt = 1; dlt < 64; dlt <<= 1) {
-							const uint32_t t = __shfl_up(inc, dlt);
-							if ((int)lane >= dlt) inc += t;
-						}
-						const uint32_t off = run + inc - val;
-						const uint32_t ri = first_r + pre + (uint32_t)__popcll(a_k & ((1ull << lane) - 1ull));
-						if (on) {
-							Entry e;
-							if (fastcell) { e.w0 = f.x | xl; e.w1 = off; e.w2 = f.y; e.w3 = f.z; }
-							else {
-								e = make_pending_entry(xl, i);
-								if (ri < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = ri;
-							}
-							if (ri < a.entry_cap) {
-								a.entries[ri] = e;
-								a.entry_seg[ri] = (uint32_t)sidx_r;
-							}
-						}
-						dirty_r = dirty_r || (__ballot(on && !fastcell) != 0ull);
-						run += __builtin_amdgcn_readlane(inc, 63);
-						pre += (uint32_t)__popcll(a_k);
-					}
-					if (lane == r) { nv_run = run & 0xFFFFu; nt_run = run >> 16; dirty = dirty_r; }
-				}
-				if (rowvalid) {
-					a.seg_cnt[sidx] = dirty ? 0u : seg_pack(nv_run, nt_run);
-					if (cnt) {
-						a.seg_dir[sidx] = SegDir{first, cnt | (dirty ? SEG_DIRTY : 0u), maskidx, pack_prefix(c0, c1, c2)};
-						if (dirty && first < a.entry_cap) a.dirty_list[atomicAdd(&a.ctr->dirty_cursor, 1u)] = (uint32_t)sidx;
-					}
-				}
-			} else if (rowvalid)
-				a.seg_cnt[sidx] = 0u;
 		}
 #pragma unroll
 		for (int k = 0; k < 4; k++) prev[k] = cur[k];
@@ -440,10 +285,245 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		issue(dA, hA, ip, ib); MC33_ADV_ISSUE();
 		if (t + 1 < T) { process(dB, hB, pp, pb); MC33_ADV(pp, pb); }
 	}
-	if (ch_end && lane == 0 && ch_end <= a.entry_cap) a.chunk_fill[ch_end / ENTRY_CHUNK - 1] = ENTRY_CHUNK - (ch_end - ch_pos);
+	if (a.trace && lane == 0) {
+		unsigned long long *tr = a.trace + 2ull * (blockIdx.x * 4ull + wv);
+		tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
+	}
 #undef MC33_ADV_ISSUE
 #undef MC33_ADV
 #undef MC33_LOAD
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_cells: one wave per slice record of the sweep (4 consecutive slices of one tile per block).  Finds the
+// cut cells again from the bit rows and writes, per row segment, the directory record, the activity mask,
+// the packed counts, and one work record per cell.  FAST cells (see mc33_cell.h) are finished from their
+// sign index via an LDS table; the others get a placeholder for k_slow_plan.
+//
+// Two ways through the active cells of the slice.  VERTICAL: every lane walks the cells of its own row
+// (good when rows hold few cells: 63 rows advance together).  HORIZONTAL: one row at a time, lane L takes
+// cell x = 64k+L (good for rows where the surface runs along x: a run of 50 cells costs 1-2 passes instead
+// of 50 iterations with one lane busy).  The split threshold is chosen per slice from a cost model.
+// ---------------------------------------------------------------------------------------------------
+struct CellsArgs {
+	Params P;
+	const uint4 *fast;       // per sign index: record words of a FAST cell (fast_record_table)
+	uint32_t ze, nXG, nYT, rz;
+	uint64_t nslots;
+	const SliceHeader *slice_hdr;
+	const uint4 *slice_bits;
+	uint32_t *seg_cnt;
+	SegDir *seg_dir;
+	uint64_t *seg_mask;
+	Entry *entries;
+	uint32_t *entry_seg;
+	uint32_t *slow_list, *dirty_list;
+	uint32_t entry_cap;
+	uint32_t horiz_cost;
+	Counters *ctr;
+};
+
+__global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
+	__shared__ uint4 s_fast[256];
+	__shared__ uint32_t s_tot[4], s_nm[4], s_base[2];
+	s_fast[threadIdx.x] = a.fast[threadIdx.x];
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	const Params &P = a.P;
+	const uint64_t slot = (uint64_t)blockIdx.x * 4 + wv;
+	// slot -> (sweep block, wave, slice of the tile) -> tile coordinates, as k_sweep numbered them
+	const uint64_t wl = slot / a.rz;
+	const uint32_t si = (uint32_t)(slot % a.rz);
+	uint32_t b = (uint32_t)(wl / 4);
+	const uint32_t w = (uint32_t)(wl % 4);
+	const uint32_t xg = b % a.nXG;
+	b /= a.nXG;
+	const uint32_t yt = b % a.nYT, zc = b / a.nYT;
+	const uint32_t seg = xg * 4 + w, xbase = seg * SEG_CELLS, y0 = yt * 63u;
+	const uint32_t z = P.zs + zc * a.rz + si;
+	const uint32_t y = y0 + lane;
+	bool live = slot < a.nslots && seg < P.nseg && z < a.ze;
+	SliceHeader h;
+	h.flags = 0;
+	if (live) h = a.slice_hdr[slot];
+	live = live && (h.flags & SLICE_VALID);
+	const bool rowvalid = live && lane < 63u && y < P.ny;
+
+	uint64_t prev[4] = {0, 0, 0, 0}, cur[4] = {0, 0, 0, 0}, act[4] = {0, 0, 0, 0};
+	uint32_t prev_h = 0, cur_h = 0, cnt = 0, c0 = 0, c1 = 0, c2 = 0, incl = 0, total = 0, nm = 0;
+	uint64_t havem = 0;
+	if (live) {  // wave-uniform
+		const uint4 *bits = a.slice_bits + slot * 256u + lane;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const uint4 q = bits[64 * k];
+			prev[k] = u64(q.x, q.y); cur[k] = u64(q.z, q.w);
+		}
+		prev_h = (uint32_t)((u64(h.prevh_lo, h.prevh_hi) >> lane) & 1ull);
+		cur_h = (uint32_t)((u64(h.curh_lo, h.curh_hi) >> lane) & 1ull);
+		uint64_t valid[4];
+		valid_masks(xbase, P.nx, valid);
+		active_cells(prev, cur, prev_h, cur_h, valid, rowvalid, act);
+		c0 = __popcll(act[0]); c1 = __popcll(act[1]); c2 = __popcll(act[2]);
+		cnt = c0 + c1 + c2 + __popcll(act[3]);
+		havem = __ballot(cnt != 0);
+		incl = cnt;  // inclusive prefix of the per-row counts over the lanes
+#pragma unroll
+		for (int dlt = 1; dlt < 64; dlt <<= 1) {
+			const uint32_t t = __shfl_up(incl, dlt);
+			if ((int)lane >= dlt) incl += t;
+		}
+		total = __builtin_amdgcn_readlane(incl, 63);
+		nm = (uint32_t)__popcll(havem);
+	}
+	// the four slices of the block get consecutive work records / mask records (they are consecutive
+	// slices of one tile: the emit kernels find neighbouring cells in neighbouring records)
+	if (lane == 0) { s_tot[wv] = total; s_nm[wv] = nm; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const uint32_t te = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3], tm = s_nm[0] + s_nm[1] + s_nm[2] + s_nm[3];
+		s_base[0] = te ? atomicAdd(&a.ctr->entry_cursor, te) : 0u;
+		s_base[1] = tm ? atomicAdd(&a.ctr->mask_cursor, tm) : 0u;
+	}
+	__syncthreads();
+	if (!total) return;  // wave-uniform (no barrier below)
+	uint32_t ebase = s_base[0], mbase = s_base[1];
+	for (uint32_t q = 0; q < wv; q++) { ebase += s_tot[q]; mbase += s_nm[q]; }
+
+	const uint64_t sidx = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y;  // storage order [z][segment][y]
+	const uint32_t first = ebase + incl - cnt;
+	const uint32_t maskidx = mbase + (uint32_t)__popcll(havem & ((1ull << lane) - 1ull));
+	if (cnt && maskidx < a.entry_cap) {
+		uint4 *mr = (uint4 *)(a.seg_mask + 4ull * maskidx);
+		mr[0] = uint4{(uint32_t)act[0], (uint32_t)(act[0] >> 32), (uint32_t)act[1], (uint32_t)(act[1] >> 32)};
+		mr[1] = uint4{(uint32_t)act[2], (uint32_t)(act[2] >> 32), (uint32_t)act[3], (uint32_t)(act[3] >> 32)};
+	}
+	uint32_t idx = first, nv_run = 0, nt_run = 0;
+	bool dirty = false;
+	// rows whose cells cannot take the fast path: on the y = 0 / z = 0 faces (extra owned edges), or in a
+	// tile plane pair that holds a sample equal to the isovalue
+	const bool planeslow = z == 0 || (h.flags & SLICE_HAS_ISO);  // wave-uniform
+	const bool rowslow = y == 0 || planeslow;
+	const uint32_t prev_hn = row_above(prev_h), cur_hn = row_above(cur_h);
+	// cost model in units of one vertical iteration: vertical = min(largest row, T) iterations,
+	// horizontal = ~horiz_cost per row above T
+	uint32_t maxcnt = cnt;
+#pragma unroll
+	for (int dlt = 32; dlt; dlt >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor(maxcnt, dlt));
+	uint32_t long_T = 256u, best = maxcnt;
+#pragma unroll
+	for (uint32_t T2 = 8; T2 <= 64; T2 <<= 1) {
+		const uint32_t c2b = T2 + a.horiz_cost * (uint32_t)__popcll(__ballot(cnt > T2));
+		if (maxcnt > T2 && c2b < best) { best = c2b; long_T = T2; }
+	}
+	const bool longrow = cnt > long_T;
+	uint64_t longrows = __ballot(longrow);
+
+#pragma unroll
+	for (int k = 0; k < 4; k++) {  // VERTICAL
+		// the four bit rows of this word, and the same shifted by one sample (x+1)
+		const uint64_t q0 = prev[k], q1 = cur[k], q0n = row_above(prev[k]), q1n = row_above(cur[k]);
+		uint64_t n0, n1, n0n, n1n;  // bit 0 of the next word of each row
+		if (k < 3) {
+			n0 = prev[k < 3 ? k + 1 : 3] & 1ull; n1 = cur[k < 3 ? k + 1 : 3] & 1ull;
+			n0n = row_above((uint32_t)prev[k < 3 ? k + 1 : 3]) & 1u; n1n = row_above((uint32_t)cur[k < 3 ? k + 1 : 3]) & 1u;
+		} else { n0 = prev_h; n1 = cur_h; n0n = prev_hn; n1n = cur_hn; }
+		const uint64_t q0s = (q0 >> 1) | (n0 << 63), q1s = (q1 >> 1) | (n1 << 63);
+		const uint64_t q0ns = (q0n >> 1) | (n0n << 63), q1ns = (q1n >> 1) | (n1n << 63);
+		uint64_t todo = longrow ? 0ull : act[k];
+		for (;;) {
+			const bool has = todo != 0ull;
+			if (!__any(has)) break;
+			if (has) {
+				const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
+				todo &= todo - 1;
+				const uint32_t xl = 64u * k + j;
+				// sign index, bit 7-c = corner c (MC:1846-1859): corners 0..3 at x, 4..7 at x+1
+				const uint32_t i = (uint32_t)((q0 >> j) & 1) << 7 | (uint32_t)((q0n >> j) & 1) << 6 | (uint32_t)((q1n >> j) & 1) << 5 |
+				                   (uint32_t)((q1 >> j) & 1) << 4 | (uint32_t)((q0s >> j) & 1) << 3 | (uint32_t)((q0ns >> j) & 1) << 2 |
+				                   (uint32_t)((q1ns >> j) & 1) << 1 | (uint32_t)((q1s >> j) & 1);
+				const uint4 f = s_fast[i];
+				Entry e;
+				if (!rowslow && f.x != FAST_NONE && (xbase + xl) != 0) {
+					e.w0 = f.x | xl; e.w1 = nv_run | nt_run << 16; e.w2 = f.y; e.w3 = f.z;
+					nv_run += f.w & 0xFFu;
+					nt_run += f.w >> 8;
+				} else {
+					e = make_pending_entry(xl, i);
+					dirty = true;
+					if (idx < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = idx;
+				}
+				if (idx < a.entry_cap) {
+					a.entries[idx] = e;
+					a.entry_seg[idx] = (uint32_t)sidx;
+				}
+				idx++;
+			}
+		}
+	}
+	while (longrows) {  // HORIZONTAL: wave-uniform loop over the long rows
+		const uint32_t r = (uint32_t)__ffsll((long long)longrows) - 1u;
+		longrows &= longrows - 1;
+		const uint32_t first_r = __builtin_amdgcn_readlane(first, r);
+		const bool slow_r = (y0 + r) == 0 || planeslow;
+		const uint64_t sidx_r = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + (y0 + r);
+		uint32_t run = 0, pre = 0;  // new vertices | triangles << 16 so far in the row; records so far
+		bool dirty_r = false;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const uint64_t a_k = readlane64(act[k], r);
+			if (!a_k) continue;
+			// r <= 62 here (row 63 of a tile is never a cell row), so row r+1 is lane r+1
+			const uint64_t q0 = readlane64(prev[k], r), q1 = readlane64(cur[k], r);
+			const uint64_t q0n = readlane64(prev[k], r + 1), q1n = readlane64(cur[k], r + 1);
+			uint64_t n0, n1, n0n, n1n;
+			if (k < 3) {
+				n0 = readlane64(prev[k < 3 ? k + 1 : 3], r) & 1ull; n1 = readlane64(cur[k < 3 ? k + 1 : 3], r) & 1ull;
+				n0n = readlane64(prev[k < 3 ? k + 1 : 3], r + 1) & 1ull; n1n = readlane64(cur[k < 3 ? k + 1 : 3], r + 1) & 1ull;
+			} else {
+				n0 = __builtin_amdgcn_readlane(prev_h, r); n1 = __builtin_amdgcn_readlane(cur_h, r);
+				n0n = __builtin_amdgcn_readlane(prev_hn, r); n1n = __builtin_amdgcn_readlane(cur_hn, r);
+			}
+			const uint64_t q0s = (q0 >> 1) | (n0 << 63), q1s = (q1 >> 1) | (n1 << 63);
+			const uint64_t q0ns = (q0n >> 1) | (n0n << 63), q1ns = (q1n >> 1) | (n1n << 63);
+			const bool on = (a_k >> lane) & 1ull;
+			const uint32_t xl = 64u * k + lane;
+			const uint32_t i = (uint32_t)((q0 >> lane) & 1) << 7 | (uint32_t)((q0n >> lane) & 1) << 6 | (uint32_t)((q1n >> lane) & 1) << 5 |
+			                   (uint32_t)((q1 >> lane) & 1) << 4 | (uint32_t)((q0s >> lane) & 1) << 3 | (uint32_t)((q0ns >> lane) & 1) << 2 |
+			                   (uint32_t)((q1ns >> lane) & 1) << 1 | (uint32_t)((q1s >> lane) & 1);
+			const uint4 f = s_fast[i];
+			const bool fastcell = on && !slow_r && f.x != FAST_NONE && (xbase + xl) != 0;
+			const uint32_t val = fastcell ? ((f.w & 0xFFu) | (f.w >> 8) << 16) : 0u;
+			uint32_t inc = val;  // inclusive scan over the lanes (cells in x order)
+#pragma unroll
+			for (int dlt = 1; dlt < 64; dlt <<= 1) {
+				const uint32_t t = __shfl_up(inc, dlt);
+				if ((int)lane >= dlt) inc += t;
+			}
+			const uint32_t off = run + inc - val;
+			const uint32_t ri = first_r + pre + (uint32_t)__popcll(a_k & ((1ull << lane) - 1ull));
+			if (on) {
+				Entry e;
+				if (fastcell) { e.w0 = f.x | xl; e.w1 = off; e.w2 = f.y; e.w3 = f.z; }
+				else {
+					e = make_pending_entry(xl, i);
+					if (ri < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = ri;
+				}
+				if (ri < a.entry_cap) {
+					a.entries[ri] = e;
+					a.entry_seg[ri] = (uint32_t)sidx_r;
+				}
+			}
+			dirty_r = dirty_r || (__ballot(on && !fastcell) != 0ull);
+			run += __builtin_amdgcn_readlane(inc, 63);
+			pre += (uint32_t)__popcll(a_k);
+		}
+		if (lane == r) { nv_run = run & 0xFFFFu; nt_run = run >> 16; dirty = dirty_r; }
+	}
+	if (rowvalid && cnt) {
+		a.seg_cnt[sidx] = dirty ? 0u : seg_pack(nv_run, nt_run);
+		a.seg_dir[sidx] = SegDir{first, cnt | (dirty ? SEG_DIRTY : 0u), maskidx, pack_prefix(c0, c1, c2)};
+		if (dirty && first < a.entry_cap) a.dirty_list[atomicAdd(&a.ctr->dirty_cursor, 1u)] = (uint32_t)sidx;
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -623,7 +703,6 @@ struct EmitArgs {
 	EmitCtx<sample_t> c;
 	Counters *ctr;
 	const uint32_t *slow_list;
-	const uint32_t *chunk_fill;
 	uint32_t entry_cap;
 	uint64_t capV, capT;
 	uint64_t ghost_segs;  // row segments of the ghost slice (0 without ghost)
@@ -649,15 +728,11 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
-	const uint32_t nchunks = ctr.entry_cursor / ENTRY_CHUNK;
-	for (uint32_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-		const uint32_t fill = a.chunk_fill[ch];
-		for (uint32_t q = threadIdx.x; q < fill; q += 256u) {
-			const uint32_t e = ch * ENTRY_CHUNK + q;
-			const Entry en = c.entries[e];
-			if (en.w3 & ENTRY_SLOW) continue;
-			emit_fast_vertices(c, en, c.entry_seg[e]);
-		}
+	const uint32_t n = ctr.entry_cursor;
+	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+		const Entry en = c.entries[e];
+		if (en.w3 & ENTRY_SLOW) continue;
+		emit_fast_vertices(c, en, c.entry_seg[e]);
 	}
 }
 
@@ -668,15 +743,11 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
-	const uint32_t nchunks = ctr.entry_cursor / ENTRY_CHUNK;
-	for (uint32_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-		const uint32_t fill = a.chunk_fill[ch];
-		for (uint32_t q = threadIdx.x; q < fill; q += 256u) {
-			const uint32_t e = ch * ENTRY_CHUNK + q;
-			const Entry en = c.entries[e];
-			if (en.w3 & ENTRY_SLOW) continue;
-			emit_fast_triangles(c, en, c.entry_seg[e], e, ids);
-		}
+	const uint32_t n = ctr.entry_cursor;
+	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+		const Entry en = c.entries[e];
+		if (en.w3 & ENTRY_SLOW) continue;
+		emit_fast_triangles(c, en, c.entry_seg[e], e, ids);
 	}
 }
 
@@ -732,13 +803,18 @@ struct mc33hip_ctx {
 	uint64_t *bsV, *bsT;
 	uint64_t bs_cap;
 	Entry *entries;
-	uint32_t *entry_seg, *slow_list, *dirty_list, *chunk_fill;
+	uint32_t *entry_seg, *slow_list, *dirty_list;
 	uint64_t entry_cap;
+	SliceHeader *slice_hdr;   // one record per (wave tile, cell slice) of the sweep
+	uint4 *slice_bits;
+	uint64_t slice_cap;
 	Counters *d_ctr, *h_ctr;
 	hipEvent_t ev[4];
 	hipStream_t aux, aux2;    // the vertex pass and the slow-record pass run beside the fast triangle pass
 	hipEvent_t ev_fork, ev_join, ev_join2;
 	bool emit_pending;        // an emit was enqueued after the last timing read
+	unsigned long long *trace;  // developer tracing (MC33_HIP_TRACE_FILE)
+	uint64_t trace_waves;
 	// state of the last count
 	bool counted;
 	Params P;
@@ -817,7 +893,8 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base); (void)hipFree(c->seg_mask);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
 	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
-	(void)hipFree(c->chunk_fill);
+	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits);
+	(void)hipFree(c->trace);
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
@@ -946,17 +1023,15 @@ static uint32_t env_u32(const char *name, uint32_t dflt) {
 
 static int alloc_entries(mc33hip_ctx *c, uint64_t cap) {
 	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
-	(void)hipFree(c->chunk_fill); (void)hipFree(c->seg_mask);
-	c->entries = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr; c->chunk_fill = nullptr;
+	(void)hipFree(c->seg_mask);
+	c->entries = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr;
 	c->seg_mask = nullptr;
 	c->entry_cap = 0;
 	if (cap > 0xFFFFFF00ull) cap = 0xFFFFFF00ull;
-	cap = (cap + ENTRY_CHUNK - 1) / ENTRY_CHUNK * ENTRY_CHUNK;
 	HIP_TRY(hipMalloc(&c->entries, cap * sizeof(Entry)));
 	HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
 	HIP_TRY(hipMalloc(&c->slow_list, cap * 4));
 	HIP_TRY(hipMalloc(&c->dirty_list, cap * 4));
-	HIP_TRY(hipMalloc(&c->chunk_fill, cap / ENTRY_CHUNK * 4));
 	HIP_TRY(hipMalloc(&c->seg_mask, cap * 32));  // one 256-bit activity mask per row segment with records
 	c->entry_cap = cap;
 	return 0;
@@ -984,7 +1059,7 @@ static int ensure_workspaces(mc33hip_ctx *c) {
 	if (!c->entries) {
 		// first guess: one cell in 32 is cut (BASELINE fields: 0.4-6 % of the cells); grown on demand
 		const uint64_t cells = (uint64_t)c->P.nx * c->P.ny * (c->range.z_end - c->P.zs);
-		return alloc_entries(c, cells / 24 + 4u * 65536);
+		return alloc_entries(c, cells / 32 + 65536);
 	}
 	return 0;
 }
@@ -995,34 +1070,57 @@ static int grow_entries(mc33hip_ctx *c, uint64_t need) {
 	return alloc_entries(c, cap);
 }
 
-// enqueue sweep + slow-cell planning + scans on the context's stream (no synchronisation)
+// enqueue sweep + cell records + slow-cell planning + scans on the context's stream (no synchronisation)
 static int enqueue_count(mc33hip_ctx *c) {
 	const Params &P = c->P;
 	hipStream_t st = c->stream;
-	HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
-	HIP_TRY(hipMemsetAsync(c->chunk_fill, 0, c->entry_cap / ENTRY_CHUNK * 4, st));
 	SweepArgs a;
 	a.G.p = c->d_grid; a.G.pitch = (uint32_t)c->pitch; a.G.z0 = c->desc.plane0; a.G.slice = c->slice;
 	a.P = P;
-	a.fast = c->d_fast;
 	a.ze = c->range.z_end;
 	a.nXG = (P.nseg + 3) / 4;
 	a.nYT = (P.ny + 62) / 63;
 	a.rz = env_u32("MC33_HIP_RZ", 16);
 	const uint32_t nZC = (a.ze - P.zs + a.rz - 1) / a.rz;
-	a.seg_cnt = c->seg_cnt; a.seg_dir = c->seg_dir; a.seg_mask = c->seg_mask;
-	a.entries = c->entries; a.entry_seg = c->entry_seg; a.slow_list = c->slow_list; a.dirty_list = c->dirty_list;
-	a.chunk_fill = c->chunk_fill;
-	a.entry_cap = (uint32_t)c->entry_cap;
-	a.debug = env_u32("MC33_HIP_DEBUG", 0);
-	a.horiz_cost = env_u32("MC33_HIP_HCOST", HORIZ_COST);
-	a.ctr = c->d_ctr;
 	const uint64_t blocks = (uint64_t)a.nXG * a.nYT * nZC;
-	if (blocks > 0x7FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
+	if (blocks > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
+	const uint64_t nslots = blocks * 4 * a.rz;
+	if (c->slice_cap < nslots) {
+		(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits);
+		c->slice_hdr = nullptr; c->slice_bits = nullptr; c->slice_cap = 0;
+		HIP_TRY(hipMalloc(&c->slice_hdr, nslots * sizeof(SliceHeader)));
+		HIP_TRY(hipMalloc(&c->slice_bits, nslots * 4096));
+		c->slice_cap = nslots;
+	}
+	a.slice_hdr = c->slice_hdr; a.slice_bits = c->slice_bits;
+	a.debug = env_u32("MC33_HIP_DEBUG", 0);
+	a.dbg_cells = getenv("MC33_HIP_VERBOSE") ? &c->d_ctr->pad_ : nullptr;
+	a.trace = nullptr;
+	if (getenv("MC33_HIP_TRACE_FILE")) {
+		(void)hipFree(c->trace);
+		c->trace = nullptr;
+		c->trace_waves = blocks * 4;
+		HIP_TRY(hipMalloc(&c->trace, c->trace_waves * 16));
+		HIP_TRY(hipMemsetAsync(c->trace, 0, c->trace_waves * 16, st));
+		a.trace = c->trace;
+	}
+	HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
+	HIP_TRY(hipMemsetAsync(c->slice_hdr, 0, nslots * sizeof(SliceHeader), st));
+	HIP_TRY(hipMemsetAsync(c->seg_cnt, 0, c->nsegs * 4, st));
 	HIP_TRY(hipEventRecord(c->ev[0], st));
 	hipLaunchKernelGGL(k_sweep, dim3((uint32_t)blocks), dim3(256), 0, st, a);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c->ev[1], st));
+	CellsArgs ca;
+	ca.P = P; ca.fast = c->d_fast;
+	ca.ze = a.ze; ca.nXG = a.nXG; ca.nYT = a.nYT; ca.rz = a.rz; ca.nslots = nslots;
+	ca.slice_hdr = c->slice_hdr; ca.slice_bits = c->slice_bits;
+	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir; ca.seg_mask = c->seg_mask;
+	ca.entries = c->entries; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
+	ca.entry_cap = (uint32_t)c->entry_cap;
+	ca.horiz_cost = env_u32("MC33_HIP_HCOST", HORIZ_COST);
+	ca.ctr = c->d_ctr;
+	hipLaunchKernelGGL(k_cells, dim3((uint32_t)((nslots + 3) / 4)), dim3(256), 0, st, ca);
 	SlowArgs sa;
 	sa.G = a.G; sa.P = P;
 	sa.tab.lut = c->d_lut; sa.tab.rule_words = c->d_rules; sa.tab.rule_index = c->d_rule_index;
@@ -1044,10 +1142,6 @@ static int enqueue_count(mc33hip_ctx *c) {
 }
 
 static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t capV, uint64_t capT) {
-	if (env_u32("MC33_HIP_DEBUG", 0)) {  // timing experiment: the work records are incomplete, never read them
-		HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-		return 0;
-	}
 	EmitArgs a;
 	a.c.tab.lut = c->d_lut; a.c.tab.rule_words = c->d_rules; a.c.tab.rule_index = c->d_rule_index;
 	a.c.P = c->P;
@@ -1058,7 +1152,6 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.c.z_emit = c->range.z_begin; a.c.v_skip = a.c.t_skip = a.c.id_delta = 0;
 	a.ctr = c->d_ctr;
 	a.slow_list = c->slow_list;
-	a.chunk_fill = c->chunk_fill;
 	a.entry_cap = (uint32_t)c->entry_cap;
 	a.capV = capV; a.capT = capT;
 	a.ghost_segs = c->ghost_segs;
@@ -1092,6 +1185,17 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 static int fetch_counters(mc33hip_ctx *c) {
 	HIP_TRY(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (getenv("MC33_HIP_VERBOSE"))
+		fprintf(stderr, "[mc33hip] cut cells: sweep %u, k_cells %u (slow %u, dirty segments %u, masks %u)\n", c->h_ctr->pad_,
+		        c->h_ctr->entry_cursor, c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->mask_cursor);
+	if (c->trace && getenv("MC33_HIP_TRACE_FILE")) {  // developer tracing: per-wave stamps of the last sweep
+		void *h = malloc(c->trace_waves * 16);
+		if (h && hipMemcpy(h, c->trace, c->trace_waves * 16, hipMemcpyDeviceToHost) == hipSuccess) {
+			FILE *f = fopen(getenv("MC33_HIP_TRACE_FILE"), "wb");
+			if (f) { fwrite(h, 16, c->trace_waves, f); fclose(f); }
+		}
+		free(h);
+	}
 	return 0;
 }
 
