@@ -20,6 +20,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <utility>
+#include <vector>
 
 #include "../../include/mc33_hip.h"
 #include "mc33_cell.h"
@@ -61,12 +64,24 @@ struct SliceHeader {
 };
 constexpr uint32_t SLICE_VALID = 1u, SLICE_HAS_ISO = 2u;
 
+// One block of k_sweep: the 4 row segments of group xg, the 63 cell rows of y tile yt, cell slices [z_lo, z_hi).
+// The host cuts every (xg, yt) column into chunks of equal WORK (rows x planes), as many in total as the
+// GPU holds blocks at once: waves of one SIMD are served oldest first, so a CU that got one block more
+// than the others ends that much later, and short tiles (the last y tile) get deeper chunks.
+struct SweepTile { uint32_t xg, yt, z_lo, z_hi; };
+
+// slice record of (cell slice z, y tile, row segment): groups of 4 consecutive slices of one tile column are
+// adjacent (one k_cells block; the emit kernels find neighbouring cells in neighbouring records)
+__host__ __device__ inline uint64_t slice_slot(uint32_t dz, uint32_t yt, uint32_t seg, uint32_t nYT, uint32_t nseg_pad) {
+	return ((((uint64_t)(dz >> 2) * nYT + yt) * nseg_pad + seg) << 2) | (dz & 3u);
+}
+
 struct SweepArgs {
 	GridView<sample_t> G;
 	Params P;
-	uint32_t ze;             // classify cell slices [P.zs, ze)
-	uint32_t nXG, nYT, rz;   // tiles: 4 segments wide, 63 cell rows high, rz slices deep
-	SliceHeader *slice_hdr;  // [block][wave][slice of the tile]
+	const SweepTile *tiles;  // [block]
+	uint32_t nYT, nseg_pad;  // y tiles, row segments rounded up to whole groups of 4
+	SliceHeader *slice_hdr;  // [slice_slot]
 	uint4 *slice_bits;       // [slot][k][lane]: {prev[k].lo, prev[k].hi, cur[k].lo, cur[k].hi}
 	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz)
 	uint32_t *dbg_cells;     // MC33_HIP_VERBOSE: cut cells counted by the sweep itself (cross-check of k_cells)
@@ -143,19 +158,15 @@ __device__ __forceinline__ void valid_masks(uint32_t xbase, uint32_t nx, uint64_
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-	uint32_t b = blockIdx.x;
-	const uint32_t xg = b % a.nXG;
-	b /= a.nXG;
-	const uint32_t yt = b % a.nYT, zc = b / a.nYT;
-	const uint32_t seg = xg * 4 + wv;
+	const SweepTile tile = a.tiles[blockIdx.x];
+	const uint32_t yt = tile.yt, seg = tile.xg * 4 + wv;
 	const Params &P = a.P;
 	if (seg >= P.nseg) return;
 	const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
 	const uint32_t nrows = min(64u, P.ny + 1 - y0);  // sample rows of this tile
-	const uint32_t z_lo = P.zs + zc * a.rz, z_hi = min(z_lo + a.rz, a.ze);
+	const uint32_t z_lo = tile.z_lo, z_hi = tile.z_hi;
 	const float iso = P.iso;
-	const uint64_t slot0 = ((uint64_t)blockIdx.x * 4 + wv) * a.rz;
 
 	// per-lane byte offsets of its four samples inside a row (clamped into the row: bits of samples
 	// beyond the grid belong to cells that the valid masks remove)
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				if (lane == 0 && n) atomicAdd(a.dbg_cells, n);
 			}
 			if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull)) {  // wave-uniform: hand the slice to k_cells
-				const uint64_t slot = slot0 + (p - 1 - z_lo);
+				const uint64_t slot = slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad);
 				uint4 *bits = a.slice_bits + slot * 256u + lane;
 #pragma unroll
 				for (int k = 0; k < 4; k++)
@@ -308,8 +319,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 struct CellsArgs {
 	Params P;
 	const uint4 *fast;       // per sign index: record words of a FAST cell (fast_record_table)
-	uint32_t ze, nXG, nYT, rz;
-	uint64_t nslots;
+	uint32_t ze, nYT, nseg_pad;
 	const SliceHeader *slice_hdr;
 	const uint4 *slice_bits;
 	uint32_t *seg_cnt;
@@ -320,31 +330,39 @@ struct CellsArgs {
 	uint32_t *slow_list, *dirty_list;
 	uint32_t entry_cap;
 	uint32_t horiz_cost;
+	uint32_t speculate;  // fetch the bit rows together with the header
 	Counters *ctr;
+	unsigned long long *trace;  // MC33_HIP_TRACE_CELLS: per wave {start, bits in, records allocated, end}
 };
 
 __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
+	const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	__shared__ uint4 s_fast[256];
 	__shared__ uint32_t s_tot[4], s_nm[4], s_base[2];
 	s_fast[threadIdx.x] = a.fast[threadIdx.x];
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	const Params &P = a.P;
+	// block -> 4 consecutive slices of one tile column (slice_slot order)
 	const uint64_t slot = (uint64_t)blockIdx.x * 4 + wv;
-	// slot -> (sweep block, wave, slice of the tile) -> tile coordinates, as k_sweep numbered them
-	const uint64_t wl = slot / a.rz;
-	const uint32_t si = (uint32_t)(slot % a.rz);
-	uint32_t b = (uint32_t)(wl / 4);
-	const uint32_t w = (uint32_t)(wl % 4);
-	const uint32_t xg = b % a.nXG;
-	b /= a.nXG;
-	const uint32_t yt = b % a.nYT, zc = b / a.nYT;
-	const uint32_t seg = xg * 4 + w, xbase = seg * SEG_CELLS, y0 = yt * 63u;
-	const uint32_t z = P.zs + zc * a.rz + si;
+	const uint32_t seg = blockIdx.x % a.nseg_pad, bt = blockIdx.x / a.nseg_pad;
+	const uint32_t yt = bt % a.nYT, zq = bt / a.nYT;
+	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
+	const uint32_t z = P.zs + zq * 4u + wv;
 	const uint32_t y = y0 + lane;
-	bool live = slot < a.nslots && seg < P.nseg && z < a.ze;
+	bool live = seg < P.nseg && z < a.ze;
 	SliceHeader h;
 	h.flags = 0;
-	if (live) h = a.slice_hdr[slot];
+	uint4 q[4] = {};
+	if (live) {
+		// header and bit rows are fetched together (one round trip); the rows of a slice without cut cells
+		// are whatever an earlier call left there and are not looked at
+		h = a.slice_hdr[slot];
+		if (a.speculate) {
+			const uint4 *bits = a.slice_bits + slot * 256u + lane;
+#pragma unroll
+			for (int k = 0; k < 4; k++) q[k] = bits[64 * k];
+		}
+	}
 	live = live && (h.flags & SLICE_VALID);
 	const bool rowvalid = live && lane < 63u && y < P.ny;
 
@@ -352,12 +370,13 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	uint32_t prev_h = 0, cur_h = 0, cnt = 0, c0 = 0, c1 = 0, c2 = 0, incl = 0, total = 0, nm = 0;
 	uint64_t havem = 0;
 	if (live) {  // wave-uniform
-		const uint4 *bits = a.slice_bits + slot * 256u + lane;
+		if (!a.speculate) {
+			const uint4 *bits = a.slice_bits + slot * 256u + lane;
 #pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const uint4 q = bits[64 * k];
-			prev[k] = u64(q.x, q.y); cur[k] = u64(q.z, q.w);
+			for (int k = 0; k < 4; k++) q[k] = bits[64 * k];
 		}
+#pragma unroll
+		for (int k = 0; k < 4; k++) { prev[k] = u64(q[k].x, q[k].y); cur[k] = u64(q[k].z, q[k].w); }
 		prev_h = (uint32_t)((u64(h.prevh_lo, h.prevh_hi) >> lane) & 1ull);
 		cur_h = (uint32_t)((u64(h.curh_lo, h.curh_hi) >> lane) & 1ull);
 		uint64_t valid[4];
@@ -375,18 +394,22 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		total = __builtin_amdgcn_readlane(incl, 63);
 		nm = (uint32_t)__popcll(havem);
 	}
+	const unsigned long long t_bits = a.trace ? __builtin_amdgcn_s_memrealtime() + (total & 0u) : 0ull;
 	// the four slices of the block get consecutive work records / mask records (they are consecutive
 	// slices of one tile: the emit kernels find neighbouring cells in neighbouring records)
 	if (lane == 0) { s_tot[wv] = total; s_nm[wv] = nm; }
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		const uint32_t te = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3], tm = s_nm[0] + s_nm[1] + s_nm[2] + s_nm[3];
-		s_base[0] = te ? atomicAdd(&a.ctr->entry_cursor, te) : 0u;
-		s_base[1] = tm ? atomicAdd(&a.ctr->mask_cursor, tm) : 0u;
+		if (te) {  // both requests go out before either result is awaited
+			const uint32_t be = atomicAdd(&a.ctr->entry_cursor, te), bm = atomicAdd(&a.ctr->mask_cursor, tm);
+			s_base[0] = be; s_base[1] = bm;
+		}
 	}
 	__syncthreads();
 	if (!total) return;  // wave-uniform (no barrier below)
 	uint32_t ebase = s_base[0], mbase = s_base[1];
+	const unsigned long long t_alloc = a.trace ? __builtin_amdgcn_s_memrealtime() + (ebase & 0u) : 0ull;
 	for (uint32_t q = 0; q < wv; q++) { ebase += s_tot[q]; mbase += s_nm[q]; }
 
 	const uint64_t sidx = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y;  // storage order [z][segment][y]
@@ -523,6 +546,10 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		a.seg_cnt[sidx] = dirty ? 0u : seg_pack(nv_run, nt_run);
 		a.seg_dir[sidx] = SegDir{first, cnt | (dirty ? SEG_DIRTY : 0u), maskidx, pack_prefix(c0, c1, c2)};
 		if (dirty && first < a.entry_cap) a.dirty_list[atomicAdd(&a.ctr->dirty_cursor, 1u)] = (uint32_t)sidx;
+	}
+	if (a.trace && lane == 0) {
+		unsigned long long *tr = a.trace + 4ull * slot;
+		tr[0] = t_start; tr[1] = t_bits; tr[2] = t_alloc; tr[3] = __builtin_amdgcn_s_memrealtime();
 	}
 }
 
@@ -808,6 +835,10 @@ struct mc33hip_ctx {
 	SliceHeader *slice_hdr;   // one record per (wave tile, cell slice) of the sweep
 	uint4 *slice_bits;
 	uint64_t slice_cap;
+	SweepTile *d_tiles;       // block plan of k_sweep for the current range
+	uint64_t tiles_cap, ntiles;
+	uint32_t tiles_zs, tiles_ze, tiles_depth;
+	uint32_t resident_blocks; // k_sweep blocks the device holds at once
 	Counters *d_ctr, *h_ctr;
 	hipEvent_t ev[4];
 	hipStream_t aux, aux2;    // the vertex pass and the slow-record pass run beside the fast triangle pass
@@ -815,6 +846,8 @@ struct mc33hip_ctx {
 	bool emit_pending;        // an emit was enqueued after the last timing read
 	unsigned long long *trace;  // developer tracing (MC33_HIP_TRACE_FILE)
 	uint64_t trace_waves;
+	unsigned long long *trace_cells;  // (MC33_HIP_TRACE_CELLS)
+	uint64_t trace_cells_n;
 	// state of the last count
 	bool counted;
 	Params P;
@@ -893,8 +926,8 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base); (void)hipFree(c->seg_mask);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
 	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
-	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits);
-	(void)hipFree(c->trace);
+	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->d_tiles);
+	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
@@ -1070,6 +1103,73 @@ static int grow_entries(mc33hip_ctx *c, uint64_t need) {
 	return alloc_entries(c, cap);
 }
 
+// Block plan of k_sweep for cell slices [zs, ze): every (segment group, y tile) column is cut along z into
+// chunks of about equal work (sample rows x waves x planes; a chunk re-reads one plane, so they are kept
+// about `depth` slices deep), and the number of chunks is a whole multiple of what the device holds at
+// once whenever the grid is large enough.  Measured on MI355X at 1024^3: with 1088 equal tiles on 256 CUs
+// the 64 CUs that got a fifth block finished 12 % after the others.
+static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
+	const Params &P = c->P;
+	const uint32_t depth = std::max(1u, env_u32("MC33_HIP_RZ", 16));
+	if (c->d_tiles && c->tiles_zs == zs && c->tiles_ze == ze && c->tiles_depth == depth) return 0;
+	if (!c->resident_blocks) {
+		int per_cu = 0, cus = 0;
+		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep, 256, 0));
+		HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+		const uint32_t want = env_u32("MC33_HIP_SWEEP_BLOCKS_PER_CU", 4);
+		c->resident_blocks = (uint32_t)std::max(1, cus) * (uint32_t)std::max(1, std::min(per_cu, (int)want));
+	}
+	const uint32_t nXG = (P.nseg + 3) / 4, nYT = (P.ny + 62) / 63, nzc = ze - zs;
+	const uint64_t ncol = (uint64_t)nXG * nYT;
+	std::vector<double> w(ncol);
+	double W = 0;
+	for (uint32_t yt = 0; yt < nYT; yt++)
+		for (uint32_t xg = 0; xg < nXG; xg++) {
+			const uint32_t rows = std::min(64u, P.ny + 1 - yt * 63u), waves = std::min(4u, P.nseg - xg * 4);
+			W += w[(uint64_t)yt * nXG + xg] = (double)rows * waves;
+		}
+	// chunks wanted: W * nzc / (256 * depth), rounded to whole rounds of the resident set
+	const double pref = W * nzc / (256.0 * depth);
+	uint64_t B = c->resident_blocks;
+	if (pref >= (double)B) B *= (uint64_t)(pref / (double)B + 0.5);
+	else B = std::max<uint64_t>(1, std::min<uint64_t>(B, (uint64_t)(W * nzc / (256.0 * 4.0))));  // small grid: at least 4 slices deep
+	std::vector<uint32_t> chunks(ncol);
+	std::vector<std::pair<double, uint64_t>> frac(ncol);
+	uint64_t total = 0;
+	for (uint64_t i = 0; i < ncol; i++) {
+		const double share = (double)B * w[i] / W;
+		const uint32_t n = (uint32_t)std::min<double>(std::max(1.0, std::floor(share)), (double)nzc);
+		chunks[i] = n; total += n;
+		frac[i] = {share - std::floor(share), i};
+	}
+	std::sort(frac.begin(), frac.end(), [](const std::pair<double, uint64_t> &x, const std::pair<double, uint64_t> &y) { return x.first > y.first; });
+	for (uint64_t k = 0; k < ncol && total < B; k++)
+		if (chunks[frac[k].second] < nzc) { chunks[frac[k].second]++; total++; }
+	if (total > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
+	std::vector<SweepTile> tiles;
+	tiles.reserve(total);
+	for (uint64_t i = 0; i < ncol; i++)
+		for (uint32_t k = 0; k < chunks[i]; k++) {
+			const uint32_t lo = zs + (uint32_t)((uint64_t)nzc * k / chunks[i]), hi = zs + (uint32_t)((uint64_t)nzc * (k + 1) / chunks[i]);
+			if (hi > lo) tiles.push_back(SweepTile{(uint32_t)(i % nXG), (uint32_t)(i / nXG), lo, hi});
+		}
+	// launch order: by depth first, so that blocks running together read neighbouring memory
+	std::stable_sort(tiles.begin(), tiles.end(), [](const SweepTile &x, const SweepTile &y) { return x.z_lo < y.z_lo; });
+	if (c->tiles_cap < tiles.size()) {
+		(void)hipFree(c->d_tiles);
+		c->d_tiles = nullptr; c->tiles_cap = 0;
+		HIP_TRY(hipMalloc(&c->d_tiles, tiles.size() * sizeof(SweepTile)));
+		c->tiles_cap = tiles.size();
+	}
+	HIP_TRY(hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(SweepTile), hipMemcpyHostToDevice));
+	c->ntiles = tiles.size();
+	c->tiles_zs = zs; c->tiles_ze = ze; c->tiles_depth = depth;
+	if (getenv("MC33_HIP_VERBOSE"))
+		fprintf(stderr, "[mc33hip] sweep plan: %llu tiles (%u resident), %llu columns, depth %.1f\n", (unsigned long long)c->ntiles,
+		        c->resident_blocks, (unsigned long long)ncol, (double)nzc * ncol / (double)c->ntiles);
+	return 0;
+}
+
 // enqueue sweep + cell records + slow-cell planning + scans on the context's stream (no synchronisation)
 static int enqueue_count(mc33hip_ctx *c) {
 	const Params &P = c->P;
@@ -1077,14 +1177,15 @@ static int enqueue_count(mc33hip_ctx *c) {
 	SweepArgs a;
 	a.G.p = c->d_grid; a.G.pitch = (uint32_t)c->pitch; a.G.z0 = c->desc.plane0; a.G.slice = c->slice;
 	a.P = P;
-	a.ze = c->range.z_end;
-	a.nXG = (P.nseg + 3) / 4;
+	const uint32_t ze = c->range.z_end;
 	a.nYT = (P.ny + 62) / 63;
-	a.rz = env_u32("MC33_HIP_RZ", 16);
-	const uint32_t nZC = (a.ze - P.zs + a.rz - 1) / a.rz;
-	const uint64_t blocks = (uint64_t)a.nXG * a.nYT * nZC;
-	if (blocks > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
-	const uint64_t nslots = blocks * 4 * a.rz;
+	a.nseg_pad = (P.nseg + 3) / 4 * 4;
+	if (int rc = plan_sweep(c, P.zs, ze)) return rc;
+	a.tiles = c->d_tiles;
+	const uint64_t blocks = c->ntiles;
+	const uint64_t cell_blocks = (uint64_t)((ze - P.zs + 3) / 4) * a.nYT * a.nseg_pad;
+	if (cell_blocks > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
+	const uint64_t nslots = cell_blocks * 4;
 	if (c->slice_cap < nslots) {
 		(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits);
 		c->slice_hdr = nullptr; c->slice_bits = nullptr; c->slice_cap = 0;
@@ -1113,14 +1214,24 @@ static int enqueue_count(mc33hip_ctx *c) {
 	HIP_TRY(hipEventRecord(c->ev[1], st));
 	CellsArgs ca;
 	ca.P = P; ca.fast = c->d_fast;
-	ca.ze = a.ze; ca.nXG = a.nXG; ca.nYT = a.nYT; ca.rz = a.rz; ca.nslots = nslots;
+	ca.ze = ze; ca.nYT = a.nYT; ca.nseg_pad = a.nseg_pad;
 	ca.slice_hdr = c->slice_hdr; ca.slice_bits = c->slice_bits;
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir; ca.seg_mask = c->seg_mask;
 	ca.entries = c->entries; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
 	ca.entry_cap = (uint32_t)c->entry_cap;
 	ca.horiz_cost = env_u32("MC33_HIP_HCOST", HORIZ_COST);
+	ca.speculate = env_u32("MC33_HIP_CELLS_SPEC", 1);
 	ca.ctr = c->d_ctr;
-	hipLaunchKernelGGL(k_cells, dim3((uint32_t)((nslots + 3) / 4)), dim3(256), 0, st, ca);
+	ca.trace = nullptr;
+	if (getenv("MC33_HIP_TRACE_CELLS")) {
+		(void)hipFree(c->trace_cells);
+		c->trace_cells = nullptr;
+		c->trace_cells_n = nslots;
+		HIP_TRY(hipMalloc(&c->trace_cells, nslots * 32));
+		HIP_TRY(hipMemsetAsync(c->trace_cells, 0, nslots * 32, st));
+		ca.trace = c->trace_cells;
+	}
+	hipLaunchKernelGGL(k_cells, dim3((uint32_t)cell_blocks), dim3(256), 0, st, ca);
 	SlowArgs sa;
 	sa.G = a.G; sa.P = P;
 	sa.tab.lut = c->d_lut; sa.tab.rule_words = c->d_rules; sa.tab.rule_index = c->d_rule_index;
@@ -1188,6 +1299,14 @@ static int fetch_counters(mc33hip_ctx *c) {
 	if (getenv("MC33_HIP_VERBOSE"))
 		fprintf(stderr, "[mc33hip] cut cells: sweep %u, k_cells %u (slow %u, dirty segments %u, masks %u)\n", c->h_ctr->pad_,
 		        c->h_ctr->entry_cursor, c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->mask_cursor);
+	if (c->trace_cells && getenv("MC33_HIP_TRACE_CELLS")) {
+		void *h = malloc(c->trace_cells_n * 32);
+		if (h && hipMemcpy(h, c->trace_cells, c->trace_cells_n * 32, hipMemcpyDeviceToHost) == hipSuccess) {
+			FILE *f = fopen(getenv("MC33_HIP_TRACE_CELLS"), "wb");
+			if (f) { fwrite(h, 32, c->trace_cells_n, f); fclose(f); }
+		}
+		free(h);
+	}
 	if (c->trace && getenv("MC33_HIP_TRACE_FILE")) {  // developer tracing: per-wave stamps of the last sweep
 		void *h = malloc(c->trace_waves * 16);
 		if (h && hipMemcpy(h, c->trace, c->trace_waves * 16, hipMemcpyDeviceToHost) == hipSuccess) {

@@ -13,7 +13,7 @@ import sys
 
 src, out = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(src + "/*/runc/*_counter_collection.csv")):
+for f in sorted(glob.glob(src + "/*/runc/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
         if k.startswith("k_"):
