@@ -49,8 +49,8 @@ typedef struct {
 	double r0[3], d[3];      /* origin, spacing                                                    */
 	float L[3];              /* extent (unused by the isosurface path)                             */
 	float Ang[3];
-	int nonortho;            /* inclined grid (MC33_spnC): not accelerated, create_MC33 returns 0  */
-	double _A[3][3], A_[3][3];
+	int nonortho;            /* inclined grid: positions / normals go through _A / A_ (MC33_spnC)  */
+	double _A[3][3], A_[3][3]; /* fractional -> cartesian cell matrix (unit edges) and its inverse  */
 	int periodic;
 	int internal_data;       /* 1: rows were allocated by alloc_F and are freed by free_memory_grd */
 	char title[160];
@@ -98,6 +98,13 @@ typedef struct {
 } MC33;
 
 extern int DefaultColorMC;   /* colour given to every vertex, 0xAABBGGRR (reference header :181) */
+
+/* c = A b (t == 0) or A^T b (t != 0) for a 3x3 matrix, used for inclined grids (reference header :186-191).
+ * _multTSA_bf assumes an upper triangular A.  A caller may point mult_Abf at either; calculate_isosurface
+ * looks at the pointer when it is called and runs the matching form on the GPU (any other function: NULL). */
+void _multTSA_bf(const double (*A)[3], MC33_real *b, MC33_real *c, int t);
+void _multA_bf(const double (*A)[3], MC33_real *b, MC33_real *c, int t);
+extern void (*mult_Abf)(const double (*)[3], MC33_real *, MC33_real *, int);
 
 /* --- isosurface path (reference header :228-258) ------------------------------------------------ */
 MC33 *create_MC33(_GRD *G);                                  /* uploads the grid to HBM once        */

@@ -73,6 +73,12 @@ int mc33hip_upload_rows(mc33hip_ctx *c, const void *const *const *F);
 int mc33hip_upload_contiguous(mc33hip_ctx *c, const void *host_samples);
 int mc33hip_adopt_device(mc33hip_ctx *c, const void *device_samples, size_t pitch, size_t slice);
 
+/* Inclined (non-orthogonal) grid: vertices and normals go through the cell matrices like MC33_spnC does
+ * (reference marching_cubes_33.c:587-621).  grd_A / grd_Ai = _GRD._A / _GRD.A_ (3x3 row major, before the
+ * scaling by d that create_MC33 applies, MC:1763-1770); triangular != 0 = the caller's mult_Abf is
+ * _multTSA_bf (MC33_util_grd.c:86-97).  NULL matrices switch back to the orthogonal stores. */
+int mc33hip_set_inclined(mc33hip_ctx *c, const double *grd_A, const double *grd_Ai, int triangular);
+
 /* Stream all work is enqueued on (a hipStream_t passed as void*; NULL = the default stream). */
 int mc33hip_set_stream(mc33hip_ctx *c, void *hip_stream);
 

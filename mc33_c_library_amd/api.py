@@ -35,10 +35,10 @@ class Timing(C.Structure):
 HIP_API = ["mc33hip_set_id_base", "mc33hip_create", "mc33hip_destroy", "mc33hip_last_error", "mc33hip_upload_rows",
            "mc33hip_upload_contiguous", "mc33hip_adopt_device", "mc33hip_set_stream", "mc33hip_count",
            "mc33hip_emit", "mc33hip_extract", "mc33hip_last_timing", "mc33hip_download",
-           "mc33hip_device_alloc", "mc33hip_device_free"]
+           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined"]
 REFERENCE_API = ["create_MC33", "calculate_isosurface", "size_of_isosurface", "free_MC33", "free_surface_memory",
                  "adjustvectorlenght_s", "DefaultColorMC", "free_memory_grd", "alloc_F", "grid_from_data_pointer",
-                 "generate_grid_from_fn"]
+                 "generate_grid_from_fn", "_multTSA_bf", "_multA_bf", "mult_Abf"]
 
 
 class MC33Error(RuntimeError):
@@ -84,6 +84,7 @@ def load_library(dtype="f32"):
     lib.mc33hip_download.argtypes = [V, V, V, C.c_size_t]
     lib.mc33hip_device_alloc.argtypes = [V, P(V), C.c_size_t]
     lib.mc33hip_device_free.argtypes = [V, V]
+    lib.mc33hip_set_inclined.argtypes = [V, V, V, C.c_int]
     _libs[dtype] = lib
     return lib
 
@@ -123,6 +124,15 @@ class DeviceGrid:
     def use_stream(self, stream):
         self.stream = stream
         _check(self.lib, self.lib.mc33hip_set_stream(self.ctx, C.c_void_p(stream.cuda_stream)))
+
+    def set_inclined(self, A=None, Ai=None, triangular=False):
+        """Non-orthogonal grid: _GRD._A / _GRD.A_ (3x3, row major); None switches back."""
+        if A is None:
+            _check(self.lib, self.lib.mc33hip_set_inclined(self.ctx, None, None, 0))
+            return
+        a = (C.c_double * 9)(*[float(x) for row in A for x in row])
+        ai = (C.c_double * 9)(*[float(x) for row in Ai for x in row])
+        _check(self.lib, self.lib.mc33hip_set_inclined(self.ctx, a, ai, int(bool(triangular))))
 
     def close(self):
         if getattr(self, "ctx", None):

@@ -40,6 +40,8 @@ typedef struct {
 	void *dV, *dN, *dT;  /* device staging of the last result, grown on demand */
 	unsigned long long capV, capT;
 	int reupload;
+	int inclined;        /* G->nonortho at create time: the MC33_spnC store */
+	double grd_A[9], grd_Ai[9];
 } mc33_private;
 #define MC33_MAGIC 0x4D43333348495031ull /* "MC33HIP1" */
 
@@ -50,8 +52,6 @@ static mc33_private *priv(MC33 *M) {
 
 MC33 *create_MC33(_GRD *G) {
 	if (!G || !G->F)
-		return 0;
-	if (G->nonortho) /* inclined grids use MC33_spnC (MC:587-621): not accelerated yet */
 		return 0;
 	mc33_private *p = (mc33_private *)calloc(1, sizeof *p);
 	if (!p)
@@ -64,7 +64,16 @@ MC33 *create_MC33(_GRD *G) {
 		M->O[j] = (MC33_real)G->r0[j];
 		M->D[j] = (MC33_real)G->d[j];
 	}
-	if (G->d[0] != G->d[1] || G->d[1] != G->d[2]) { /* MC:1772-1775 */
+	if (G->nonortho) { /* MC:1763-1770: the matrices MC33_spnC multiplies with */
+		for (int j = 0; j != 3; j++)
+			for (int i = 0; i != 3; i++) {
+				M->_A[j][i] = G->_A[j][i] * G->d[i];
+				M->A_[j][i] = G->A_[j][i] / G->d[j];
+			}
+		p->inclined = 1;
+		memcpy(p->grd_A, G->_A, sizeof p->grd_A);
+		memcpy(p->grd_Ai, G->A_, sizeof p->grd_Ai);
+	} else if (G->d[0] != G->d[1] || G->d[1] != G->d[2]) { /* MC:1772-1775 */
 		M->ca = (MC33_real)(G->d[2] / G->d[0]);
 		M->cb = (MC33_real)(G->d[2] / G->d[1]);
 	}
@@ -100,7 +109,38 @@ void free_MC33(MC33 *M) {
 	free(p);
 }
 
+/* --- mult_Abf (reference header :186-191, MC33_util_grd.c:86-114) --------------------------------- */
+void _multTSA_bf(const double (*A)[3], MC33_real *b, MC33_real *c, int t) {
+	if (t) { /* rows of A^T, last first: c may alias b */
+		c[2] = A[0][2] * b[0] + A[1][2] * b[1] + A[2][2] * b[2];
+		c[1] = A[0][1] * b[0] + A[1][1] * b[1];
+		c[0] = A[0][0] * b[0];
+	} else {
+		c[0] = A[0][0] * b[0] + A[0][1] * b[1] + A[0][2] * b[2];
+		c[1] = A[1][1] * b[1] + A[1][2] * b[2];
+		c[2] = A[2][2] * b[2];
+	}
+}
+
+void _multA_bf(const double (*A)[3], MC33_real *b, MC33_real *c, int t) {
+	const int r = t ? 3 : 1, s = t ? 1 : 3; /* element (i, j) of the matrix applied = ((const double *)A)[i*s + j*r] */
+	const double *a = &A[0][0];
+	const double c0 = a[0] * b[0] + a[r] * b[1] + a[2 * r] * b[2];
+	const double c1 = a[s] * b[0] + a[s + r] * b[1] + a[s + 2 * r] * b[2];
+	c[2] = a[2 * s] * b[0] + a[2 * s + r] * b[1] + a[2 * s + 2 * r] * b[2];
+	c[0] = c0;
+	c[1] = c1;
+}
+
+void (*mult_Abf)(const double (*)[3], MC33_real *, MC33_real *, int) = _multA_bf;
+
 static int refresh_grid(mc33_private *p) {
+	if (p->inclined) { /* the reference calls through mult_Abf for every vertex (MC:608, 612) */
+		if (mult_Abf != _multA_bf && mult_Abf != _multTSA_bf)
+			return MC33HIP_EINVAL; /* a caller-supplied function cannot run on the GPU */
+		if (mc33hip_set_inclined(p->ctx, p->grd_A, p->grd_Ai, mult_Abf == _multTSA_bf) != MC33HIP_OK)
+			return MC33HIP_EINVAL;
+	}
 	if (!p->reupload)
 		return 0;
 	return mc33hip_upload_rows(p->ctx, (const void *const *const *)p->grid->F);

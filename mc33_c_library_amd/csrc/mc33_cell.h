@@ -41,7 +41,9 @@ struct Params {
 	float iso;
 	float O[3], D[3];     // float copies of r0, d (MC:1779-1782)
 	float ca, cb;         // MC:1773-1774
-	int32_t store_mode;   // 0: MC33_spn0 (MC:485), 1: MC33_spnA (MC:518), 2: MC33_spnB (MC:551)
+	int32_t store_mode;   // 0: MC33_spn0 (MC:485), 1: MC33_spnA (MC:518), 2: MC33_spnB (MC:551), 3: MC33_spnC (MC:587)
+	int32_t triangular;   // spnC: mult_Abf is _multTSA_bf (UTIL:86-97) rather than _multA_bf (UTIL:99-112)
+	double A[9], Ai[9];   // spnC: M->_A, M->A_ (row major; MC:1763-1770)
 };
 
 struct Tables {
@@ -519,11 +521,44 @@ MC33_HD void vertex_centre(uint32_t x, uint32_t y, uint32_t z, const VRef &v, fl
 
 MC33_HD float inv_sqrt_exact(float f) { return 1.0f / sqrtf(f); }  // MC:70-73 (the reference's portable form)
 
-// world position and unit normal of vertex `id` (MC:485-585)
+// b <- A b or A^T b (3x3, row major), products and sums in double, rounded to float on assignment: the two
+// forms of the reference's mult_Abf (UTIL:86-112).  The triangular form skips the zero terms and writes its
+// results one by one, which matters for the rounding of nothing but is kept for -0 / non-finite inputs.
+MC33_HD void mat_vec(const double *A, float *b, bool transposed, bool triangular) {
+	if (triangular) {
+		if (transposed) {
+			b[2] = (float)(A[2] * b[0] + A[5] * b[1] + A[8] * b[2]);
+			b[1] = (float)(A[1] * b[0] + A[4] * b[1]);
+			b[0] = (float)(A[0] * b[0]);
+		} else {
+			b[0] = (float)(A[0] * b[0] + A[1] * b[1] + A[2] * b[2]);
+			b[1] = (float)(A[4] * b[1] + A[5] * b[2]);
+			b[2] = (float)(A[8] * b[2]);
+		}
+		return;
+	}
+	double u, v;
+	if (transposed) {
+		u = A[0] * b[0] + A[3] * b[1] + A[6] * b[2];
+		v = A[1] * b[0] + A[4] * b[1] + A[7] * b[2];
+		b[2] = (float)(A[2] * b[0] + A[5] * b[1] + A[8] * b[2]);
+	} else {
+		u = A[0] * b[0] + A[1] * b[1] + A[2] * b[2];
+		v = A[3] * b[0] + A[4] * b[1] + A[5] * b[2];
+		b[2] = (float)(A[6] * b[0] + A[7] * b[1] + A[8] * b[2]);
+	}
+	b[0] = (float)u; b[1] = (float)v;
+}
+
+// world position and unit normal of vertex `id` (MC:485-621)
 MC33_HD void store_vertex(const Params &P, float *r, float *V, float *N, uint32_t id) {
 	float *p = V + 3 * (uint64_t)id;
 	if (P.store_mode == 0) {
 		p[0] = r[0]; p[1] = r[1]; p[2] = r[2];
+	} else if (P.store_mode == 3) {  // MC:607-612
+		mat_vec(P.A, r, false, P.triangular != 0);
+		for (int k = 0; k < 3; k++) p[k] = r[k] + P.O[k];
+		mat_vec(P.Ai, r + 3, true, P.triangular != 0);
 	} else {
 		for (int k = 0; k < 3; k++) p[k] = r[k] * P.D[k] + P.O[k];
 		if (P.store_mode == 2) { r[3] *= P.ca; r[4] *= P.cb; }

@@ -844,6 +844,8 @@ struct mc33hip_ctx {
 	hipStream_t aux, aux2;    // the vertex pass and the slow-record pass run beside the fast triangle pass
 	hipEvent_t ev_fork, ev_join, ev_join2;
 	bool emit_pending;        // an emit was enqueued after the last timing read
+	bool inclined, triangular;   // non-orthogonal grid (MC33_spnC): _GRD._A / _GRD.A_ as given
+	double grd_A[9], grd_Ai[9];
 	unsigned long long *trace;  // developer tracing (MC33_HIP_TRACE_FILE)
 	uint64_t trace_waves;
 	unsigned long long *trace_cells;  // (MC33_HIP_TRACE_CELLS)
@@ -1041,6 +1043,17 @@ static void fill_params(mc33hip_ctx *c, float iso, const mc33hip_range *r) {
 	// store selection and float copies: MC:1772-1782
 	if (d.d[0] != d.d[1] || d.d[1] != d.d[2]) { P.store_mode = 2; P.ca = (float)(d.d[2] / d.d[0]); P.cb = (float)(d.d[2] / d.d[1]); }
 	else { P.store_mode = (d.d[0] == 1 && d.r0[0] == 0 && d.r0[1] == 0 && d.r0[2] == 0) ? 0 : 1; P.ca = P.cb = 1.0f; }
+	P.triangular = 0;
+	for (int k = 0; k < 9; k++) P.A[k] = P.Ai[k] = 0.0;
+	if (c->inclined) {  // G->nonortho: MC:1763-1770
+		P.store_mode = 3;
+		P.triangular = c->triangular;
+		for (int j = 0; j < 3; j++)
+			for (int i = 0; i < 3; i++) {
+				P.A[3 * j + i] = c->grd_A[3 * j + i] * d.d[i];
+				P.Ai[3 * j + i] = c->grd_Ai[3 * j + i] / d.d[j];
+			}
+	}
 	for (int k = 0; k < 3; k++) { P.O[k] = (float)d.r0[k]; P.D[k] = (float)d.d[k]; }
 	c->range = *r;
 	c->nsegs = (uint64_t)(r->z_end - P.zs) * P.ny * P.nseg;
@@ -1365,6 +1378,15 @@ extern "C" int mc33hip_count(mc33hip_ctx *c, float iso, const mc33hip_range *ran
 	read_timing(c, false, launches);
 	if ((rc = finish_counts(c, out))) return rc;
 	c->counted = true;
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_set_inclined(mc33hip_ctx *c, const double *grd_A, const double *grd_Ai, int triangular) {
+	if (!c) return MC33HIP_EINVAL;
+	c->inclined = grd_A && grd_Ai;
+	c->triangular = triangular != 0;
+	if (c->inclined) { memcpy(c->grd_A, grd_A, sizeof c->grd_A); memcpy(c->grd_Ai, grd_Ai, sizeof c->grd_Ai); }
+	c->counted = false;
 	return MC33HIP_OK;
 }
 

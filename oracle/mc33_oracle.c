@@ -137,7 +137,9 @@ typedef struct {
 	uint32_t nx, ny, nz; /* cells per axis  */
 	float iso;
 	float O[3], D[3], ca, cb;
-	int store_mode;      /* 0: spn0 (MC:485), 1: spnA (MC:518), 2: spnB (MC:551) */
+	int store_mode;      /* 0: spn0 (MC:485), 1: spnA (MC:518), 2: spnB (MC:551), 3: spnC (MC:587) */
+	double A[3][3], Ai[3][3]; /* spnC: _A[j][i]*d[i] and A_[j][i]/d[j] (MC:1763-1770) */
+	int triangular;      /* spnC: mult_Abf points at _multTSA_bf (UTIL:86-97) instead of _multA_bf (UTIL:99-112) */
 	uint32_t nV, nT, capV, capT;
 	float *V, *N;
 	uint32_t *T;
@@ -169,7 +171,34 @@ static uint32_t *id_slot(oracle_ctx *c, int axis, uint32_t x, uint32_t y, uint32
 	}
 }
 
-/* append one vertex: r[0..2] grid-index position, r[3..5] gradient (MC:485-585) */
+/* c = A b or A^T b in double, rounded to float on assignment: the two forms of mult_Abf (UTIL:86-112) */
+static void mat_vec(const double (*A)[3], float *b, int transposed, int triangular) {
+	if (triangular) {
+		if (transposed) {
+			b[2] = A[0][2] * b[0] + A[1][2] * b[1] + A[2][2] * b[2];
+			b[1] = A[0][1] * b[0] + A[1][1] * b[1];
+			b[0] = A[0][0] * b[0];
+		} else {
+			b[0] = A[0][0] * b[0] + A[0][1] * b[1] + A[0][2] * b[2];
+			b[1] = A[1][1] * b[1] + A[1][2] * b[2];
+			b[2] = A[2][2] * b[2];
+		}
+		return;
+	}
+	double u, v;
+	if (transposed) {
+		u = A[0][0] * b[0] + A[1][0] * b[1] + A[2][0] * b[2];
+		v = A[0][1] * b[0] + A[1][1] * b[1] + A[2][1] * b[2];
+		b[2] = A[0][2] * b[0] + A[1][2] * b[1] + A[2][2] * b[2];
+	} else {
+		u = A[0][0] * b[0] + A[0][1] * b[1] + A[0][2] * b[2];
+		v = A[1][0] * b[0] + A[1][1] * b[1] + A[1][2] * b[2];
+		b[2] = A[2][0] * b[0] + A[2][1] * b[1] + A[2][2] * b[2];
+	}
+	b[0] = u; b[1] = v;
+}
+
+/* append one vertex: r[0..2] grid-index position, r[3..5] gradient (MC:485-621) */
 static uint32_t emit_vertex(oracle_ctx *c, float *r) {
 	uint32_t id = c->nV;
 	if (id == c->capV) {
@@ -185,6 +214,10 @@ static uint32_t emit_vertex(oracle_ctx *c, float *r) {
 	float *p = c->V + 3 * (size_t)id;
 	if (c->store_mode == 0) {
 		p[0] = r[0]; p[1] = r[1]; p[2] = r[2];
+	} else if (c->store_mode == 3) { /* MC:607-612 */
+		mat_vec(c->A, r, 0, c->triangular);
+		for (int k = 0; k < 3; k++) p[k] = r[k] + c->O[k];
+		mat_vec(c->Ai, r + 3, 1, c->triangular);
 	} else {
 		for (int k = 0; k < 3; k++) p[k] = r[k] * c->D[k] + c->O[k];
 		if (c->store_mode == 2) { r[3] *= c->ca; r[4] *= c->cb; }
@@ -472,6 +505,12 @@ static unsigned cell_values(const oracle_ctx *c, uint32_t x, uint32_t y, uint32_
 
 int mc33o_calculate_isosurface(const mc33o_sample *data, uint32_t npx, uint32_t npy, uint32_t npz,
                                const double r0[3], const double d[3], float iso, mc33o_surface *out) {
+	return mc33o_calculate_isosurface_inclined(data, npx, npy, npz, r0, d, 0, 0, 0, iso, out);
+}
+
+int mc33o_calculate_isosurface_inclined(const mc33o_sample *data, uint32_t npx, uint32_t npy, uint32_t npz,
+                                        const double r0[3], const double d[3], const double *grd_A, const double *grd_Ai,
+                                        int triangular, float iso, mc33o_surface *out) {
 	oracle_ctx c;
 	memset(&c, 0, sizeof c);
 	memset(out, 0, sizeof *out);
@@ -482,6 +521,15 @@ int mc33o_calculate_isosurface(const mc33o_sample *data, uint32_t npx, uint32_t 
 	/* store selection: MC:1772-1782 */
 	if (d[0] != d[1] || d[1] != d[2]) { c.store_mode = 2; c.ca = (float)(d[2] / d[0]); c.cb = (float)(d[2] / d[1]); }
 	else c.store_mode = (d[0] == 1 && r0[0] == 0 && r0[1] == 0 && r0[2] == 0) ? 0 : 1;
+	if (grd_A && grd_Ai) { /* G->nonortho: MC:1763-1770 */
+		c.store_mode = 3;
+		c.triangular = triangular;
+		for (int j = 0; j < 3; j++)
+			for (int i = 0; i < 3; i++) {
+				c.A[j][i] = grd_A[3 * j + i] * d[i];
+				c.Ai[j][i] = grd_Ai[3 * j + i] / d[j];
+			}
+	}
 	for (int k = 0; k < 3; k++) { c.O[k] = (float)r0[k]; c.D[k] = (float)d[k]; }
 	c.capV = c.capT = 4096;
 	c.V = (float *)malloc((size_t)c.capV * 12);

@@ -29,6 +29,11 @@ typedef struct {
  * exact_rsqrt is always used for normals (1.0f/sqrtf, marching_cubes_33.c:70-73). */
 int mc33o_calculate_isosurface(const mc33o_sample *data, uint32_t npx, uint32_t npy, uint32_t npz,
                                const double r0[3], const double d[3], float iso, mc33o_surface *out);
+/* Inclined grid (_GRD.nonortho, MC33_spnC MC:587-621): grd_A / grd_Ai are _GRD._A / _GRD.A_ (3x3, row major);
+ * triangular != 0 selects the _multTSA_bf form of mult_Abf (MC33_util_grd.c:86-97).  NULL matrices = the call above. */
+int mc33o_calculate_isosurface_inclined(const mc33o_sample *data, uint32_t npx, uint32_t npy, uint32_t npz,
+                                        const double r0[3], const double d[3], const double *grd_A, const double *grd_Ai,
+                                        int triangular, float iso, mc33o_surface *out);
 void mc33o_free_surface(mc33o_surface *s);
 
 /* Per-cell classification only (no geometry): for every cell writes the 8-bit sign index and the

@@ -102,3 +102,22 @@ def analytic_field(name, n=48):
     else:
         raise KeyError(name)
     return f.astype(np.float32)
+
+
+def cell_matrices(alpha, beta, gamma):
+    """_GRD._A (fractional -> cartesian, unit cell edges) and _GRD.A_ (its inverse) of a cell with angles
+    alpha, beta, gamma in degrees - the upper triangular pair read_grd builds (reference MC33_util_grd.c:218-236),
+    derived here from the standard crystallographic convention a || x, b in the xy plane."""
+    ca, cb, cg = (np.cos(np.radians(t)) for t in (alpha, beta, gamma))
+    sg = np.sin(np.radians(gamma))
+    A = np.array([[1.0, cg, cb],
+                  [0.0, sg, (ca - cb * cg) / sg],
+                  [0.0, 0.0, np.sqrt(sg * sg + 2 * ca * cb * cg - ca * ca - cb * cb) / sg]])
+    return A, np.linalg.inv(A)
+
+
+def general_matrices(seed=5):
+    """A full (not triangular) well-conditioned 3x3 matrix and its inverse, for the _multA_bf form."""
+    rng = np.random.RandomState(seed)
+    A = np.eye(3) + 0.3 * rng.uniform(-1, 1, (3, 3))
+    return A, np.linalg.inv(A)

@@ -39,6 +39,12 @@ CASES = [
     ("u16_mod7_s1_iso3", "u16", lambda: (fx.noise_u16(32, 1, 7), None, None), 3.0, False),
     ("u16_cos_96x80x48_iso25268.5", "u16", lambda: (fx.cos_field_u16(96, 80, 48), None, None), 25268.5, False),
 ]
+# non-orthogonal grids (MC33_spnC): name -> (matrices, mult_Abf is _multTSA_bf)
+INCLINED = {
+    "inclined_cos40_general": (fx.general_matrices(), False),
+    "inclined_cos40_cell_80_95_70": (fx.cell_matrices(80.0, 95.0, 70.0), True),
+}
+CASES += [(n, "f32", lambda: (fx.cos_field(40)[0], (-1.0, 0.5, 2.0), (0.2, 0.3, 0.45)), 0.1, False) for n in INCLINED]
 
 
 def main():
@@ -47,7 +53,10 @@ def main():
     meta = {}
     for name, dt, gen, iso, full in CASES:
         data, r0, d = gen()
-        S = refs[dt].isosurface(data, iso, r0, d)
+        inc = INCLINED.get(name)
+        refs[dt].set_triangular(bool(inc and inc[1]))
+        S = refs[dt].isosurface(data, iso, r0, d, inclined=inc[0] if inc else None)
+        refs[dt].set_triangular(False)
         meta[name] = {"dtype": dt, "iso": iso, "shape": list(data.shape), "grid_fnv": orc.fnv(data),
                       "nV": S.nV, "nT": S.nT, "T_fnv": orc.fnv(S.T), "V_fnv": orc.fnv(S.V), "N_fnv": orc.fnv(S.N)}
         if full:

@@ -26,6 +26,13 @@ GENERATORS = {
     "u16_mod7_s1_iso3": lambda: (fx.noise_u16(32, 1, 7), None, None),
     "u16_cos_96x80x48_iso25268.5": lambda: (fx.cos_field_u16(96, 80, 48), None, None),
 }
+# non-orthogonal grids (MC33_spnC): name -> (matrices, mult_Abf is _multTSA_bf)
+INCLINED = {
+    "inclined_cos40_general": (fx.general_matrices(), False),
+    "inclined_cos40_cell_80_95_70": (fx.cell_matrices(80.0, 95.0, 70.0), True),
+}
+for _n in INCLINED:
+    GENERATORS[_n] = lambda: (fx.cos_field(40)[0], (-1.0, 0.5, 2.0), (0.2, 0.3, 0.45))
 assert set(GENERATORS) == set(GOLDEN)
 
 

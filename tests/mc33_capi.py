@@ -146,7 +146,7 @@ class MC33Lib:
         L.free_memory_grd.argtypes = [C.POINTER(GRD)]
 
     # -- grid ------------------------------------------------------------------------------
-    def make_grid(self, data, r0=None, d=None):
+    def make_grid(self, data, r0=None, d=None, inclined=None):
         """data: contiguous [Nz, Ny, Nx] array (x fastest), like grid_from_data_pointer expects
         (MC33_util_grd.c:585-627).  r0/d overwrite the origin / spacing afterwards, which is what
         generate_grid_from_fn stores (MC33_util_grd.c:656-657)."""
@@ -162,6 +162,12 @@ class MC33Lib:
             for k in range(3):
                 G.contents.d[k] = float(d[k])
                 G.contents.L[k] = float(d[k]) * G.contents.N[k]
+        if inclined is not None:  # what read_grd sets for cell angles != 90 (MC33_util_grd.c:218-236)
+            G.contents.nonortho = 1
+            for j in range(3):
+                for i in range(3):
+                    G.contents._A[j][i] = float(inclined[0][j][i])
+                    G.contents.A_[j][i] = float(inclined[1][j][i])
         return G, data  # keep `data` alive as long as G
 
     def copy_surface(self, S):
@@ -182,9 +188,16 @@ class MC33Lib:
             color = np.zeros((0,), np.int32)
         return Surface(nV, nT, V, N, T, color, s.iso, s.capv, s.capt)
 
-    def isosurface(self, data, iso, r0=None, d=None):
+    def set_triangular(self, on):
+        """Point the library's mult_Abf at _multTSA_bf (upper triangular cell matrix) or back at _multA_bf,
+        as a caller of the reference may (marching_cubes_33.h:186-191)."""
+        fp = C.c_void_p.in_dll(self.lib, "mult_Abf")
+        fn = self.lib._multTSA_bf if on else self.lib._multA_bf
+        fp.value = C.cast(fn, C.c_void_p).value
+
+    def isosurface(self, data, iso, r0=None, d=None, inclined=None):
         """The reference's usage snippet (marching_cubes_33.h:31-52) end to end."""
-        G, keep = self.make_grid(data, r0, d)
+        G, keep = self.make_grid(data, r0, d, inclined)
         try:
             M = self.lib.create_MC33(G)
             if not M:

@@ -25,6 +25,10 @@ class Oracle:
         L.mc33o_calculate_isosurface.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_float,
                                                  C.POINTER(OSURF)]
+        L.mc33o_calculate_isosurface_inclined.restype = C.c_int
+        L.mc33o_calculate_isosurface_inclined.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p,
+                                                          C.c_void_p, C.c_int, C.c_float, C.POINTER(OSURF)]
         L.mc33o_free_surface.argtypes = [C.POINTER(OSURF)]
         L.mc33o_classify.restype = C.c_int
         L.mc33o_classify.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]
@@ -32,13 +36,20 @@ class Oracle:
         L.mc33o_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
         L.mc33o_fill_cos_field.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double]
 
-    def isosurface(self, data, iso, r0=None, d=None):
+    def isosurface(self, data, iso, r0=None, d=None, inclined=None, triangular=False):
+        """inclined: (A, Ai) = the _GRD._A / _GRD.A_ matrices of a non-orthogonal grid (MC33_spnC)."""
         data = np.ascontiguousarray(data, dtype=self.np_dtype)
         nz, ny, nx = data.shape
         r0a = (C.c_double * 3)(*(r0 if r0 is not None else (0.0, 0.0, 0.0)))
         da = (C.c_double * 3)(*(d if d is not None else (1.0, 1.0, 1.0)))
         s = OSURF()
-        rc = self.lib.mc33o_calculate_isosurface(data.ctypes.data, nx, ny, nz, r0a, da, C.c_float(iso), C.byref(s))
+        if inclined is not None:
+            A = np.ascontiguousarray(inclined[0], np.float64)
+            Ai = np.ascontiguousarray(inclined[1], np.float64)
+            rc = self.lib.mc33o_calculate_isosurface_inclined(data.ctypes.data, nx, ny, nz, r0a, da, A.ctypes.data,
+                                                              Ai.ctypes.data, int(triangular), C.c_float(iso), C.byref(s))
+        else:
+            rc = self.lib.mc33o_calculate_isosurface(data.ctypes.data, nx, ny, nz, r0a, da, C.c_float(iso), C.byref(s))
         if rc:
             raise MemoryError("oracle failed")
 

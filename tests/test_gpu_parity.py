@@ -9,9 +9,9 @@ from parity import assert_surface_parity
 pytestmark = pytest.mark.gpu
 
 
-def check(products, reflibs, dtype, data, iso, r0=None, d=None, label=""):
-    got = products[dtype].isosurface(data, iso, r0, d)
-    ref = reflibs[dtype].isosurface(data, iso, r0, d)
+def check(products, reflibs, dtype, data, iso, r0=None, d=None, label="", inclined=None):
+    got = products[dtype].isosurface(data, iso, r0, d, inclined=inclined)
+    ref = reflibs[dtype].isosurface(data, iso, r0, d, inclined=inclined)
     extent = float(max(1.0, max(data.shape))) if d is None else float(max(abs(a) + abs(b) * n for a, b, n in zip(r0, d, data.shape[::-1])))
     ev, en, vb, nb = assert_surface_parity(got, ref, extent, label)
     print("%-28s nV %8d nT %8d  maxrel V %.2e N %.2e  bit-exact V %s N %s" % (label, got.nV, got.nT, ev, en, vb, nb))
@@ -64,6 +64,42 @@ def test_spacing_variants(products, reflibs):
     check(products, reflibs, "f32", data, 0.1, (1, 2, 3), (0.5, 0.25, 1.0), "spnB anisotropic")
     check(products, reflibs, "f32", data, 0.1, (1, 2, 3), (0.5, 0.5, 0.5), "spnA")
     check(products, reflibs, "f32", data, 0.1, (0, 0, 0), (1, 1, 1), "spn0")
+
+
+@pytest.mark.parametrize("triangular", [False, True])
+def test_inclined_grids(products, reflibs, triangular):
+    """Non-orthogonal grids: MC33_spnC (reference marching_cubes_33.c:587-621) with both forms of mult_Abf
+    (MC33_util_grd.c:86-112); the caller selects the form by pointing mult_Abf at it."""
+    mats = fx.cell_matrices(80.0, 95.0, 70.0) if triangular else fx.general_matrices()
+    libs = list(products.values()) + list(reflibs.values())
+    for lib in libs:
+        lib.set_triangular(triangular)
+    try:
+        data, r0, _ = fx.cos_field(48)
+        for d in ((0.25, 0.25, 0.25), (0.2, 0.3, 0.45)):
+            got = check(products, reflibs, "f32", data, 0.1, r0, d, "inclined cos48", inclined=mats)
+            assert got.nV > 5000
+        check(products, reflibs, "f32", fx.noise_quant(24, 2), 1.0, (1.0, 2.0, 3.0), (0.5, 0.5, 0.5), "inclined degenerate", inclined=mats)
+        check(products, reflibs, "u16", fx.noise_u16(24, 3, 7), 3.0, (1.0, 2.0, 3.0), (0.5, 0.25, 0.5), "inclined u16", inclined=mats)
+    finally:
+        for lib in libs:
+            lib.set_triangular(False)
+
+
+def test_inclined_grid_rejects_foreign_matrix_function(products):
+    """mult_Abf pointing at a function of the caller cannot run on the GPU: NULL + memoryfault, no silent
+    substitution."""
+    import ctypes as C
+    lib = products["f32"]
+    fp = C.c_void_p.in_dll(lib.lib, "mult_Abf")
+    old = fp.value
+    fp.value = C.cast(lib.lib.free_MC33, C.c_void_p).value  # any address that is neither of the two forms
+    try:
+        data, r0, d = fx.cos_field(17)
+        with pytest.raises(MemoryError):
+            lib.isosurface(data, 0.1, r0, d, inclined=fx.general_matrices())
+    finally:
+        fp.value = old
 
 
 @pytest.mark.parametrize("name", ["tangle", "torus3", "decocube", "gyroid"])

@@ -19,7 +19,7 @@ def _same(a, b):
     return (a.nV, a.nT) == (b.nV, b.nT) and np.array_equal(a.T, b.T) and bits_equal(a.V, b.V) and bits_equal(a.N, b.N)
 
 
-@pytest.mark.parametrize("name", [n for n in sorted(GOLDEN) if n not in ("cos256",)])
+@pytest.mark.parametrize("name", [n for n in sorted(GOLDEN) if n not in ("cos256",) and not n.startswith("inclined")])
 def test_formulation_matches_golden(emus, oracles, name):
     data, r0, d = GENERATORS[name]()
     dt = GOLDEN[name]["dtype"]

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import fixtures as fx
-from golden_cases import GENERATORS, GOLDEN, check_against_golden
+from golden_cases import GENERATORS, GOLDEN, INCLINED, check_against_golden
 from parity import bits_equal
 
 
@@ -13,7 +13,9 @@ from parity import bits_equal
 def test_oracle_matches_golden(oracles, name):
     data, r0, d = GENERATORS[name]()
     o = oracles[GOLDEN[name]["dtype"]]
-    check_against_golden(name, o.isosurface(data, GOLDEN[name]["iso"], r0, d), o.fnv, data)
+    inc = INCLINED.get(name)
+    s = o.isosurface(data, GOLDEN[name]["iso"], r0, d, inclined=inc[0] if inc else None, triangular=bool(inc and inc[1]))
+    check_against_golden(name, s, o.fnv, data)
 
 
 def _same(a, b):
@@ -66,3 +68,24 @@ def test_oracle_readme_known_answers(oracles):
     e = np.sort(np.concatenate([s.T[:, [0, 1]], s.T[:, [1, 2]], s.T[:, [2, 0]]]), axis=1)
     _, counts = np.unique(e, axis=0, return_counts=True)
     assert np.all(counts == 2) and s.T.max() == s.nV - 1
+
+
+@pytest.mark.parametrize("triangular", [False, True])
+def test_oracle_bit_exact_vs_reference_inclined_grid(oracles, reflibs, triangular):
+    """Non-orthogonal grids (MC33_spnC, reference marching_cubes_33.c:587-621): positions and normals go through
+    the cell matrices in double; both forms of mult_Abf (MC33_util_grd.c:86-112)."""
+    mats = fx.cell_matrices(80.0, 95.0, 70.0) if triangular else fx.general_matrices()
+    for lib in reflibs.values():
+        lib.set_triangular(triangular)
+    try:
+        data, r0, _ = fx.cos_field(24)
+        for d in ((0.25, 0.25, 0.25), (0.2, 0.3, 0.45)):
+            ref = reflibs["f32"].isosurface(data, 0.1, r0, d, inclined=mats)
+            assert ref.nV > 1000
+            assert _same(oracles["f32"].isosurface(data, 0.1, r0, d, inclined=mats, triangular=triangular), ref)
+        q = fx.noise_u16(20, 3, 7)
+        ref = reflibs["u16"].isosurface(q, 3.0, (1.0, 2.0, 3.0), (0.5, 0.5, 0.5), inclined=mats)
+        assert _same(oracles["u16"].isosurface(q, 3.0, (1.0, 2.0, 3.0), (0.5, 0.5, 0.5), inclined=mats, triangular=triangular), ref)
+    finally:
+        for lib in reflibs.values():
+            lib.set_triangular(False)
