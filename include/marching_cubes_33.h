@@ -114,6 +114,13 @@ void free_MC33(MC33 *M);
 void free_surface_memory(surface *S);
 void adjustvectorlenght_s(surface *S);
 
+/* --- surface files (reference header :193-222), host C: csrc/mc33_surface_io.c -------------------- */
+int write_bin_s(surface *S, const char *filename);   /* ".sup" binary container; 0 on success, -1 on failure */
+surface *read_bin_s(const char *filename);           /* NULL on failure; also reads ".sud" (double) files      */
+int write_txt_s(surface *S, const char *filename);
+int write_obj_s(surface *S, const char *filename);   /* Wavefront OBJ with per-vertex normals                  */
+int write_ply_s(surface *S, const char *filename, const char *author, const char *object); /* ASCII PLY       */
+
 /* --- grid container helpers (reference header :263-329), host C ---------------------------------- */
 void free_memory_grd(_GRD *Z);
 int alloc_F(_GRD *Z);
@@ -122,6 +129,14 @@ _GRD *generate_grid_from_fn(double x_initial, double y_initial, double z_initial
                             double x_final, double y_final, double z_final,
                             double x_step, double y_step, double z_step,
                             double (*fn)(double x, double y, double z));
+
+
+/* --- grid file readers (reference header :263-311), host C: csrc/mc33_grid_io.c; NULL on failure --------- */
+_GRD *read_grd(const char *filename);                  /* DMol .grd text file (may describe an inclined cell)  */
+_GRD *read_grd_binary(const char *filename);           /* the library's own binary container ("_GRD")          */
+_GRD *read_scanfiles(const char *filename, unsigned int res, int order); /* numbered res x res u16 slices       */
+_GRD *read_raw_file(const char *filename, unsigned int *N, int byte, int isfloat); /* bare samples, N = points  */
+_GRD *read_dat_file(const char *filename);             /* u16 nx, ny, nz header + u16 samples                  */
 
 #ifdef __cplusplus
 }

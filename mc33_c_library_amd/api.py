@@ -38,7 +38,9 @@ HIP_API = ["mc33hip_set_id_base", "mc33hip_create", "mc33hip_destroy", "mc33hip_
            "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined"]
 REFERENCE_API = ["create_MC33", "calculate_isosurface", "size_of_isosurface", "free_MC33", "free_surface_memory",
                  "adjustvectorlenght_s", "DefaultColorMC", "free_memory_grd", "alloc_F", "grid_from_data_pointer",
-                 "generate_grid_from_fn", "_multTSA_bf", "_multA_bf", "mult_Abf"]
+                 "generate_grid_from_fn", "_multTSA_bf", "_multA_bf", "mult_Abf",
+                 "write_bin_s", "read_bin_s", "write_txt_s", "write_obj_s", "write_ply_s",
+                 "read_grd", "read_grd_binary", "read_scanfiles", "read_raw_file", "read_dat_file"]
 
 
 class MC33Error(RuntimeError):

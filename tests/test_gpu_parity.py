@@ -183,3 +183,40 @@ def test_config4_u16_wide_rows(products, reflibs):
     data = fx.cos_field_u16(2048, 96, 40)
     for k in (0, 3, 7):
         check(products, reflibs, "u16", data, 15268.5 + 5000.0 * k, label="u16 2048-wide iso#%d" % k)
+
+
+def test_file_to_file_pipeline(products, reflibs, tmp_path):
+    """The examples' whole flow (reference GLUT_example/TestMC33_glut.c:800-1000): read a grid file, extract,
+    write the surface.  An inclined DMol .grd text grid through read_grd -> create_MC33 -> calculate_isosurface ->
+    write_bin_s / write_ply_s; the files of the product and of the reference must be identical."""
+    import ctypes as C
+    from test_grid_io import declare as declare_grid, write_grd_text
+    from test_surface_io import declare as declare_surf
+    import mc33_capi
+    N = (30, 26, 22)
+    data, _, _ = fx.cos_field(40)
+    vals = data[:N[2] + 1, :N[1] + 1, :N[0] + 1].astype(np.float64)
+    path = str(tmp_path / "cell.grd")
+    write_grd_text(path, N, (6.0, 5.2, 4.4), (80.0, 95.0, 70.0), (0, 0, 0), 3, vals.ravel())
+    out = {}
+    for tag, lib in (("p", products["f32"]), ("r", reflibs["f32"])):
+        L = declare_grid(lib)
+        declare_surf(lib)
+        lib.set_triangular(True)  # what the examples do for .grd cells (upper triangular matrices)
+        try:
+            G = L.read_grd(path.encode())
+            assert G and G.contents.nonortho == 1
+            M = L.create_MC33(G)
+            assert M
+            S = L.calculate_isosurface(M, C.c_float(0.2))
+            assert S and S.contents.nV > 1000
+            a, b = str(tmp_path / (tag + ".sup")).encode(), str(tmp_path / (tag + ".ply")).encode()
+            assert L.write_bin_s(S, a) == 0 and L.write_ply_s(S, b, b"test", b"inclined cell") == 0
+            out[tag] = (open(a, "rb").read(), open(b, "rb").read())
+            L.free_surface_memory(S)
+            L.free_MC33(M)
+            L.free_memory_grd(G)
+        finally:
+            lib.set_triangular(False)
+    assert out["p"][0] == out["r"][0], "binary surface files differ"
+    assert out["p"][1] == out["r"][1], "PLY files differ"
