@@ -1,4 +1,4 @@
-/* marching_cubes_33.h -- public C API of the MI355X-native MC33 library (libMC33_f32.so / libMC33_u16.so).
+/* marching_cubes_33.h -- public C API of the MI355X-native MC33 library (libMC33_{f32,u8,u16,u32}.so).
  *
  * Binary- and source-compatible with the header of dvega68/MC33_c_library (reference
  * include/marching_cubes_33.h): same type names, same struct layouts (checked by static asserts in
@@ -8,8 +8,11 @@
  *
  * Compile-time variants, as in the reference (reference header :57-88):
  *   default                         GRD_data_type = float,          MC33_real = float
+ *   -DINTEGER_GRD -DGRD_TYPE_SIZE=1 GRD_data_type = unsigned char,  MC33_real = float
  *   -DINTEGER_GRD -DGRD_TYPE_SIZE=2 GRD_data_type = unsigned short, MC33_real = float
- * Other grid types (uchar, uint, double) and GRD_ORTHOGONAL are not built yet (out of scope).
+ *   -DINTEGER_GRD -DGRD_TYPE_SIZE=4 GRD_data_type = unsigned int,   MC33_real = float
+ * One library per variant, like the reference's one-type-per-compile model.  Double grids (MC33_real = double)
+ * and GRD_ORTHOGONAL are not built (out of scope).
  */
 #ifndef marching_cubes_33_h
 #define marching_cubes_33_h
@@ -18,11 +21,15 @@
 #define MC33C_VERSION_MINOR 5
 
 #if defined(INTEGER_GRD)
-#  if GRD_TYPE_SIZE == 2
-typedef unsigned short int GRD_data_type;
 typedef float MC33_real;
+#  if GRD_TYPE_SIZE == 4
+typedef unsigned int GRD_data_type;
+#  elif GRD_TYPE_SIZE == 2
+typedef unsigned short int GRD_data_type;
+#  elif GRD_TYPE_SIZE == 1
+typedef unsigned char GRD_data_type;
 #  else
-#    error "this build provides INTEGER_GRD only with GRD_TYPE_SIZE == 2 (unsigned short)"
+#    error "INTEGER_GRD needs GRD_TYPE_SIZE 1, 2 or 4"
 #  endif
 #elif defined(GRD_TYPE_SIZE) && GRD_TYPE_SIZE == 8
 #  error "double grids are not provided by this build"

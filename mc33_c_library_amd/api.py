@@ -108,8 +108,12 @@ class DeviceGrid:
             self.dtype, sb = "f32", 4
         elif tensor.dtype in (torch.int16, torch.uint16):
             self.dtype, sb = "u16", 2
+        elif tensor.dtype == torch.uint8:
+            self.dtype, sb = "u8", 1
+        elif tensor.dtype in (torch.int32, torch.uint32):
+            self.dtype, sb = "u32", 4
         else:
-            raise TypeError("grid samples must be float32 or (u)int16")
+            raise TypeError("grid samples must be float32, uint8, (u)int16 or (u)int32 bit patterns")
         self.lib = load_library(self.dtype)
         self.tensor = tensor  # keeps the memory alive
         npz, npy, pitch = tensor.shape[0], tensor.shape[1], tensor.stride(1)

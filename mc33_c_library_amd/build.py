@@ -27,6 +27,8 @@ C_FLAGS = ["-O2", "-ffp-contract=off", "-std=c11", "-fPIC", "-Wall", "-Wextra"]
 VARIANTS = {
     "f32": {"hip": [], "c": []},
     "u16": {"hip": ["-DMC33_GRD_U16"], "c": ["-DINTEGER_GRD", "-DGRD_TYPE_SIZE=2"]},
+    "u8": {"hip": ["-DMC33_GRD_U8"], "c": ["-DINTEGER_GRD", "-DGRD_TYPE_SIZE=1"]},
+    "u32": {"hip": ["-DMC33_GRD_U32"], "c": ["-DINTEGER_GRD", "-DGRD_TYPE_SIZE=4"]},
 }
 
 
@@ -76,7 +78,10 @@ def build(dtype, force=False, verbose_resources=False):
 
 
 def build_all(force=False):
-    return [build(d, force) for d in VARIANTS]
+    """All variants; the HIP translation units are compiled side by side (minutes each)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
+        return list(ex.map(lambda d: build(d, force), VARIANTS))
 
 
 if __name__ == "__main__":

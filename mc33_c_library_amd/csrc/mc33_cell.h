@@ -81,6 +81,9 @@ MC33_HD float sample_diff(float a, float b) { return a - b; }
 // unsigned short promotes to int in the reference's expressions (e.g. MC:851); the difference meets
 // a float operand only afterwards
 MC33_HD float sample_diff(uint16_t a, uint16_t b) { return (float)((int)a - (int)b); }
+MC33_HD float sample_diff(uint8_t a, uint8_t b) { return (float)((int)a - (int)b); }
+// unsigned int does not promote: the difference wraps modulo 2^32 before it becomes a float
+MC33_HD float sample_diff(uint32_t a, uint32_t b) { return (float)(uint32_t)(a - b); }
 
 MC33_HD uint32_t sign_of(float f) { return __builtin_bit_cast(uint32_t, f) >> 31; }  // MC:406-408
 

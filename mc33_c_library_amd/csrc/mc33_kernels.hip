@@ -31,9 +31,15 @@
 
 using namespace mc33;
 
-#ifdef MC33_GRD_U16
+#if defined(MC33_GRD_U16)
 typedef uint16_t sample_t;
 #define MC33_SAMPLE_BYTES 2
+#elif defined(MC33_GRD_U8)
+typedef uint8_t sample_t;
+#define MC33_SAMPLE_BYTES 1
+#elif defined(MC33_GRD_U32)
+typedef uint32_t sample_t;
+#define MC33_SAMPLE_BYTES 4
 #else
 typedef float sample_t;
 #define MC33_SAMPLE_BYTES 4
@@ -196,8 +202,12 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	const uint32_t NB = (nrows + 3u) / 4u;
 	const uint32_t T = (z_hi - z_lo + 1u) * NB;
 	const uint32_t tile_bytes = nrows * rowbytes;
-#ifdef MC33_GRD_U16
+#if defined(MC33_GRD_U16)
 #define MC33_LOAD(rs, vo, so) ((float)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0))
+#elif defined(MC33_GRD_U8)
+#define MC33_LOAD(rs, vo, so) ((float)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rs, vo, so, 0))
+#elif defined(MC33_GRD_U32)
+#define MC33_LOAD(rs, vo, so) ((float)(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0))
 #else
 #define MC33_LOAD(rs, vo, so) (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0)))
 #endif

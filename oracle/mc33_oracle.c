@@ -154,10 +154,13 @@ static inline mc33o_sample sample(const oracle_ctx *c, uint32_t x, uint32_t y, u
 }
 
 /* difference of two samples as the reference's expression yields it: float for float grids,
- * int (then converted) for unsigned short grids (integer promotion) */
+ * int (then converted) for unsigned char / short grids (integer promotion), unsigned modulo 2^32 for
+ * unsigned int grids (no promotion) */
 static inline float sdiff(mc33o_sample a, mc33o_sample b) {
-#ifdef MC33_ORACLE_U16
+#if defined(MC33_ORACLE_U16) || defined(MC33_ORACLE_U8)
 	return (float)((int)a - (int)b);
+#elif defined(MC33_ORACLE_U32)
+	return (float)(uint32_t)(a - b);
 #else
 	return a - b;
 #endif

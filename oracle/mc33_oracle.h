@@ -11,8 +11,12 @@
 #define MC33_ORACLE_H
 #include <stdint.h>
 
-#ifdef MC33_ORACLE_U16
+#if defined(MC33_ORACLE_U16)
 typedef uint16_t mc33o_sample; /* INTEGER_GRD, GRD_TYPE_SIZE 2 (marching_cubes_33.h:66-75) */
+#elif defined(MC33_ORACLE_U8)
+typedef uint8_t mc33o_sample;  /* INTEGER_GRD, GRD_TYPE_SIZE 1 (marching_cubes_33.h:75-76) */
+#elif defined(MC33_ORACLE_U32)
+typedef uint32_t mc33o_sample; /* INTEGER_GRD, GRD_TYPE_SIZE 4 (marching_cubes_33.h:68-72) */
 #else
 typedef float mc33o_sample;    /* default float grid (marching_cubes_33.h:84-85) */
 #endif

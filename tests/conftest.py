@@ -14,6 +14,9 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+DTYPES = ("f32", "u16", "u8", "u32")  # one library per GRD_data_type, like the reference's compile-time variants
+
+
 def _have(path):
     return os.path.exists(path)
 
@@ -24,7 +27,7 @@ def reflibs():
     from mc33_capi import MC33Lib, ref_path
     if not _have(ref_path("f32")):
         pytest.skip("oracle/_ref not built (run python -c 'import __graft_entry__ as g; g.build()')")
-    return {"f32": MC33Lib(ref_path("f32"), "f32"), "u16": MC33Lib(ref_path("u16"), "u16")}
+    return {d: MC33Lib(ref_path(d), d) for d in DTYPES if _have(ref_path(d))}
 
 
 @pytest.fixture(scope="session")
@@ -32,7 +35,7 @@ def oracles():
     from mc33_oracle import Oracle, oracle_path
     if not _have(oracle_path("f32")):
         pytest.skip("oracle library not built")
-    return {"f32": Oracle("f32"), "u16": Oracle("u16")}
+    return {d: Oracle(d) for d in DTYPES if _have(oracle_path(d))}
 
 
 @pytest.fixture(scope="session")
@@ -40,4 +43,6 @@ def products():
     """The product libraries through the reference's own C API (GPU needed to call into them)."""
     from mc33_capi import MC33Lib, product_path
     assert _have(product_path("f32")), "libMC33_f32.so missing: the HIP extension must be built (no fallback)"
-    return {"f32": MC33Lib(product_path("f32"), "f32"), "u16": MC33Lib(product_path("u16"), "u16")}
+    for d in DTYPES:
+        assert _have(product_path(d)), "libMC33_%s.so missing: the HIP extension must be built (no fallback)" % d
+    return {d: MC33Lib(product_path(d), d) for d in DTYPES}

@@ -121,3 +121,26 @@ def general_matrices(seed=5):
     rng = np.random.RandomState(seed)
     A = np.eye(3) + 0.3 * rng.uniform(-1, 1, (3, 3))
     return A, np.linalg.inv(A)
+
+
+def noise_u8(n, seed, mod=None, shape=None):
+    """uchar noise: r & 0xFF, or r % mod (few distinct values: many samples equal an integer isovalue)."""
+    shape = shape or (n, n, n)
+    s = lcg_stream(int(np.prod(shape)), seed)
+    v = (s % np.uint32(mod)) if mod else (s & np.uint32(0xFF))
+    return v.astype(np.uint8).reshape(shape)
+
+
+def noise_u32(n, seed, mod=None, shape=None):
+    """uint noise over the whole 32-bit range (differences wrap modulo 2^32 in the reference's normal formulas,
+    SURVEY.md Appendix G), or r % mod."""
+    shape = shape or (n, n, n)
+    s = lcg_stream(int(np.prod(shape)), seed)
+    v = (s % np.uint32(mod)) if mod else (s * np.uint32(2654435761))
+    return v.astype(np.uint32).reshape(shape)
+
+
+def cos_field_int(n, dtype, amp, mid):
+    """cos x + cos y + cos z on [-4, 4]^3 quantised to an unsigned integer type: mid + amp * f."""
+    f, _, _ = cos_field(n, dtype=np.float64)
+    return np.rint(mid + amp * f).astype(dtype)

@@ -3,8 +3,8 @@
 Test infrastructure.  The SAME binding drives three different shared objects, because all of them
 export the reference's C API:
 
-  * oracle/_ref/libMC33ref_{f32,u16}.so  - the unmodified reference (built by oracle/Makefile)
-  * mc33_c_library_amd/libMC33_{f32,u16}.so - the product (HIP kernels behind the C-ABI shim)
+  * oracle/_ref/libMC33ref_{f32,u8,u16,u32}.so  - the unmodified reference (built by oracle/Makefile)
+  * mc33_c_library_amd/libMC33_{f32,u8,u16,u32}.so - the product (HIP kernels behind the C-ABI shim)
 
 so a parity test reads like "run the reference's own usage snippet twice and diff the surfaces".
 """
@@ -116,13 +116,16 @@ class Surface:
         self.color, self.iso, self.capv, self.capt = color, iso, capv, capt
 
 
+NP_DTYPES = {"f32": np.float32, "u8": np.uint8, "u16": np.uint16, "u32": np.uint32}  # GRD_data_type per library
+
+
 class MC33Lib:
-    """Any shared object exporting the reference C API, for one GRD_data_type ('f32' or 'u16')."""
+    """Any shared object exporting the reference C API, for one GRD_data_type ('f32', 'u8', 'u16', 'u32')."""
 
     def __init__(self, path, dtype="f32"):
         self.path = path
         self.dtype = dtype
-        self.np_dtype = np.float32 if dtype == "f32" else np.uint16
+        self.np_dtype = NP_DTYPES[dtype]
         if os.path.basename(path).startswith("libMC33_"):
             preload_torch()
         # RTLD_LOCAL (default): several of these libraries define the same symbols.

@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from mc33_capi import ROOT, Surface
+from mc33_capi import NP_DTYPES, ROOT, Surface
 
 
 class OSURF(C.Structure):
@@ -18,7 +18,7 @@ def oracle_path(dtype="f32"):
 class Oracle:
     def __init__(self, dtype="f32"):
         self.dtype = dtype
-        self.np_dtype = np.float32 if dtype == "f32" else np.uint16
+        self.np_dtype = NP_DTYPES[dtype]
         self.lib = C.CDLL(oracle_path(dtype))
         L = self.lib
         L.mc33o_calculate_isosurface.restype = C.c_int

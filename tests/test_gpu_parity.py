@@ -220,3 +220,15 @@ def test_file_to_file_pipeline(products, reflibs, tmp_path):
             lib.set_triangular(False)
     assert out["p"][0] == out["r"][0], "binary surface files differ"
     assert out["p"][1] == out["r"][1], "PLY files differ"
+
+
+@pytest.mark.parametrize("seed", [1, 4])
+def test_uchar_and_uint_grids(products, reflibs, seed):
+    """GRD_TYPE_SIZE 1 and 4 libraries (reference marching_cubes_33.h:66-79), including samples equal to the
+    isovalue and uint differences that wrap modulo 2^32 in the normals."""
+    for data, iso in ((fx.noise_u8(24, seed), 127.5), (fx.noise_u8(24, seed), 128.0), (fx.noise_u8(24, seed, 5), 2.0),
+                      (fx.cos_field_int(70, np.uint8, 40.0, 128.0), 130.5), (fx.noise_u8(0, seed, shape=(3, 5, 300)), 100.0)):
+        check(products, reflibs, "u8", data, iso, label="u8")
+    for data, iso in ((fx.noise_u32(24, seed), 2147483648.0), (fx.noise_u32(24, seed, 7), 3.0), (fx.noise_u32(24, seed, 7), 2.5),
+                      (fx.cos_field_int(70, np.uint32, 0.6e9, 2.0e9), 2.2e9)):
+        check(products, reflibs, "u32", data, iso, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0), label="u32")

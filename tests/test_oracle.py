@@ -89,3 +89,17 @@ def test_oracle_bit_exact_vs_reference_inclined_grid(oracles, reflibs, triangula
     finally:
         for lib in reflibs.values():
             lib.set_triangular(False)
+
+
+@pytest.mark.parametrize("seed", [1, 4])
+def test_oracle_bit_exact_vs_reference_uchar_and_uint(oracles, reflibs, seed):
+    """GRD_TYPE_SIZE 1 and 4 (reference marching_cubes_33.h:66-79): uchar promotes to int like ushort; uint
+    differences wrap modulo 2^32 before they meet a float."""
+    for data, iso in ((fx.noise_u8(20, seed), 127.5), (fx.noise_u8(20, seed), 128.0), (fx.noise_u8(20, seed, 5), 2.0),
+                      (fx.cos_field_int(24, np.uint8, 40.0, 128.0), 130.5)):
+        assert _same(oracles["u8"].isosurface(data, iso), reflibs["u8"].isosurface(data, iso))
+    for data, iso in ((fx.noise_u32(20, seed), 2147483648.0), (fx.noise_u32(20, seed, 7), 3.0), (fx.noise_u32(20, seed, 7), 2.5),
+                      (fx.cos_field_int(24, np.uint32, 0.6e9, 2.0e9), 2.2e9)):
+        ref = reflibs["u32"].isosurface(data, iso, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0))
+        assert ref.nV > 100
+        assert _same(oracles["u32"].isosurface(data, iso, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0)), ref)
