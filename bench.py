@@ -259,13 +259,15 @@ def main():
                 "frac": (grid_bytes_alg / (sw * 1e-3) / 1e9 / PEAK_HBM_GBS) if sw else None,
                 "traffic": None,
                 "algorithmic_bytes_per_launch": grid_bytes_alg,
-                "kernel_ms": {"k_sweep": sw, "k_scan_x3": avg(scan_ms), "k_emit": avg(emit_ms)},
+                # hipEvent brackets of the library: the sweep alone; k_cells + slow-cell planning + the 3 scan
+                # kernels; the three emit kernels (running side by side on 3 streams)
+                "kernel_ms": {"k_sweep": sw, "k_cells_slow_scans": avg(scan_ms), "k_emit_x3": avg(emit_ms) if emit_ms else None},
                 "whole_call": {"algorithmic_bytes": grid_bytes_alg + out_bytes,
                                "device_ms": sw + avg(scan_ms) + avg(emit_ms),
                                "frac": ((grid_bytes_alg + out_bytes) / ((sw + avg(scan_ms) + avg(emit_ms)) * 1e-3) / 1e9 / PEAK_HBM_GBS)
                                if sw else None}}
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and world == 1 and n == 1024:  # the counters were collected on this workload
             try:
                 roof["traffic"] = json.load(open(pmc)).get("k_sweep_bytes_per_launch")
             except Exception:

@@ -332,6 +332,7 @@ struct CellsArgs {
 	uint32_t ze, nYT, nseg_pad;
 	const SliceHeader *slice_hdr;
 	const uint4 *slice_bits;
+	uint2 *slot_dir;         // [slice_slot]: {first work record, number of records} of the slice (emit pass)
 	uint32_t *seg_cnt;
 	SegDir *seg_dir;
 	uint64_t *seg_mask;
@@ -359,7 +360,8 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
 	const uint32_t z = P.zs + zq * 4u + wv;
 	const uint32_t y = y0 + lane;
-	bool live = seg < P.nseg && z < a.ze;
+	const bool in_grid = seg < P.nseg && z < a.ze;
+	bool live = in_grid;
 	SliceHeader h;
 	h.flags = 0;
 	uint4 q[4] = {};
@@ -417,11 +419,15 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		}
 	}
 	__syncthreads();
-	if (!total) return;  // wave-uniform (no barrier below)
+	if (!total) {  // wave-uniform (no barrier below)
+		if (in_grid && lane == 0) a.slot_dir[slot] = uint2{0u, 0u};
+		return;
+	}
 	uint32_t ebase = s_base[0], mbase = s_base[1];
 	const unsigned long long t_alloc = a.trace ? __builtin_amdgcn_s_memrealtime() + (ebase & 0u) : 0ull;
 	for (uint32_t q = 0; q < wv; q++) { ebase += s_tot[q]; mbase += s_nm[q]; }
 
+	if (lane == 0) a.slot_dir[slot] = uint2{ebase, total};
 	const uint64_t sidx = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y;  // storage order [z][segment][y]
 	const uint32_t first = ebase + incl - cnt;
 	const uint32_t maskidx = mbase + (uint32_t)__popcll(havem & ((1ull << lane) - 1ull));
@@ -744,7 +750,53 @@ struct EmitArgs {
 	uint64_t capV, capT;
 	uint64_t ghost_segs;  // row segments of the ghost slice (0 without ghost)
 	uint32_t id_base;
+	const uint2 *slot_dir;   // [slice_slot]: {first record, records} per (slice, y tile, row segment)
+	uint32_t nYT, nseg_pad, z_end;
+	uint32_t linear;         // MC33_HIP_EMIT_LINEAR (measurement): walk the records in storage order instead
 };
+
+// The fast emit passes walk the records by (cell slice, y tile): one block takes the records of ALL row
+// segments of that slab piece, because their vertices (and triangles) are neighbours in the output arrays
+// (ids run z -> y -> x): the block then writes whole cache lines.  With one wave per record range the
+// 12-byte pieces of a line came from blocks on different XCDs, every L2 wrote its part back separately and
+// the vertex pass wrote 2.7x its algorithmic bytes (WRITE_SIZE 250 MB for 94 MB of V and N at 1024^3).
+struct RecordWalk {
+	uint32_t s_first[64], s_pre[65];
+};
+template <class F>
+__device__ __forceinline__ void walk_records(const EmitArgs &a, const Params &P, uint32_t z_first, RecordWalk &w, F &&body) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t groups = (a.z_end - z_first) * a.nYT;
+	for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
+		const uint32_t z = z_first + g / a.nYT, yt = g % a.nYT;
+		for (uint32_t seg0 = 0; seg0 < P.nseg; seg0 += 64u) {
+			const uint32_t nsg = min(64u, P.nseg - seg0);
+			__syncthreads();  // the previous chunk's table is no longer read
+			if (threadIdx.x < 64u) {
+				const uint2 d = lane < nsg ? a.slot_dir[slice_slot(z - P.zs, yt, seg0 + lane, a.nYT, a.nseg_pad)] : uint2{0u, 0u};
+				uint32_t incl = d.y;
+#pragma unroll
+				for (int dlt = 1; dlt < 64; dlt <<= 1) {
+					const uint32_t t = __shfl_up(incl, dlt);
+					if ((int)lane >= dlt) incl += t;
+				}
+				w.s_first[lane] = d.x;
+				w.s_pre[lane + 1] = incl;
+				if (lane == 0) w.s_pre[0] = 0;
+			}
+			__syncthreads();
+			const uint32_t total = w.s_pre[nsg];
+			for (uint32_t i = threadIdx.x; i < total; i += 256u) {
+				uint32_t lo = 0, hi = nsg;  // the segment with s_pre[seg] <= i < s_pre[seg + 1]
+				while (hi - lo > 1u) {
+					const uint32_t mid = (lo + hi) >> 1;
+					if (i >= w.s_pre[mid]) lo = mid; else hi = mid;
+				}
+				body(w.s_first[lo] + (i - w.s_pre[lo]));
+			}
+		}
+	}
+}
 
 // capacity / overflow check shared by both emit kernels; fills the slab offsets of the context
 __device__ __forceinline__ bool emit_prepare(const EmitArgs &a, EmitCtx<sample_t> &c, const Counters &ctr) {
@@ -765,12 +817,19 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
-	const uint32_t n = ctr.entry_cursor;
-	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
-		const Entry en = c.entries[e];
-		if (en.w3 & ENTRY_SLOW) continue;
-		emit_fast_vertices(c, en, c.entry_seg[e]);
+	__shared__ RecordWalk walk;
+	if (a.linear) {
+		const uint32_t n = ctr.entry_cursor;
+		for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+			const Entry en = c.entries[e];
+			if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, c.entry_seg[e]);
+		}
+		return;
 	}
+	walk_records(a, c.P, max(c.z_emit, c.P.zs), walk, [&](uint32_t e) {
+		const Entry en = c.entries[e];
+		if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, c.entry_seg[e]);
+	});
 }
 
 // triangles of the fast records (ids of shared edges through the owners' records)
@@ -780,12 +839,19 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
-	const uint32_t n = ctr.entry_cursor;
-	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
-		const Entry en = c.entries[e];
-		if (en.w3 & ENTRY_SLOW) continue;
-		emit_fast_triangles(c, en, c.entry_seg[e], e, ids);
+	__shared__ RecordWalk walk;
+	if (a.linear) {
+		const uint32_t n = ctr.entry_cursor;
+		for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+			const Entry en = c.entries[e];
+			if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, c.entry_seg[e], e, ids);
+		}
+		return;
 	}
+	walk_records(a, c.P, max(c.z_emit, c.P.zs), walk, [&](uint32_t e) {
+		const Entry en = c.entries[e];
+		if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, c.entry_seg[e], e, ids);
+	});
 }
 
 __global__ __launch_bounds__(256) void k_emit_slow(const EmitArgs a) {
@@ -844,6 +910,7 @@ struct mc33hip_ctx {
 	uint64_t entry_cap;
 	SliceHeader *slice_hdr;   // one record per (wave tile, cell slice) of the sweep
 	uint4 *slice_bits;
+	uint2 *slot_dir;
 	uint64_t slice_cap;
 	SweepTile *d_tiles;       // block plan of k_sweep for the current range
 	uint64_t tiles_cap, ntiles;
@@ -938,7 +1005,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base); (void)hipFree(c->seg_mask);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
 	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
-	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->d_tiles);
+	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->slot_dir); (void)hipFree(c->d_tiles);
 	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
@@ -1210,10 +1277,14 @@ static int enqueue_count(mc33hip_ctx *c) {
 	if (cell_blocks > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
 	const uint64_t nslots = cell_blocks * 4;
 	if (c->slice_cap < nslots) {
-		(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits);
-		c->slice_hdr = nullptr; c->slice_bits = nullptr; c->slice_cap = 0;
+		(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->slot_dir);
+		c->slice_hdr = nullptr; c->slice_bits = nullptr; c->slot_dir = nullptr; c->slice_cap = 0;
 		HIP_TRY(hipMalloc(&c->slice_hdr, nslots * sizeof(SliceHeader)));
 		HIP_TRY(hipMalloc(&c->slice_bits, nslots * 4096));
+		HIP_TRY(hipMalloc(&c->slot_dir, nslots * sizeof(uint2)));
+		if (getenv("MC33_HIP_VERBOSE"))
+			fprintf(stderr, "[mc33hip] slice records: hdr %p bits %p dir %p (%llu slots), grid %p\n", (void *)c->slice_hdr, (void *)c->slice_bits,
+			        (void *)c->slot_dir, (unsigned long long)nslots, (void *)c->d_grid);
 		c->slice_cap = nslots;
 	}
 	a.slice_hdr = c->slice_hdr; a.slice_bits = c->slice_bits;
@@ -1238,7 +1309,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	CellsArgs ca;
 	ca.P = P; ca.fast = c->d_fast;
 	ca.ze = ze; ca.nYT = a.nYT; ca.nseg_pad = a.nseg_pad;
-	ca.slice_hdr = c->slice_hdr; ca.slice_bits = c->slice_bits;
+	ca.slice_hdr = c->slice_hdr; ca.slice_bits = c->slice_bits; ca.slot_dir = c->slot_dir;
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir; ca.seg_mask = c->seg_mask;
 	ca.entries = c->entries; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
 	ca.entry_cap = (uint32_t)c->entry_cap;
@@ -1290,7 +1361,14 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.capV = capV; a.capT = capT;
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
-	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 32u);
+	a.slot_dir = c->slot_dir;
+	a.nYT = (c->P.ny + 62) / 63;
+	a.nseg_pad = (c->P.nseg + 3) / 4 * 4;
+	a.z_end = c->range.z_end;
+	const uint64_t groups = (uint64_t)(c->range.z_end - c->range.z_begin) * a.nYT;  // (slice, y tile) pieces
+	a.linear = env_u32("MC33_HIP_EMIT_LINEAR", 0);
+	const uint32_t blocks = a.linear ? env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 32u)
+	                                 : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(groups, 1), env_u32("MC33_HIP_EMIT_BLOCKS", 1u << 20));
 	// The three emit passes are independent (V/N vs T, fast vs slow records) and each is bound by the
 	// latency of scattered reads, not by bandwidth: the vertex pass runs on a second stream beside the
 	// two triangle passes and joins before the end-of-call event.
