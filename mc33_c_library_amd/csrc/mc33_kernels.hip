@@ -66,8 +66,10 @@ struct SliceHeader {
 	uint32_t flags;       // bit 0: record valid (the slice holds cut cells); bit 1: a sample of the two tile
 	                      // planes equals the isovalue (no fast path for this slice)
 	uint32_t prevh_lo, prevh_hi, curh_lo, curh_hi;  // halo-column bits of the 64 sample rows (ballots)
-	uint32_t pad_[3];
+	uint32_t cells, rows;  // cut cells of the slice / rows that hold some: what k_slots turns into record ranges
+	uint32_t pad_;
 };
+constexpr uint32_t SLOT_CHUNK = 4096;  // slice slots per partial sum (one k_slots block)
 constexpr uint32_t SLICE_VALID = 1u, SLICE_HAS_ISO = 2u;
 
 // One block of k_sweep: the 4 row segments of group xg, the 63 cell rows of y tile yt, cell slices [z_lo, z_hi).
@@ -90,11 +92,10 @@ struct SweepArgs {
 	SliceHeader *slice_hdr;  // [slice_slot]
 	uint4 *slice_bits;       // [slot][k][lane]: {prev[k].lo, prev[k].hi, cur[k].lo, cur[k].hi}
 	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz)
-	uint32_t *dbg_cells;     // MC33_HIP_VERBOSE: cut cells counted by the sweep itself (cross-check of k_cells)
+	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: rows << 32 | cells of the slices of that chunk
 	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only; the later passes are not launched): 2 = stream only
 };
 
-constexpr uint32_t HORIZ_COST = 5;   // cost of one row processed across the lanes, in vertical-loop iterations
 
 // fast[i] of mc33_cell.h unpacked into the record words written for a FAST cell:
 // x = w0 without the cell's x, y = w2, z = w3, w = new vertices | triangles << 8   (x == FAST_NONE: not fast)
@@ -266,11 +267,6 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		if (p > z_lo && !(a.debug & 2u)) {
 			uint64_t act[4];
 			active_cells(prev, cur, prev_h, cur_h, valid, rowvalid, act);
-			if (a.dbg_cells) {
-				uint32_t n = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
-				for (int dlt = 32; dlt; dlt >>= 1) n += __shfl_xor(n, dlt);
-				if (lane == 0 && n) atomicAdd(a.dbg_cells, n);
-			}
 			if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull)) {  // wave-uniform: hand the slice to k_cells
 				const uint64_t slot = slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad);
 				uint4 *bits = a.slice_bits + slot * 256u + lane;
@@ -278,13 +274,19 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				for (int k = 0; k < 4; k++)
 					bits[64 * k] = uint4{(uint32_t)prev[k], (uint32_t)(prev[k] >> 32), (uint32_t)cur[k], (uint32_t)(cur[k] >> 32)};
 				const uint64_t bp = __ballot(prev_h != 0), bc = __ballot(cur_h != 0);
+				// cut cells and non-empty rows of the slice: the record ranges are prefix sums of these (k_slots)
+				uint32_t ncell = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
+				const uint32_t nrow = (uint32_t)__popcll(__ballot(ncell != 0));
+#pragma unroll
+				for (int dlt = 32; dlt; dlt >>= 1) ncell += __shfl_xor(ncell, dlt);
 				if (lane == 0) {
 					SliceHeader h;
 					h.flags = SLICE_VALID | ((prev_z || cur_z) ? SLICE_HAS_ISO : 0u);
 					h.prevh_lo = (uint32_t)bp; h.prevh_hi = (uint32_t)(bp >> 32);
 					h.curh_lo = (uint32_t)bc; h.curh_hi = (uint32_t)(bc >> 32);
-					h.pad_[0] = h.pad_[1] = h.pad_[2] = 0;
+					h.cells = ncell; h.rows = nrow; h.pad_ = 0;
 					a.slice_hdr[slot] = h;
+					atomicAdd(a.slot_part + slot / SLOT_CHUNK, (unsigned long long)nrow << 32 | ncell);
 				}
 			}
 		}
@@ -316,15 +318,66 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_cells: one wave per slice record of the sweep (4 consecutive slices of one tile per block).  Finds the
-// cut cells again from the bit rows and writes, per row segment, the directory record, the activity mask,
-// the packed counts, and one work record per cell.  FAST cells (see mc33_cell.h) are finished from their
-// sign index via an LDS table; the others get a placeholder for k_slow_plan.
-//
-// Two ways through the active cells of the slice.  VERTICAL: every lane walks the cells of its own row
-// (good when rows hold few cells: 63 rows advance together).  HORIZONTAL: one row at a time, lane L takes
-// cell x = 64k+L (good for rows where the surface runs along x: a run of 50 cells costs 1-2 passes instead
-// of 50 iterations with one lane busy).  The split threshold is chosen per slice from a cost model.
+// k_slots: exclusive prefix sums of (cut cells, non-empty rows) over the slice slots in slot order = the
+// work-record range and the mask-record range of every slice.  The sweep has already added every slice
+// into the partial sum of its chunk of SLOT_CHUNK slots; block c sums the partials below c and scans its
+// own chunk.  Record order is therefore a function of the grid alone (no allocation atomics).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const unsigned long long *part, uint64_t nslots, uint2 *slot_base,
+                                               Counters *ctr) {
+	__shared__ unsigned long long s_red[256];
+	const uint32_t c = blockIdx.x, t = threadIdx.x;
+	unsigned long long below = 0;
+	for (uint32_t q = t; q < c; q += 256u) below += part[q];
+	s_red[t] = below;
+	__syncthreads();
+	for (uint32_t d = 128; d; d >>= 1) {
+		if (t < d) s_red[t] += s_red[t + d];
+		__syncthreads();
+	}
+	const unsigned long long base = s_red[0];
+	__syncthreads();
+	constexpr uint32_t PER = SLOT_CHUNK / 256;
+	const uint64_t s0 = (uint64_t)c * SLOT_CHUNK + (uint64_t)t * PER;
+	uint32_t cells[PER], rows[PER];
+	unsigned long long mine = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < PER; k++) {
+		const bool in = s0 + k < nslots;
+		const uint4 h = in ? *(const uint4 *)((const uint32_t *)(hdr + s0 + k) + 4) : uint4{0, 0, 0, 0};  // {curh_hi, cells, rows, pad}
+		const bool valid = in && (hdr[s0 + k].flags & SLICE_VALID);
+		cells[k] = valid ? h.y : 0u; rows[k] = valid ? h.z : 0u;
+		mine += (unsigned long long)rows[k] << 32 | cells[k];
+	}
+	s_red[t] = mine;
+	__syncthreads();
+	for (uint32_t d = 1; d < 256; d <<= 1) {  // inclusive scan over the threads
+		const unsigned long long v = t >= d ? s_red[t - d] : 0ull;
+		__syncthreads();
+		s_red[t] += v;
+		__syncthreads();
+	}
+	unsigned long long run = base + s_red[t] - mine;
+#pragma unroll
+	for (uint32_t k = 0; k < PER; k++) {
+		if (s0 + k < nslots) slot_base[s0 + k] = uint2{(uint32_t)run, (uint32_t)(run >> 32)};
+		run += (unsigned long long)rows[k] << 32 | cells[k];
+	}
+	if (c == gridDim.x - 1 && t == 255) {  // totals; 32-bit fields (a carry out of the cells would also exceed every capacity)
+		const unsigned long long tot = base + s_red[255];
+		ctr->entry_cursor = (tot & 0xFFFFFFFFull) > 0xFFFFFF00ull ? 0xFFFFFFFFu : (uint32_t)tot;
+		ctr->mask_cursor = (uint32_t)(tot >> 32);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_cells: turns the slice records of the sweep into work records; one wave per slice, waves independent.
+// Lane = row for the bookkeeping (activity masks, per-row counts, directory); for the cells themselves the
+// wave takes 64 cells at a time in record order (row, then x): lane g finds its row by a search in the
+// prefix sums of the row counts, its cell as the n-th set bit of the row's activity mask, reads the 8
+// corner bits from the bit rows (LDS), and finishes FAST cells (interior, group-0 table word, no corner
+// equal to iso) from the sign index via the LDS table; the in-segment vertex / triangle offsets are a
+// segmented scan over the 64 cells.  Records of a slice are written as one contiguous run.
 // ---------------------------------------------------------------------------------------------------
 struct CellsArgs {
 	Params P;
@@ -332,6 +385,7 @@ struct CellsArgs {
 	uint32_t ze, nYT, nseg_pad;
 	const SliceHeader *slice_hdr;
 	const uint4 *slice_bits;
+	const uint2 *slot_base;  // [slice_slot]: {first work record, first mask record} (k_slots)
 	uint2 *slot_dir;         // [slice_slot]: {first work record, number of records} of the slice (emit pass)
 	uint32_t *seg_cnt;
 	SegDir *seg_dir;
@@ -340,18 +394,37 @@ struct CellsArgs {
 	uint32_t *entry_seg;
 	uint32_t *slow_list, *dirty_list;
 	uint32_t entry_cap;
-	uint32_t horiz_cost;
-	uint32_t speculate;  // fetch the bit rows together with the header
 	Counters *ctr;
-	unsigned long long *trace;  // MC33_HIP_TRACE_CELLS: per wave {start, bits in, records allocated, end}
+	unsigned long long *trace;  // MC33_HIP_TRACE_CELLS: per wave {start, bits in, rows done, end}
+};
+
+// n-th (0-based) set bit of w; n < popcount(w)
+__device__ __forceinline__ uint32_t nth_set_bit(uint64_t w, uint32_t n) {
+	uint32_t pos = 0;
+#pragma unroll
+	for (int width = 32; width; width >>= 1) {
+		const uint32_t c = (uint32_t)__popcll(w & ((1ull << width) - 1ull));
+		const bool up = n >= c;
+		n -= up ? c : 0u;
+		w = up ? w >> width : w;
+		pos += up ? (uint32_t)width : 0u;
+	}
+	return pos;
+}
+
+struct CellsLds {            // per wave
+	uint64_t bits[64][9];    // row r: prev[0..3], cur[0..3] (row 63 of the tile is only ever the row above); the
+	uint64_t act[64][5];     // odd row pitches keep neighbouring rows on different LDS banks
+	uint32_t incl[64], run[64], slowrow[64];
 };
 
 __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	__shared__ uint4 s_fast[256];
-	__shared__ uint32_t s_tot[4], s_nm[4], s_base[2];
+	__shared__ CellsLds s_w[4];
 	s_fast[threadIdx.x] = a.fast[threadIdx.x];
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	CellsLds &L = s_w[wv];
 	const Params &P = a.P;
 	// block -> 4 consecutive slices of one tile column (slice_slot order)
 	const uint64_t slot = (uint64_t)blockIdx.x * 4 + wv;
@@ -361,73 +434,56 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	const uint32_t z = P.zs + zq * 4u + wv;
 	const uint32_t y = y0 + lane;
 	const bool in_grid = seg < P.nseg && z < a.ze;
-	bool live = in_grid;
 	SliceHeader h;
-	h.flags = 0;
+	h.flags = 0; h.cells = 0;
 	uint4 q[4] = {};
-	if (live) {
-		// header and bit rows are fetched together (one round trip); the rows of a slice without cut cells
-		// are whatever an earlier call left there and are not looked at
+	uint2 base = {0u, 0u};
+	if (in_grid) {  // header, ranges and bit rows are fetched together (one round trip); the rows of a slice
+		// without cut cells are whatever an earlier call left there and are not looked at
 		h = a.slice_hdr[slot];
-		if (a.speculate) {
-			const uint4 *bits = a.slice_bits + slot * 256u + lane;
+		base = a.slot_base[slot];
+		const uint4 *bits = a.slice_bits + slot * 256u + lane;
 #pragma unroll
-			for (int k = 0; k < 4; k++) q[k] = bits[64 * k];
-		}
+		for (int k = 0; k < 4; k++) q[k] = bits[64 * k];
 	}
-	live = live && (h.flags & SLICE_VALID);
-	const bool rowvalid = live && lane < 63u && y < P.ny;
-
-	uint64_t prev[4] = {0, 0, 0, 0}, cur[4] = {0, 0, 0, 0}, act[4] = {0, 0, 0, 0};
-	uint32_t prev_h = 0, cur_h = 0, cnt = 0, c0 = 0, c1 = 0, c2 = 0, incl = 0, total = 0, nm = 0;
-	uint64_t havem = 0;
-	if (live) {  // wave-uniform
-		if (!a.speculate) {
-			const uint4 *bits = a.slice_bits + slot * 256u + lane;
-#pragma unroll
-			for (int k = 0; k < 4; k++) q[k] = bits[64 * k];
-		}
-#pragma unroll
-		for (int k = 0; k < 4; k++) { prev[k] = u64(q[k].x, q[k].y); cur[k] = u64(q[k].z, q[k].w); }
-		prev_h = (uint32_t)((u64(h.prevh_lo, h.prevh_hi) >> lane) & 1ull);
-		cur_h = (uint32_t)((u64(h.curh_lo, h.curh_hi) >> lane) & 1ull);
-		uint64_t valid[4];
-		valid_masks(xbase, P.nx, valid);
-		active_cells(prev, cur, prev_h, cur_h, valid, rowvalid, act);
-		c0 = __popcll(act[0]); c1 = __popcll(act[1]); c2 = __popcll(act[2]);
-		cnt = c0 + c1 + c2 + __popcll(act[3]);
-		havem = __ballot(cnt != 0);
-		incl = cnt;  // inclusive prefix of the per-row counts over the lanes
-#pragma unroll
-		for (int dlt = 1; dlt < 64; dlt <<= 1) {
-			const uint32_t t = __shfl_up(incl, dlt);
-			if ((int)lane >= dlt) incl += t;
-		}
-		total = __builtin_amdgcn_readlane(incl, 63);
-		nm = (uint32_t)__popcll(havem);
-	}
-	const unsigned long long t_bits = a.trace ? __builtin_amdgcn_s_memrealtime() + (total & 0u) : 0ull;
-	// the four slices of the block get consecutive work records / mask records (they are consecutive
-	// slices of one tile: the emit kernels find neighbouring cells in neighbouring records)
-	if (lane == 0) { s_tot[wv] = total; s_nm[wv] = nm; }
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		const uint32_t te = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3], tm = s_nm[0] + s_nm[1] + s_nm[2] + s_nm[3];
-		if (te) {  // both requests go out before either result is awaited
-			const uint32_t be = atomicAdd(&a.ctr->entry_cursor, te), bm = atomicAdd(&a.ctr->mask_cursor, tm);
-			s_base[0] = be; s_base[1] = bm;
-		}
-	}
-	__syncthreads();
-	if (!total) {  // wave-uniform (no barrier below)
+	__syncthreads();  // s_fast
+	const bool live = in_grid && (h.flags & SLICE_VALID);  // wave-uniform
+	if (!live) {
 		if (in_grid && lane == 0) a.slot_dir[slot] = uint2{0u, 0u};
 		return;
 	}
-	uint32_t ebase = s_base[0], mbase = s_base[1];
-	const unsigned long long t_alloc = a.trace ? __builtin_amdgcn_s_memrealtime() + (ebase & 0u) : 0ull;
-	for (uint32_t q = 0; q < wv; q++) { ebase += s_tot[q]; mbase += s_nm[q]; }
-
+	const bool rowvalid = lane < 63u && y < P.ny;
+	uint64_t prev[4], cur[4], act[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) { prev[k] = u64(q[k].x, q[k].y); cur[k] = u64(q[k].z, q[k].w); }
+	const uint64_t bp = u64(h.prevh_lo, h.prevh_hi), bc = u64(h.curh_lo, h.curh_hi);  // halo-column bits of the rows
+	{
+		uint64_t valid[4];
+		valid_masks(xbase, P.nx, valid);
+		active_cells(prev, cur, (uint32_t)((bp >> lane) & 1ull), (uint32_t)((bc >> lane) & 1ull), valid, rowvalid, act);
+	}
+	const uint32_t c0 = __popcll(act[0]), c1 = __popcll(act[1]), c2 = __popcll(act[2]);
+	const uint32_t cnt = c0 + c1 + c2 + __popcll(act[3]);
+	const uint64_t havem = __ballot(cnt != 0);
+	uint32_t incl = cnt;  // inclusive prefix of the per-row counts over the lanes
+#pragma unroll
+	for (int dlt = 1; dlt < 64; dlt <<= 1) {
+		const uint32_t t = __shfl_up(incl, dlt);
+		if ((int)lane >= dlt) incl += t;
+	}
+	const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+	const unsigned long long t_bits = a.trace ? __builtin_amdgcn_s_memrealtime() + (total & 0u) : 0ull;
+	const uint32_t ebase = base.x, mbase = base.y;
 	if (lane == 0) a.slot_dir[slot] = uint2{ebase, total};
+
+	// rows whose cells cannot take the fast path: on the y = 0 / z = 0 faces (extra owned edges), or in a
+	// tile plane pair that holds a sample equal to the isovalue
+	const bool planeslow = z == 0 || (h.flags & SLICE_HAS_ISO);  // wave-uniform
+#pragma unroll
+	for (int k = 0; k < 4; k++) { L.bits[lane][k] = prev[k]; L.bits[lane][4 + k] = cur[k]; L.act[lane][k] = act[k]; }
+	L.incl[lane] = incl;
+	L.run[lane] = 0;
+	L.slowrow[lane] = (y == 0 || planeslow) ? 1u : 0u;  // becomes 2 when a cell of the row went to the slow list
 	const uint64_t sidx = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y;  // storage order [z][segment][y]
 	const uint32_t first = ebase + incl - cnt;
 	const uint32_t maskidx = mbase + (uint32_t)__popcll(havem & ((1ull << lane) - 1ull));
@@ -436,136 +492,82 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		mr[0] = uint4{(uint32_t)act[0], (uint32_t)(act[0] >> 32), (uint32_t)act[1], (uint32_t)(act[1] >> 32)};
 		mr[1] = uint4{(uint32_t)act[2], (uint32_t)(act[2] >> 32), (uint32_t)act[3], (uint32_t)(act[3] >> 32)};
 	}
-	uint32_t idx = first, nv_run = 0, nt_run = 0;
-	bool dirty = false;
-	// rows whose cells cannot take the fast path: on the y = 0 / z = 0 faces (extra owned edges), or in a
-	// tile plane pair that holds a sample equal to the isovalue
-	const bool planeslow = z == 0 || (h.flags & SLICE_HAS_ISO);  // wave-uniform
-	const bool rowslow = y == 0 || planeslow;
-	const uint32_t prev_hn = row_above(prev_h), cur_hn = row_above(cur_h);
-	// cost model in units of one vertical iteration: vertical = min(largest row, T) iterations,
-	// horizontal = ~horiz_cost per row above T
-	uint32_t maxcnt = cnt;
-#pragma unroll
-	for (int dlt = 32; dlt; dlt >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor(maxcnt, dlt));
-	uint32_t long_T = 256u, best = maxcnt;
-#pragma unroll
-	for (uint32_t T2 = 8; T2 <= 64; T2 <<= 1) {
-		const uint32_t c2b = T2 + a.horiz_cost * (uint32_t)__popcll(__ballot(cnt > T2));
-		if (maxcnt > T2 && c2b < best) { best = c2b; long_T = T2; }
-	}
-	const bool longrow = cnt > long_T;
-	uint64_t longrows = __ballot(longrow);
+	const unsigned long long t_rows = a.trace ? __builtin_amdgcn_s_memrealtime() + (first & 0u) : 0ull;
+	const uint64_t sidx0 = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y0;
 
+	for (uint32_t g0 = 0; g0 < total; g0 += 64u) {  // wave-uniform
+		const uint32_t g = g0 + lane;
+		const bool on = g < total;
+		// row: the first r with incl[r] > g
+		uint32_t lo = 0, hi = 63;
 #pragma unroll
-	for (int k = 0; k < 4; k++) {  // VERTICAL
-		// the four bit rows of this word, and the same shifted by one sample (x+1)
-		const uint64_t q0 = prev[k], q1 = cur[k], q0n = row_above(prev[k]), q1n = row_above(cur[k]);
-		uint64_t n0, n1, n0n, n1n;  // bit 0 of the next word of each row
-		if (k < 3) {
-			n0 = prev[k < 3 ? k + 1 : 3] & 1ull; n1 = cur[k < 3 ? k + 1 : 3] & 1ull;
-			n0n = row_above((uint32_t)prev[k < 3 ? k + 1 : 3]) & 1u; n1n = row_above((uint32_t)cur[k < 3 ? k + 1 : 3]) & 1u;
-		} else { n0 = prev_h; n1 = cur_h; n0n = prev_hn; n1n = cur_hn; }
-		const uint64_t q0s = (q0 >> 1) | (n0 << 63), q1s = (q1 >> 1) | (n1 << 63);
-		const uint64_t q0ns = (q0n >> 1) | (n0n << 63), q1ns = (q1n >> 1) | (n1n << 63);
-		uint64_t todo = longrow ? 0ull : act[k];
-		for (;;) {
-			const bool has = todo != 0ull;
-			if (!__any(has)) break;
-			if (has) {
-				const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
-				todo &= todo - 1;
-				const uint32_t xl = 64u * k + j;
-				// sign index, bit 7-c = corner c (MC:1846-1859): corners 0..3 at x, 4..7 at x+1
-				const uint32_t i = (uint32_t)((q0 >> j) & 1) << 7 | (uint32_t)((q0n >> j) & 1) << 6 | (uint32_t)((q1n >> j) & 1) << 5 |
-				                   (uint32_t)((q1 >> j) & 1) << 4 | (uint32_t)((q0s >> j) & 1) << 3 | (uint32_t)((q0ns >> j) & 1) << 2 |
-				                   (uint32_t)((q1ns >> j) & 1) << 1 | (uint32_t)((q1s >> j) & 1);
-				const uint4 f = s_fast[i];
-				Entry e;
-				if (!rowslow && f.x != FAST_NONE && (xbase + xl) != 0) {
-					e.w0 = f.x | xl; e.w1 = nv_run | nt_run << 16; e.w2 = f.y; e.w3 = f.z;
-					nv_run += f.w & 0xFFu;
-					nt_run += f.w >> 8;
-				} else {
-					e = make_pending_entry(xl, i);
-					dirty = true;
-					if (idx < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = idx;
-				}
-				if (idx < a.entry_cap) {
-					a.entries[idx] = e;
-					a.entry_seg[idx] = (uint32_t)sidx;
-				}
-				idx++;
-			}
+		for (int step = 0; step < 6; step++) {
+			const uint32_t mid = (lo + hi) >> 1;
+			const bool right = L.incl[mid] <= g;
+			lo = right ? mid + 1 : lo;
+			hi = right ? hi : mid;
 		}
-	}
-	while (longrows) {  // HORIZONTAL: wave-uniform loop over the long rows
-		const uint32_t r = (uint32_t)__ffsll((long long)longrows) - 1u;
-		longrows &= longrows - 1;
-		const uint32_t first_r = __builtin_amdgcn_readlane(first, r);
-		const bool slow_r = (y0 + r) == 0 || planeslow;
-		const uint64_t sidx_r = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + (y0 + r);
-		uint32_t run = 0, pre = 0;  // new vertices | triangles << 16 so far in the row; records so far
-		bool dirty_r = false;
+		const uint32_t r = on ? lo : 62u;  // (row 63 of a tile is never a cell row)
+		const uint64_t a0 = L.act[r][0], a1 = L.act[r][1], a2 = L.act[r][2], a3 = L.act[r][3];
+		const uint32_t p0 = __popcll(a0), p1 = p0 + __popcll(a1), p2 = p1 + __popcll(a2), rowcnt = p2 + __popcll(a3);
+		const uint32_t kin = on ? g - (L.incl[r] - rowcnt) : 0u;  // position of the cell among the cells of its row
+		const uint32_t wsel = (kin >= p0) + (kin >= p1) + (kin >= p2);
+		const uint64_t aw = wsel == 0 ? a0 : wsel == 1 ? a1 : wsel == 2 ? a2 : a3;
+		const uint32_t xl = 64u * wsel + (on ? nth_set_bit(aw, kin - (wsel == 0 ? 0u : wsel == 1 ? p0 : wsel == 2 ? p1 : p2)) : 0u);
+		// the 8 corner bits: sample x and x+1 of rows r, r+1 on the two planes
+		const uint32_t w0 = xl >> 6, b0 = xl & 63u, w1 = min(w0 + 1u, 3u);
+		const bool wrap = b0 == 63u;  // x+1 is bit 0 of the next word, or the halo column after the last word
+		uint32_t i = 0;
 #pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const uint64_t a_k = readlane64(act[k], r);
-			if (!a_k) continue;
-			// r <= 62 here (row 63 of a tile is never a cell row), so row r+1 is lane r+1
-			const uint64_t q0 = readlane64(prev[k], r), q1 = readlane64(cur[k], r);
-			const uint64_t q0n = readlane64(prev[k], r + 1), q1n = readlane64(cur[k], r + 1);
-			uint64_t n0, n1, n0n, n1n;
-			if (k < 3) {
-				n0 = readlane64(prev[k < 3 ? k + 1 : 3], r) & 1ull; n1 = readlane64(cur[k < 3 ? k + 1 : 3], r) & 1ull;
-				n0n = readlane64(prev[k < 3 ? k + 1 : 3], r + 1) & 1ull; n1n = readlane64(cur[k < 3 ? k + 1 : 3], r + 1) & 1ull;
-			} else {
-				n0 = __builtin_amdgcn_readlane(prev_h, r); n1 = __builtin_amdgcn_readlane(cur_h, r);
-				n0n = __builtin_amdgcn_readlane(prev_hn, r); n1n = __builtin_amdgcn_readlane(cur_hn, r);
-			}
-			const uint64_t q0s = (q0 >> 1) | (n0 << 63), q1s = (q1 >> 1) | (n1 << 63);
-			const uint64_t q0ns = (q0n >> 1) | (n0n << 63), q1ns = (q1n >> 1) | (n1n << 63);
-			const bool on = (a_k >> lane) & 1ull;
-			const uint32_t xl = 64u * k + lane;
-			const uint32_t i = (uint32_t)((q0 >> lane) & 1) << 7 | (uint32_t)((q0n >> lane) & 1) << 6 | (uint32_t)((q1n >> lane) & 1) << 5 |
-			                   (uint32_t)((q1 >> lane) & 1) << 4 | (uint32_t)((q0s >> lane) & 1) << 3 | (uint32_t)((q0ns >> lane) & 1) << 2 |
-			                   (uint32_t)((q1ns >> lane) & 1) << 1 | (uint32_t)((q1s >> lane) & 1);
-			const uint4 f = s_fast[i];
-			const bool fastcell = on && !slow_r && f.x != FAST_NONE && (xbase + xl) != 0;
-			const uint32_t val = fastcell ? ((f.w & 0xFFu) | (f.w >> 8) << 16) : 0u;
-			uint32_t inc = val;  // inclusive scan over the lanes (cells in x order)
-#pragma unroll
-			for (int dlt = 1; dlt < 64; dlt <<= 1) {
-				const uint32_t t = __shfl_up(inc, dlt);
-				if ((int)lane >= dlt) inc += t;
-			}
-			const uint32_t off = run + inc - val;
-			const uint32_t ri = first_r + pre + (uint32_t)__popcll(a_k & ((1ull << lane) - 1ull));
-			if (on) {
-				Entry e;
-				if (fastcell) { e.w0 = f.x | xl; e.w1 = off; e.w2 = f.y; e.w3 = f.z; }
-				else {
-					e = make_pending_entry(xl, i);
-					if (ri < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = ri;
-				}
-				if (ri < a.entry_cap) {
-					a.entries[ri] = e;
-					a.entry_seg[ri] = (uint32_t)sidx_r;
-				}
-			}
-			dirty_r = dirty_r || (__ballot(on && !fastcell) != 0ull);
-			run += __builtin_amdgcn_readlane(inc, 63);
-			pre += (uint32_t)__popcll(a_k);
+		for (int c = 0; c < 4; c++) {  // c: 0 = (row r, prev) 1 = (row r+1, prev) 2 = (row r+1, cur) 3 = (row r, cur): corners 0..3, MC:1846-1859
+			const uint32_t rr = r + ((c == 1 || c == 2) ? 1u : 0u), pl = (c >= 2) ? 4u : 0u;
+			const uint64_t W = L.bits[rr][pl + w0], Wn = L.bits[rr][pl + w1];
+			const uint32_t halo = (uint32_t)(((pl ? bc : bp) >> rr) & 1ull);
+			const uint32_t here = (uint32_t)(W >> b0) & 1u;
+			const uint32_t next = wrap ? (w0 < 3u ? (uint32_t)Wn & 1u : halo) : (uint32_t)(W >> (b0 + 1u)) & 1u;
+			i |= here << (7 - c) | next << (3 - c);
 		}
-		if (lane == r) { nv_run = run & 0xFFFFu; nt_run = run >> 16; dirty = dirty_r; }
+		const uint4 f = s_fast[i];
+		const uint32_t rowflag = L.slowrow[r];
+		const bool fastcell = on && !(rowflag & 1u) && f.x != FAST_NONE && (xbase + xl) != 0;
+		const uint32_t val = fastcell ? ((f.w & 0xFFu) | (f.w >> 8) << 16) : 0u;  // new vertices | triangles << 16
+		// offsets inside the row segment: exclusive scan over the cells of the same row
+		uint32_t sc = val;
+#pragma unroll
+		for (int dlt = 1; dlt < 64; dlt <<= 1) {
+			const uint32_t t = __shfl_up(sc, dlt);
+			if ((int)lane >= dlt) sc += t;
+		}
+		const uint32_t head = lane - min(lane, kin);  // lane of the first cell of my row inside this batch
+		const uint32_t before_head = __shfl(sc, head) - __shfl(val, head);
+		const uint32_t carry = kin > lane ? L.run[r] : 0u;  // the row began in an earlier batch
+		const uint32_t off = carry + (sc - val) - before_head;
+		if (on) {
+			const uint32_t ri = ebase + g;
+			Entry e;
+			if (fastcell) { e.w0 = f.x | xl; e.w1 = off; e.w2 = f.y; e.w3 = f.z; }
+			else {
+				e = make_pending_entry(xl, i);
+				L.slowrow[r] = rowflag | 2u;
+				if (ri < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = ri;
+			}
+			if (ri < a.entry_cap) {
+				a.entries[ri] = e;
+				a.entry_seg[ri] = (uint32_t)(sidx0 + r);
+			}
+			if (kin + 1u == rowcnt || lane == 63u) L.run[r] = off + val;  // last cell of the row in this batch
+		}
 	}
 	if (rowvalid && cnt) {
-		a.seg_cnt[sidx] = dirty ? 0u : seg_pack(nv_run, nt_run);
+		const bool dirty = (L.slowrow[lane] & 2u) != 0;
+		const uint32_t run = L.run[lane];
+		a.seg_cnt[sidx] = dirty ? 0u : seg_pack(run & 0xFFFFu, run >> 16);
 		a.seg_dir[sidx] = SegDir{first, cnt | (dirty ? SEG_DIRTY : 0u), maskidx, pack_prefix(c0, c1, c2)};
 		if (dirty && first < a.entry_cap) a.dirty_list[atomicAdd(&a.ctr->dirty_cursor, 1u)] = (uint32_t)sidx;
 	}
 	if (a.trace && lane == 0) {
 		unsigned long long *tr = a.trace + 4ull * slot;
-		tr[0] = t_start; tr[1] = t_bits; tr[2] = t_alloc; tr[3] = __builtin_amdgcn_s_memrealtime();
+		tr[0] = t_start; tr[1] = t_bits; tr[2] = t_rows; tr[3] = __builtin_amdgcn_s_memrealtime();
 	}
 }
 
@@ -910,7 +912,8 @@ struct mc33hip_ctx {
 	uint64_t entry_cap;
 	SliceHeader *slice_hdr;   // one record per (wave tile, cell slice) of the sweep
 	uint4 *slice_bits;
-	uint2 *slot_dir;
+	uint2 *slot_dir, *slot_base;
+	unsigned long long *slot_part;
 	uint64_t slice_cap;
 	SweepTile *d_tiles;       // block plan of k_sweep for the current range
 	uint64_t tiles_cap, ntiles;
@@ -1006,6 +1009,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
 	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
 	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->slot_dir); (void)hipFree(c->d_tiles);
+	(void)hipFree(c->slot_base); (void)hipFree(c->slot_part);
 	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
@@ -1282,14 +1286,16 @@ static int enqueue_count(mc33hip_ctx *c) {
 		HIP_TRY(hipMalloc(&c->slice_hdr, nslots * sizeof(SliceHeader)));
 		HIP_TRY(hipMalloc(&c->slice_bits, nslots * 4096));
 		HIP_TRY(hipMalloc(&c->slot_dir, nslots * sizeof(uint2)));
-		if (getenv("MC33_HIP_VERBOSE"))
-			fprintf(stderr, "[mc33hip] slice records: hdr %p bits %p dir %p (%llu slots), grid %p\n", (void *)c->slice_hdr, (void *)c->slice_bits,
-			        (void *)c->slot_dir, (unsigned long long)nslots, (void *)c->d_grid);
+		(void)hipFree(c->slot_base); (void)hipFree(c->slot_part);
+		c->slot_base = nullptr; c->slot_part = nullptr;
+		HIP_TRY(hipMalloc(&c->slot_base, nslots * sizeof(uint2)));
+		HIP_TRY(hipMalloc(&c->slot_part, ((nslots + SLOT_CHUNK - 1) / SLOT_CHUNK) * 8));
 		c->slice_cap = nslots;
 	}
 	a.slice_hdr = c->slice_hdr; a.slice_bits = c->slice_bits;
 	a.debug = env_u32("MC33_HIP_DEBUG", 0);
-	a.dbg_cells = getenv("MC33_HIP_VERBOSE") ? &c->d_ctr->pad_ : nullptr;
+	a.slot_part = c->slot_part;
+	const uint64_t nchunks = (nslots + SLOT_CHUNK - 1) / SLOT_CHUNK;
 	a.trace = nullptr;
 	if (getenv("MC33_HIP_TRACE_FILE")) {
 		(void)hipFree(c->trace);
@@ -1301,6 +1307,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	}
 	HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
 	HIP_TRY(hipMemsetAsync(c->slice_hdr, 0, nslots * sizeof(SliceHeader), st));
+	HIP_TRY(hipMemsetAsync(c->slot_part, 0, nchunks * 8, st));
 	HIP_TRY(hipMemsetAsync(c->seg_cnt, 0, c->nsegs * 4, st));
 	HIP_TRY(hipEventRecord(c->ev[0], st));
 	hipLaunchKernelGGL(k_sweep, dim3((uint32_t)blocks), dim3(256), 0, st, a);
@@ -1309,12 +1316,10 @@ static int enqueue_count(mc33hip_ctx *c) {
 	CellsArgs ca;
 	ca.P = P; ca.fast = c->d_fast;
 	ca.ze = ze; ca.nYT = a.nYT; ca.nseg_pad = a.nseg_pad;
-	ca.slice_hdr = c->slice_hdr; ca.slice_bits = c->slice_bits; ca.slot_dir = c->slot_dir;
+	ca.slice_hdr = c->slice_hdr; ca.slice_bits = c->slice_bits; ca.slot_dir = c->slot_dir; ca.slot_base = c->slot_base;
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir; ca.seg_mask = c->seg_mask;
 	ca.entries = c->entries; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
 	ca.entry_cap = (uint32_t)c->entry_cap;
-	ca.horiz_cost = env_u32("MC33_HIP_HCOST", HORIZ_COST);
-	ca.speculate = env_u32("MC33_HIP_CELLS_SPEC", 1);
 	ca.ctr = c->d_ctr;
 	ca.trace = nullptr;
 	if (getenv("MC33_HIP_TRACE_CELLS")) {
@@ -1325,6 +1330,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 		HIP_TRY(hipMemsetAsync(c->trace_cells, 0, nslots * 32, st));
 		ca.trace = c->trace_cells;
 	}
+	hipLaunchKernelGGL(k_slots, dim3((uint32_t)nchunks), dim3(256), 0, st, c->slice_hdr, c->slot_part, nslots, c->slot_base, c->d_ctr);
 	hipLaunchKernelGGL(k_cells, dim3((uint32_t)cell_blocks), dim3(256), 0, st, ca);
 	SlowArgs sa;
 	sa.G = a.G; sa.P = P;
@@ -1398,8 +1404,8 @@ static int fetch_counters(mc33hip_ctx *c) {
 	HIP_TRY(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (getenv("MC33_HIP_VERBOSE"))
-		fprintf(stderr, "[mc33hip] cut cells: sweep %u, k_cells %u (slow %u, dirty segments %u, masks %u)\n", c->h_ctr->pad_,
-		        c->h_ctr->entry_cursor, c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->mask_cursor);
+		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, non-empty row segments %u)\n", c->h_ctr->entry_cursor,
+		        c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->mask_cursor);
 	if (c->trace_cells && getenv("MC33_HIP_TRACE_CELLS")) {
 		void *h = malloc(c->trace_cells_n * 32);
 		if (h && hipMemcpy(h, c->trace_cells, c->trace_cells_n * 32, hipMemcpyDeviceToHost) == hipSuccess) {
