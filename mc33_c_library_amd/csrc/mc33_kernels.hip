@@ -71,6 +71,9 @@ struct SliceHeader {
 };
 constexpr uint32_t SLOT_CHUNK = 4096;  // slice slots per partial sum (one k_slots block)
 constexpr uint32_t SLICE_VALID = 1u, SLICE_HAS_ISO = 2u;
+// The upper 30 bits of `flags` carry the number of the extraction that wrote the record (epoch >= 1): records
+// of earlier calls are simply not valid any more, and the 2 MB of headers need no clearing between calls.
+__host__ __device__ inline bool slice_valid(uint32_t flags, uint32_t epoch) { return (flags & ~SLICE_HAS_ISO) == (epoch << 2 | SLICE_VALID); }
 
 // One block of k_sweep: the 4 row segments of group xg, the 63 cell rows of y tile yt, cell slices [z_lo, z_hi).
 // The host cuts every (xg, yt) column into chunks of equal WORK (rows x planes), as many in total as the
@@ -93,6 +96,7 @@ struct SweepArgs {
 	uint4 *slice_bits;       // [slot][k][lane]: {prev[k].lo, prev[k].hi, cur[k].lo, cur[k].hi}
 	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz)
 	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: rows << 32 | cells of the slices of that chunk
+	uint32_t epoch;          // number of this extraction (stamped into the slice headers)
 	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only; the later passes are not launched): 2 = stream only
 };
 
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				for (int dlt = 32; dlt; dlt >>= 1) ncell += __shfl_xor(ncell, dlt);
 				if (lane == 0) {
 					SliceHeader h;
-					h.flags = SLICE_VALID | ((prev_z || cur_z) ? SLICE_HAS_ISO : 0u);
+					h.flags = a.epoch << 2 | SLICE_VALID | ((prev_z || cur_z) ? SLICE_HAS_ISO : 0u);
 					h.prevh_lo = (uint32_t)bp; h.prevh_hi = (uint32_t)(bp >> 32);
 					h.curh_lo = (uint32_t)bc; h.curh_hi = (uint32_t)(bc >> 32);
 					h.cells = ncell; h.rows = nrow; h.pad_ = 0;
@@ -323,10 +327,16 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 // into the partial sum of its chunk of SLOT_CHUNK slots; block c sums the partials below c and scans its
 // own chunk.  Record order is therefore a function of the grid alone (no allocation atomics).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const unsigned long long *part, uint64_t nslots, uint2 *slot_base,
-                                               Counters *ctr) {
+__global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const unsigned long long *part, unsigned long long *part_next,
+                                               uint32_t part_cap, uint32_t epoch, uint64_t nslots, uint2 *slot_base, Counters *ctr) {
 	__shared__ unsigned long long s_red[256];
 	const uint32_t c = blockIdx.x, t = threadIdx.x;
+	if (t == 0) part_next[c] = 0;  // the partial sums of the NEXT extraction live in the other half: cleared here
+	if (c == 0) for (uint32_t q = gridDim.x + t; q < part_cap; q += 256u) part_next[q] = 0;  // (a later range may be longer)
+	if (c == 0 && t == 0) {        // ... and so are the counters the later passes of this one add to
+		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0;
+		ctr->totV = ctr->totT = ctr->ghostV = ctr->ghostT = 0;
+	}
 	unsigned long long below = 0;
 	for (uint32_t q = t; q < c; q += 256u) below += part[q];
 	s_red[t] = below;
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 	for (uint32_t k = 0; k < PER; k++) {
 		const bool in = s0 + k < nslots;
 		const uint4 h = in ? *(const uint4 *)((const uint32_t *)(hdr + s0 + k) + 4) : uint4{0, 0, 0, 0};  // {curh_hi, cells, rows, pad}
-		const bool valid = in && (hdr[s0 + k].flags & SLICE_VALID);
+		const bool valid = in && slice_valid(hdr[s0 + k].flags, epoch);
 		cells[k] = valid ? h.y : 0u; rows[k] = valid ? h.z : 0u;
 		mine += (unsigned long long)rows[k] << 32 | cells[k];
 	}
@@ -385,6 +395,7 @@ struct CellsArgs {
 	uint32_t ze, nYT, nseg_pad;
 	const SliceHeader *slice_hdr;
 	const uint4 *slice_bits;
+	uint32_t epoch;          // number of this extraction: headers written by earlier ones are not valid
 	const uint2 *slot_base;  // [slice_slot]: {first work record, first mask record} (k_slots)
 	uint2 *slot_dir;         // [slice_slot]: {first work record, number of records} of the slice (emit pass)
 	uint32_t *seg_cnt;
@@ -447,12 +458,14 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		for (int k = 0; k < 4; k++) q[k] = bits[64 * k];
 	}
 	__syncthreads();  // s_fast
-	const bool live = in_grid && (h.flags & SLICE_VALID);  // wave-uniform
-	if (!live) {
+	const bool live = in_grid && slice_valid(h.flags, a.epoch);  // wave-uniform
+	const bool rowvalid = lane < 63u && y < P.ny;
+	const uint64_t sidx = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y;  // storage order [z][segment][y]
+	if (!live) {  // no cut cell in the slice: empty record range, zero counts for its row segments
 		if (in_grid && lane == 0) a.slot_dir[slot] = uint2{0u, 0u};
+		if (in_grid && rowvalid) a.seg_cnt[sidx] = 0u;
 		return;
 	}
-	const bool rowvalid = lane < 63u && y < P.ny;
 	uint64_t prev[4], cur[4], act[4];
 #pragma unroll
 	for (int k = 0; k < 4; k++) { prev[k] = u64(q[k].x, q[k].y); cur[k] = u64(q[k].z, q[k].w); }
@@ -484,7 +497,6 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	L.incl[lane] = incl;
 	L.run[lane] = 0;
 	L.slowrow[lane] = (y == 0 || planeslow) ? 1u : 0u;  // becomes 2 when a cell of the row went to the slow list
-	const uint64_t sidx = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y;  // storage order [z][segment][y]
 	const uint32_t first = ebase + incl - cnt;
 	const uint32_t maskidx = mbase + (uint32_t)__popcll(havem & ((1ull << lane) - 1ull));
 	if (cnt && maskidx < a.entry_cap) {
@@ -558,6 +570,7 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 			if (kin + 1u == rowcnt || lane == 63u) L.run[r] = off + val;  // last cell of the row in this batch
 		}
 	}
+	if (rowvalid && !cnt) a.seg_cnt[sidx] = 0u;  // every row segment of the range is written: no clearing pass
 	if (rowvalid && cnt) {
 		const bool dirty = (L.slowrow[lane] & 2u) != 0;
 		const uint32_t run = L.run[lane];
@@ -914,6 +927,7 @@ struct mc33hip_ctx {
 	uint4 *slice_bits;
 	uint2 *slot_dir, *slot_base;
 	unsigned long long *slot_part;
+	uint32_t epoch;           // extractions since the slice headers were last cleared
 	uint64_t slice_cap;
 	SweepTile *d_tiles;       // block plan of k_sweep for the current range
 	uint64_t tiles_cap, ntiles;
@@ -1289,13 +1303,23 @@ static int enqueue_count(mc33hip_ctx *c) {
 		(void)hipFree(c->slot_base); (void)hipFree(c->slot_part);
 		c->slot_base = nullptr; c->slot_part = nullptr;
 		HIP_TRY(hipMalloc(&c->slot_base, nslots * sizeof(uint2)));
-		HIP_TRY(hipMalloc(&c->slot_part, ((nslots + SLOT_CHUNK - 1) / SLOT_CHUNK) * 8));
+		const uint64_t part_bytes = ((nslots + SLOT_CHUNK - 1) / SLOT_CHUNK) * 8;
+		HIP_TRY(hipMalloc(&c->slot_part, 2 * part_bytes));  // two halves, used by alternate extractions
+		HIP_TRY(hipMemsetAsync(c->slice_hdr, 0, nslots * sizeof(SliceHeader), st));
+		HIP_TRY(hipMemsetAsync(c->slot_part, 0, 2 * part_bytes, st));
+		c->epoch = 0;
 		c->slice_cap = nslots;
 	}
 	a.slice_hdr = c->slice_hdr; a.slice_bits = c->slice_bits;
 	a.debug = env_u32("MC33_HIP_DEBUG", 0);
-	a.slot_part = c->slot_part;
-	const uint64_t nchunks = (nslots + SLOT_CHUNK - 1) / SLOT_CHUNK;
+	const uint64_t nchunks = (c->slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;  // (capacity: the halves keep their place)
+	if (++c->epoch >= (1u << 30)) {  // stamps wrap: start over with clean headers
+		HIP_TRY(hipMemsetAsync(c->slice_hdr, 0, c->slice_cap * sizeof(SliceHeader), st));
+		c->epoch = 1;
+	}
+	unsigned long long *part_now = c->slot_part + (c->epoch & 1u) * nchunks, *part_next = c->slot_part + ((c->epoch + 1u) & 1u) * nchunks;
+	a.slot_part = part_now;
+	a.epoch = c->epoch;
 	a.trace = nullptr;
 	if (getenv("MC33_HIP_TRACE_FILE")) {
 		(void)hipFree(c->trace);
@@ -1305,10 +1329,8 @@ static int enqueue_count(mc33hip_ctx *c) {
 		HIP_TRY(hipMemsetAsync(c->trace, 0, c->trace_waves * 16, st));
 		a.trace = c->trace;
 	}
-	HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
-	HIP_TRY(hipMemsetAsync(c->slice_hdr, 0, nslots * sizeof(SliceHeader), st));
-	HIP_TRY(hipMemsetAsync(c->slot_part, 0, nchunks * 8, st));
-	HIP_TRY(hipMemsetAsync(c->seg_cnt, 0, c->nsegs * 4, st));
+	// nothing is cleared between extractions: headers carry the epoch, k_slots resets the counters and the
+	// partial sums of the next call, k_cells writes every row segment count of the range
 	HIP_TRY(hipEventRecord(c->ev[0], st));
 	hipLaunchKernelGGL(k_sweep, dim3((uint32_t)blocks), dim3(256), 0, st, a);
 	HIP_TRY(hipGetLastError());
@@ -1317,6 +1339,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	ca.P = P; ca.fast = c->d_fast;
 	ca.ze = ze; ca.nYT = a.nYT; ca.nseg_pad = a.nseg_pad;
 	ca.slice_hdr = c->slice_hdr; ca.slice_bits = c->slice_bits; ca.slot_dir = c->slot_dir; ca.slot_base = c->slot_base;
+	ca.epoch = c->epoch;
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir; ca.seg_mask = c->seg_mask;
 	ca.entries = c->entries; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
 	ca.entry_cap = (uint32_t)c->entry_cap;
@@ -1330,7 +1353,8 @@ static int enqueue_count(mc33hip_ctx *c) {
 		HIP_TRY(hipMemsetAsync(c->trace_cells, 0, nslots * 32, st));
 		ca.trace = c->trace_cells;
 	}
-	hipLaunchKernelGGL(k_slots, dim3((uint32_t)nchunks), dim3(256), 0, st, c->slice_hdr, c->slot_part, nslots, c->slot_base, c->d_ctr);
+	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((nslots + SLOT_CHUNK - 1) / SLOT_CHUNK)), dim3(256), 0, st, c->slice_hdr, part_now, part_next,
+	                   (uint32_t)nchunks, c->epoch, nslots, c->slot_base, c->d_ctr);
 	hipLaunchKernelGGL(k_cells, dim3((uint32_t)cell_blocks), dim3(256), 0, st, ca);
 	SlowArgs sa;
 	sa.G = a.G; sa.P = P;

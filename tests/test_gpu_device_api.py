@@ -92,3 +92,38 @@ def test_capacity_error_reports_sizes():
     assert not ok and cnt.nV > 8 and cnt.nT > 8
     V2, N2, T2, c2 = g.extract(0.0)
     assert c2.nV == cnt.nV and c2.nT == cnt.nT
+
+
+def test_one_context_many_extractions_of_different_extent(reflibs):
+    """Nothing is cleared between extractions of one context (epoch-stamped slice headers, alternating partial
+    sums, counts rewritten in place): a long run of calls with changing isovalues and z ranges - whole volume,
+    thin slabs, empty results, whole volume again - must each equal a fresh computation."""
+    import torch
+    from mc33_c_library_amd import DeviceGrid, Range
+    data, r0, d = fx.cos_field(150)
+    nz = data.shape[0] - 1
+    t = torch.from_numpy(data).cuda()
+    g = DeviceGrid(t, r0=r0, d=d)
+    ref_cache = {}
+
+    def reference(iso):
+        if iso not in ref_cache:
+            ref_cache[iso] = reflibs["f32"].isosurface(data, iso, r0, d)
+        return ref_cache[iso]
+
+    plan = [(0.0, None), (2.5, None), (0.0, (10, 14)), (5.0, None), (0.0, None), (1.0, (100, nz)), (-1.0, (0, 3)), (0.0, None),
+            (2.5, (40, 41)), (2.5, None)]
+    for step, (iso, zr) in enumerate(plan * 2):
+        if zr is None:
+            V, N, T, cnt = g.extract(iso)
+            ref = reference(iso)
+            assert (cnt.nV, cnt.nT) == (ref.nV, ref.nT), (step, iso)
+            assert np.array_equal(T.cpu().numpy().view(np.uint32), ref.T) and beq(V.cpu().numpy(), ref.V) and beq(N.cpu().numpy(), ref.N)
+        else:  # a slab of the same resident grid: compare with a fresh context doing the same
+            rng = Range(zr[0], zr[1], 1 if zr[0] else 0, 0)
+            V, N, T, cnt = g.extract(iso, rng)
+            g2 = DeviceGrid(t, r0=r0, d=d)
+            V2, N2, T2, cnt2 = g2.extract(iso, rng)
+            assert (cnt.nV, cnt.nT) == (cnt2.nV, cnt2.nT), (step, iso, zr)
+            assert torch.equal(T, T2) and torch.equal(V.view(torch.int32), V2.view(torch.int32)) and torch.equal(N.view(torch.int32), N2.view(torch.int32))
+            g2.close()
