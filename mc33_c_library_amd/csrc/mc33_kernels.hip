@@ -397,7 +397,6 @@ struct CellsArgs {
 	const uint4 *slice_bits;
 	uint32_t epoch;          // number of this extraction: headers written by earlier ones are not valid
 	const uint2 *slot_base;  // [slice_slot]: {first work record, first mask record} (k_slots)
-	uint2 *slot_dir;         // [slice_slot]: {first work record, number of records} of the slice (emit pass)
 	uint32_t *seg_cnt;
 	SegDir *seg_dir;
 	uint64_t *seg_mask;
@@ -461,8 +460,7 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	const bool live = in_grid && slice_valid(h.flags, a.epoch);  // wave-uniform
 	const bool rowvalid = lane < 63u && y < P.ny;
 	const uint64_t sidx = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y;  // storage order [z][segment][y]
-	if (!live) {  // no cut cell in the slice: empty record range, zero counts for its row segments
-		if (in_grid && lane == 0) a.slot_dir[slot] = uint2{0u, 0u};
+	if (!live) {  // no cut cell in the slice: zero counts for its row segments
 		if (in_grid && rowvalid) a.seg_cnt[sidx] = 0u;
 		return;
 	}
@@ -487,7 +485,6 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
 	const unsigned long long t_bits = a.trace ? __builtin_amdgcn_s_memrealtime() + (total & 0u) : 0ull;
 	const uint32_t ebase = base.x, mbase = base.y;
-	if (lane == 0) a.slot_dir[slot] = uint2{ebase, total};
 
 	// rows whose cells cannot take the fast path: on the y = 0 / z = 0 faces (extra owned edges), or in a
 	// tile plane pair that holds a sample equal to the isovalue
@@ -765,53 +762,13 @@ struct EmitArgs {
 	uint64_t capV, capT;
 	uint64_t ghost_segs;  // row segments of the ghost slice (0 without ghost)
 	uint32_t id_base;
-	const uint2 *slot_dir;   // [slice_slot]: {first record, records} per (slice, y tile, row segment)
-	uint32_t nYT, nseg_pad, z_end;
-	uint32_t linear;         // MC33_HIP_EMIT_LINEAR (measurement): walk the records in storage order instead
 };
 
-// The fast emit passes walk the records by (cell slice, y tile): one block takes the records of ALL row
-// segments of that slab piece, because their vertices (and triangles) are neighbours in the output arrays
-// (ids run z -> y -> x): the block then writes whole cache lines.  With one wave per record range the
-// 12-byte pieces of a line came from blocks on different XCDs, every L2 wrote its part back separately and
-// the vertex pass wrote 2.7x its algorithmic bytes (WRITE_SIZE 250 MB for 94 MB of V and N at 1024^3).
-struct RecordWalk {
-	uint32_t s_first[64], s_pre[65];
-};
-template <class F>
-__device__ __forceinline__ void walk_records(const EmitArgs &a, const Params &P, uint32_t z_first, RecordWalk &w, F &&body) {
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t groups = (a.z_end - z_first) * a.nYT;
-	for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
-		const uint32_t z = z_first + g / a.nYT, yt = g % a.nYT;
-		for (uint32_t seg0 = 0; seg0 < P.nseg; seg0 += 64u) {
-			const uint32_t nsg = min(64u, P.nseg - seg0);
-			__syncthreads();  // the previous chunk's table is no longer read
-			if (threadIdx.x < 64u) {
-				const uint2 d = lane < nsg ? a.slot_dir[slice_slot(z - P.zs, yt, seg0 + lane, a.nYT, a.nseg_pad)] : uint2{0u, 0u};
-				uint32_t incl = d.y;
-#pragma unroll
-				for (int dlt = 1; dlt < 64; dlt <<= 1) {
-					const uint32_t t = __shfl_up(incl, dlt);
-					if ((int)lane >= dlt) incl += t;
-				}
-				w.s_first[lane] = d.x;
-				w.s_pre[lane + 1] = incl;
-				if (lane == 0) w.s_pre[0] = 0;
-			}
-			__syncthreads();
-			const uint32_t total = w.s_pre[nsg];
-			for (uint32_t i = threadIdx.x; i < total; i += 256u) {
-				uint32_t lo = 0, hi = nsg;  // the segment with s_pre[seg] <= i < s_pre[seg + 1]
-				while (hi - lo > 1u) {
-					const uint32_t mid = (lo + hi) >> 1;
-					if (i >= w.s_pre[mid]) lo = mid; else hi = mid;
-				}
-				body(w.s_first[lo] + (i - w.s_pre[lo]));
-			}
-		}
-	}
-}
+// The fast emit passes take the records in storage order, which k_slots made (4 slices of a tile column, next
+// row segment, next y tile, ...): neighbouring threads work on neighbouring cells, and consecutive slices of a
+// column - which share two of their three sample planes - are handled close in time.  (Tried: one block per
+// (slice, y tile) piece over all row segments, so that whole output cache lines come from one XCD - the write
+// traffic fell from 2.7x to 1.4x of the algorithmic bytes, the time did not.)
 
 // capacity / overflow check shared by both emit kernels; fills the slab offsets of the context
 __device__ __forceinline__ bool emit_prepare(const EmitArgs &a, EmitCtx<sample_t> &c, const Counters &ctr) {
@@ -832,19 +789,11 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
-	__shared__ RecordWalk walk;
-	if (a.linear) {
-		const uint32_t n = ctr.entry_cursor;
-		for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
-			const Entry en = c.entries[e];
-			if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, c.entry_seg[e]);
-		}
-		return;
-	}
-	walk_records(a, c.P, max(c.z_emit, c.P.zs), walk, [&](uint32_t e) {
+	const uint32_t n = ctr.entry_cursor;
+	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
 		const Entry en = c.entries[e];
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, c.entry_seg[e]);
-	});
+	}
 }
 
 // triangles of the fast records (ids of shared edges through the owners' records)
@@ -854,19 +803,11 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
-	__shared__ RecordWalk walk;
-	if (a.linear) {
-		const uint32_t n = ctr.entry_cursor;
-		for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
-			const Entry en = c.entries[e];
-			if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, c.entry_seg[e], e, ids);
-		}
-		return;
-	}
-	walk_records(a, c.P, max(c.z_emit, c.P.zs), walk, [&](uint32_t e) {
+	const uint32_t n = ctr.entry_cursor;
+	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
 		const Entry en = c.entries[e];
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, c.entry_seg[e], e, ids);
-	});
+	}
 }
 
 __global__ __launch_bounds__(256) void k_emit_slow(const EmitArgs a) {
@@ -925,7 +866,7 @@ struct mc33hip_ctx {
 	uint64_t entry_cap;
 	SliceHeader *slice_hdr;   // one record per (wave tile, cell slice) of the sweep
 	uint4 *slice_bits;
-	uint2 *slot_dir, *slot_base;
+	uint2 *slot_base;
 	unsigned long long *slot_part;
 	uint32_t epoch;           // extractions since the slice headers were last cleared
 	uint64_t slice_cap;
@@ -1022,7 +963,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base); (void)hipFree(c->seg_mask);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
 	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
-	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->slot_dir); (void)hipFree(c->d_tiles);
+	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->d_tiles);
 	(void)hipFree(c->slot_base); (void)hipFree(c->slot_part);
 	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
 	(void)hipFree(c->d_ctr);
@@ -1295,11 +1236,10 @@ static int enqueue_count(mc33hip_ctx *c) {
 	if (cell_blocks > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
 	const uint64_t nslots = cell_blocks * 4;
 	if (c->slice_cap < nslots) {
-		(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->slot_dir);
-		c->slice_hdr = nullptr; c->slice_bits = nullptr; c->slot_dir = nullptr; c->slice_cap = 0;
+		(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits);
+		c->slice_hdr = nullptr; c->slice_bits = nullptr; c->slice_cap = 0;
 		HIP_TRY(hipMalloc(&c->slice_hdr, nslots * sizeof(SliceHeader)));
 		HIP_TRY(hipMalloc(&c->slice_bits, nslots * 4096));
-		HIP_TRY(hipMalloc(&c->slot_dir, nslots * sizeof(uint2)));
 		(void)hipFree(c->slot_base); (void)hipFree(c->slot_part);
 		c->slot_base = nullptr; c->slot_part = nullptr;
 		HIP_TRY(hipMalloc(&c->slot_base, nslots * sizeof(uint2)));
@@ -1338,7 +1278,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	CellsArgs ca;
 	ca.P = P; ca.fast = c->d_fast;
 	ca.ze = ze; ca.nYT = a.nYT; ca.nseg_pad = a.nseg_pad;
-	ca.slice_hdr = c->slice_hdr; ca.slice_bits = c->slice_bits; ca.slot_dir = c->slot_dir; ca.slot_base = c->slot_base;
+	ca.slice_hdr = c->slice_hdr; ca.slice_bits = c->slice_bits; ca.slot_base = c->slot_base;
 	ca.epoch = c->epoch;
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir; ca.seg_mask = c->seg_mask;
 	ca.entries = c->entries; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
@@ -1391,14 +1331,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.capV = capV; a.capT = capT;
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
-	a.slot_dir = c->slot_dir;
-	a.nYT = (c->P.ny + 62) / 63;
-	a.nseg_pad = (c->P.nseg + 3) / 4 * 4;
-	a.z_end = c->range.z_end;
-	const uint64_t groups = (uint64_t)(c->range.z_end - c->range.z_begin) * a.nYT;  // (slice, y tile) pieces
-	a.linear = env_u32("MC33_HIP_EMIT_LINEAR", 0);
-	const uint32_t blocks = a.linear ? env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 32u)
-	                                 : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(groups, 1), env_u32("MC33_HIP_EMIT_BLOCKS", 1u << 20));
+	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 32u);
 	// The three emit passes are independent (V/N vs T, fast vs slow records) and each is bound by the
 	// latency of scattered reads, not by bandwidth: the vertex pass runs on a second stream beside the
 	// two triangle passes and joins before the end-of-call event.
@@ -1409,11 +1342,13 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 		HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
 		HIP_TRY(hipStreamWaitEvent(c->aux2, c->ev_fork, 0));
 	}
+	// the vertex pass is the longest of the three: it goes on the context's own stream (first), so that the
+	// end-of-call event follows it directly and the two joins find their streams already idle
+	hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);
+	hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, sv, a);
+	if (fork) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
 	hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 256)), dim3(256), 0, ss, a);
 	if (fork) HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
-	hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, sv, a);
-	if (fork) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
-	hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, c->stream, a);
 	HIP_TRY(hipGetLastError());
 	if (fork) {
 		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
