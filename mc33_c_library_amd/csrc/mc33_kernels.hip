@@ -770,6 +770,21 @@ struct EmitArgs {
 // (slice, y tile) piece over all row segments, so that whole output cache lines come from one XCD - the write
 // traffic fell from 2.7x to 1.4x of the algorithmic bytes, the time did not.)
 
+// Work split of the fast emit passes: blocks are dealt to the 8 XCDs round robin (block b runs on XCD b % 8), each
+// XCD has its own L2, and neighbouring records read neighbouring samples.  So every XCD gets ONE contiguous
+// eighth of the record array, and the blocks that are resident on it together walk it side by side.
+struct XcdWalk {
+	uint32_t first, end, stride;
+	__device__ XcdWalk(uint32_t n) {
+		const uint32_t chunks = (n + 255u) / 256u, per_xcd = (chunks + 7u) / 8u;
+		const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, blocks_per_xcd = (gridDim.x + 7u) >> 3;
+		const uint32_t c0 = xcd * per_xcd;
+		first = (c0 + slot) * 256u + threadIdx.x;
+		end = min((c0 + per_xcd) * 256u, n);
+		stride = blocks_per_xcd * 256u;
+	}
+};
+
 // capacity / overflow check shared by both emit kernels; fills the slab offsets of the context
 __device__ __forceinline__ bool emit_prepare(const EmitArgs &a, EmitCtx<sample_t> &c, const Counters &ctr) {
 	const uint64_t gV = a.ghost_segs ? ctr.ghostV : 0, gT = a.ghost_segs ? ctr.ghostT : 0;
@@ -789,8 +804,8 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
-	const uint32_t n = ctr.entry_cursor;
-	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+	const XcdWalk w(ctr.entry_cursor);
+	for (uint32_t e = w.first; e < w.end; e += w.stride) {
 		const Entry en = c.entries[e];
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, c.entry_seg[e]);
 	}
@@ -803,8 +818,8 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
-	const uint32_t n = ctr.entry_cursor;
-	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+	const XcdWalk w(ctr.entry_cursor);
+	for (uint32_t e = w.first; e < w.end; e += w.stride) {
 		const Entry en = c.entries[e];
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, c.entry_seg[e], e, ids);
 	}
@@ -1331,7 +1346,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.capV = capV; a.capT = capT;
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
-	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 32u);
+	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 64u);
 	// The three emit passes are independent (V/N vs T, fast vs slow records) and each is bound by the
 	// latency of scattered reads, not by bandwidth: the vertex pass runs on a second stream beside the
 	// two triangle passes and joins before the end-of-call event.
