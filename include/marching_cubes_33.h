@@ -1,4 +1,4 @@
-/* marching_cubes_33.h -- public C API of the MI355X-native MC33 library (libMC33_{f32,u8,u16,u32}.so).
+/* marching_cubes_33.h -- public C API of the MI355X-native MC33 library (libMC33_{f32,f64,u8,u16,u32}.so).
  *
  * Binary- and source-compatible with the header of dvega68/MC33_c_library (reference
  * include/marching_cubes_33.h): same type names, same struct layouts (checked by static asserts in
@@ -11,8 +11,9 @@
  *   -DINTEGER_GRD -DGRD_TYPE_SIZE=1 GRD_data_type = unsigned char,  MC33_real = float
  *   -DINTEGER_GRD -DGRD_TYPE_SIZE=2 GRD_data_type = unsigned short, MC33_real = float
  *   -DINTEGER_GRD -DGRD_TYPE_SIZE=4 GRD_data_type = unsigned int,   MC33_real = float
- * One library per variant, like the reference's one-type-per-compile model.  Double grids (MC33_real = double)
- * and GRD_ORTHOGONAL are not built (out of scope).
+ *   -DGRD_TYPE_SIZE=8               GRD_data_type = double,         MC33_real = double (vertices, isovalue)
+ * One library per variant, like the reference's one-type-per-compile model.  GRD_ORTHOGONAL is not built
+ * (out of scope).
  */
 #ifndef marching_cubes_33_h
 #define marching_cubes_33_h
@@ -32,7 +33,8 @@ typedef unsigned char GRD_data_type;
 #    error "INTEGER_GRD needs GRD_TYPE_SIZE 1, 2 or 4"
 #  endif
 #elif defined(GRD_TYPE_SIZE) && GRD_TYPE_SIZE == 8
-#  error "double grids are not provided by this build"
+typedef double GRD_data_type;
+typedef double MC33_real;
 #else
 typedef float GRD_data_type;
 typedef float MC33_real;

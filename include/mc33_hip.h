@@ -27,8 +27,8 @@ extern "C" {
 typedef struct mc33hip_ctx mc33hip_ctx;
 
 /* Geometry of the (slab of the) grid one context works on.  Replaces the part of create_MC33 that
- * snapshots _GRD (MC:1758-1782).  sample_bytes: 4 = float, 2 = unsigned short; it must match the
- * library variant (libMC33_f32 / libMC33_u16). */
+ * snapshots _GRD (MC:1758-1782).  sample_bytes must match the library variant: libMC33_f32 4 (float),
+ * libMC33_u8 1, libMC33_u16 2, libMC33_u32 4 (unsigned int), libMC33_f64 8 (double). */
 typedef struct {
 	unsigned int npx, npy;      /* points per row / rows per plane                                       */
 	unsigned int npz_resident;  /* planes resident in this context                                        */
@@ -84,21 +84,22 @@ int mc33hip_set_stream(mc33hip_ctx *c, void *hip_stream);
 
 /* Count pass only: classification + prefix sums; the device twin of size_of_isosurface (MC:1892-1940).
  * Synchronises the stream. */
-int mc33hip_count(mc33hip_ctx *c, float iso, const mc33hip_range *range, mc33hip_counts *out);
+int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *range, mc33hip_counts *out);
 
 /* Global number of the first vertex of the range last counted (z-slab decomposition: known only after
  * the ranks have exchanged their counts).  Takes effect in the next mc33hip_emit. */
 int mc33hip_set_id_base(mc33hip_ctx *c, unsigned int id_base);
 
 /* Emit pass for the range last counted, into caller-owned DEVICE buffers:
- * V, N: capV x 3 floats; T: capT x 3 unsigned.  Replaces the vertex/triangle appends of MC33_findCase
+ * V: capV x 3 MC33_real (float; double in libMC33_f64), N: capV x 3 floats; T: capT x 3 unsigned.  The isovalue
+ * is passed as a double and used as MC33_real.  Replaces the vertex/triangle appends of MC33_findCase
  * (MC:780-1252).  Asynchronous on the context's stream. */
 int mc33hip_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long long capV, unsigned long long capT);
 
 /* Whole extraction (count + emit) with ONE synchronisation at the end; fails with MC33HIP_ECAPACITY
  * (and reports the needed sizes in *out) when the buffers are too small.  This is the path
  * calculate_isosurface (MC:1816-1889) and bench.py use. */
-int mc33hip_extract(mc33hip_ctx *c, float iso, const mc33hip_range *range, void *dV, void *dN, void *dT,
+int mc33hip_extract(mc33hip_ctx *c, double iso, const mc33hip_range *range, void *dV, void *dN, void *dT,
                     unsigned long long capV, unsigned long long capT, mc33hip_counts *out);
 
 int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t);  /* waits for a pending mc33hip_emit */

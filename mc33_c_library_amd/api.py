@@ -78,10 +78,10 @@ def load_library(dtype="f32"):
     lib.mc33hip_upload_contiguous.argtypes = [V, V]
     lib.mc33hip_adopt_device.argtypes = [V, V, C.c_size_t, C.c_size_t]
     lib.mc33hip_set_stream.argtypes = [V, V]
-    lib.mc33hip_count.argtypes = [V, C.c_float, P(Range), P(Counts)]
+    lib.mc33hip_count.argtypes = [V, C.c_double, P(Range), P(Counts)]
     lib.mc33hip_set_id_base.argtypes = [V, C.c_uint]
     lib.mc33hip_emit.argtypes = [V, V, V, V, C.c_ulonglong, C.c_ulonglong]
-    lib.mc33hip_extract.argtypes = [V, C.c_float, P(Range), V, V, V, C.c_ulonglong, C.c_ulonglong, P(Counts)]
+    lib.mc33hip_extract.argtypes = [V, C.c_double, P(Range), V, V, V, C.c_ulonglong, C.c_ulonglong, P(Counts)]
     lib.mc33hip_last_timing.argtypes = [V, P(Timing)]
     lib.mc33hip_download.argtypes = [V, V, V, C.c_size_t]
     lib.mc33hip_device_alloc.argtypes = [V, P(V), C.c_size_t]
@@ -112,8 +112,10 @@ class DeviceGrid:
             self.dtype, sb = "u8", 1
         elif tensor.dtype in (torch.int32, torch.uint32):
             self.dtype, sb = "u32", 4
+        elif tensor.dtype == torch.float64:
+            self.dtype, sb = "f64", 8
         else:
-            raise TypeError("grid samples must be float32, uint8, (u)int16 or (u)int32 bit patterns")
+            raise TypeError("grid samples must be float32, float64, uint8, (u)int16 or (u)int32 bit patterns")
         self.lib = load_library(self.dtype)
         self.tensor = tensor  # keeps the memory alive
         npz, npy, pitch = tensor.shape[0], tensor.shape[1], tensor.stride(1)
@@ -153,7 +155,7 @@ class DeviceGrid:
     def count(self, iso, rng=None):
         rng = rng or self.full_range()
         cnt = Counts()
-        _check(self.lib, self.lib.mc33hip_count(self.ctx, C.c_float(iso), C.byref(rng), C.byref(cnt)))
+        _check(self.lib, self.lib.mc33hip_count(self.ctx, C.c_double(iso), C.byref(rng), C.byref(cnt)))
         return cnt
 
     def extract_into(self, iso, V, N, T, rng=None):
@@ -161,7 +163,7 @@ class DeviceGrid:
         Returns (Counts, enough_capacity)."""
         rng = rng or self.full_range()
         cnt = Counts()
-        rc = self.lib.mc33hip_extract(self.ctx, C.c_float(iso), C.byref(rng), C.c_void_p(V.data_ptr()),
+        rc = self.lib.mc33hip_extract(self.ctx, C.c_double(iso), C.byref(rng), C.c_void_p(V.data_ptr()),
                                       C.c_void_p(N.data_ptr()), C.c_void_p(T.data_ptr()), V.shape[0], T.shape[0],
                                       C.byref(cnt))
         _check(self.lib, rc, allow=(ECAPACITY,))
@@ -179,8 +181,8 @@ class DeviceGrid:
         import torch
         rng = rng or self.full_range()
         cnt = self.count(iso, rng)
-        V = torch.empty((max(cnt.nV, 1), 3), dtype=torch.float32, device=self.device)
-        N = torch.empty_like(V)
+        V = torch.empty((max(cnt.nV, 1), 3), dtype=torch.float64 if self.dtype == "f64" else torch.float32, device=self.device)
+        N = torch.empty((max(cnt.nV, 1), 3), dtype=torch.float32, device=self.device)
         T = torch.empty((max(cnt.nT, 1), 3), dtype=torch.int32, device=self.device)
         _check(self.lib, self.lib.mc33hip_emit(self.ctx, C.c_void_p(V.data_ptr()), C.c_void_p(N.data_ptr()),
                                                C.c_void_p(T.data_ptr()), V.shape[0], T.shape[0]))

@@ -29,6 +29,7 @@ VARIANTS = {
     "u16": {"hip": ["-DMC33_GRD_U16"], "c": ["-DINTEGER_GRD", "-DGRD_TYPE_SIZE=2"]},
     "u8": {"hip": ["-DMC33_GRD_U8"], "c": ["-DINTEGER_GRD", "-DGRD_TYPE_SIZE=1"]},
     "u32": {"hip": ["-DMC33_GRD_U32"], "c": ["-DINTEGER_GRD", "-DGRD_TYPE_SIZE=4"]},
+    "f64": {"hip": ["-DMC33_GRD_F64"], "c": ["-DGRD_TYPE_SIZE=8"]},
 }
 
 
@@ -80,7 +81,7 @@ def build(dtype, force=False, verbose_resources=False):
 def build_all(force=False):
     """All variants; the HIP translation units are compiled side by side (minutes each)."""
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
         return list(ex.map(lambda d: build(d, force), VARIANTS))
 
 

@@ -23,8 +23,13 @@ _Static_assert(sizeof(_GRD) == 416 && offsetof(_GRD, d) == 48 && offsetof(_GRD, 
                offsetof(_GRD, internal_data) == 252, "_GRD layout differs from the reference");
 _Static_assert(sizeof(surface) == 64 && offsetof(surface, iso) == 48 && offsetof(surface, user) == 56,
                "surface layout differs from the reference");
+#if GRD_TYPE_SIZE == 8 /* measured against the reference header compiled with -DGRD_TYPE_SIZE=8 */
+_Static_assert(sizeof(MC33) == 344 && offsetof(MC33, memoryfault) == 56 && offsetof(MC33, O) == 72 && offsetof(MC33, nx) == 136 &&
+               offsetof(MC33, store) == 152 && offsetof(MC33, Dx) == 304, "MC33 layout differs from the reference (double build)");
+#else
 _Static_assert(sizeof(MC33) == 304 && offsetof(MC33, memoryfault) == 52 && offsetof(MC33, nx) == 96 &&
                offsetof(MC33, Dx) == 264, "MC33 layout differs from the reference");
+#endif
 
 #ifndef DEFAULT_SURFACE_COLOR
 #define DEFAULT_SURFACE_COLOR 0xff5c5c5c /* grey, 0xAABBGGRR (MC:76-78) */
@@ -169,7 +174,7 @@ static int ensure_staging(mc33_private *p, unsigned long long nV, unsigned long 
 		if (p->dN) mc33hip_device_free(p->ctx, p->dN);
 		p->dV = p->dN = 0; p->capV = 0;
 		unsigned long long cap = nV + nV / 8 + 1024;
-		if (mc33hip_device_alloc(p->ctx, &p->dV, cap * 12) != MC33HIP_OK) return -1;
+		if (mc33hip_device_alloc(p->ctx, &p->dV, cap * 3 * sizeof(MC33_real)) != MC33HIP_OK) return -1;
 		if (mc33hip_device_alloc(p->ctx, &p->dN, cap * 12) != MC33HIP_OK) return -1;
 		p->capV = cap;
 	}
@@ -222,7 +227,7 @@ surface *calculate_isosurface(MC33 *M, MC33_real iso) {
 	S->T = (unsigned int(*)[3])malloc((nT ? nT : 1) * 3 * sizeof(int));
 	S->color = (int *)malloc(nV * sizeof(int));
 	if (!S->V || !S->N || !S->T || !S->color ||
-	    mc33hip_download(p->ctx, S->V, p->dV, nV * 12) != MC33HIP_OK ||
+	    mc33hip_download(p->ctx, S->V, p->dV, nV * 3 * sizeof(MC33_real)) != MC33HIP_OK ||
 	    mc33hip_download(p->ctx, S->N, p->dN, nV * 12) != MC33HIP_OK ||
 	    mc33hip_download(p->ctx, S->T, p->dT, nT * 12) != MC33HIP_OK) {
 		free(S->V); free(S->N); free(S->T); free(S->color); free(S);

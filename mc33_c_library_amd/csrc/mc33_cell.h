@@ -34,13 +34,21 @@ namespace mc33 {
 constexpr uint32_t SEG_CELLS = 256;  // cells of one row segment (one wave: 64 lanes x 4 samples)
 constexpr uint32_t NO_ID = 0xFFFFFFFFu;
 
+// MC33_real of the reference (marching_cubes_33.h:66-88): corner values, interpolation, vertex positions and the
+// isovalue are float, except in the double build (GRD_TYPE_SIZE 8) where they are double.  Normals are always float.
+#ifdef MC33_REAL_DOUBLE
+typedef double real_t;
+#else
+typedef float real_t;
+#endif
+
 struct Params {
 	uint32_t nx, ny, nz;  // cells per axis (= _GRD.N, marching_cubes_33.h:113)
 	uint32_t nseg;        // row segments per row = ceil(nx / SEG_CELLS)
 	uint32_t zs;          // first cell slice this launch covers (row-segment records are relative to it)
-	float iso;
-	float O[3], D[3];     // float copies of r0, d (MC:1779-1782)
-	float ca, cb;         // MC:1773-1774
+	real_t iso;
+	real_t O[3], D[3];     // MC33_real copies of r0, d (MC:1779-1782)
+	real_t ca, cb;         // MC:1773-1774
 	int32_t store_mode;   // 0: MC33_spn0 (MC:485), 1: MC33_spnA (MC:518), 2: MC33_spnB (MC:551), 3: MC33_spnC (MC:587)
 	int32_t triangular;   // spnC: mult_Abf is _multTSA_bf (UTIL:86-97) rather than _multA_bf (UTIL:99-112)
 	double A[9], Ai[9];   // spnC: M->_A, M->A_ (row major; MC:1763-1770)
@@ -78,6 +86,7 @@ struct GridView {  // pitched copy of _GRD.F in HBM: sample (x,y,z) at p[(z-z0)*
 };
 
 MC33_HD float sample_diff(float a, float b) { return a - b; }
+MC33_HD double sample_diff(double a, double b) { return a - b; }
 // unsigned short promotes to int in the reference's expressions (e.g. MC:851); the difference meets
 // a float operand only afterwards
 MC33_HD float sample_diff(uint16_t a, uint16_t b) { return (float)((int)a - (int)b); }
@@ -86,13 +95,14 @@ MC33_HD float sample_diff(uint8_t a, uint8_t b) { return (float)((int)a - (int)b
 MC33_HD float sample_diff(uint32_t a, uint32_t b) { return (float)(uint32_t)(a - b); }
 
 MC33_HD uint32_t sign_of(float f) { return __builtin_bit_cast(uint32_t, f) >> 31; }  // MC:406-408
+MC33_HD uint32_t sign_of(double f) { return (uint32_t)(__builtin_bit_cast(uint64_t, f) >> 63); }  // MC:402-404
 
 // per-thread arrays living wherever the caller wants them (the stack on the host, an LDS column on
 // the device so that run-time indexing never turns into scratch memory)
 struct VRef {
-	float *p;
+	real_t *p;
 	int stride;
-	MC33_HD float &operator[](int k) const { return p[k * stride]; }
+	MC33_HD real_t &operator[](int k) const { return p[k * stride]; }
 };
 struct URef {
 	uint32_t *p;
@@ -138,11 +148,11 @@ MC33_HD OwnerRef owner_of(uint32_t axis, uint32_t px, uint32_t py, uint32_t pz) 
 
 // the 8 corner values v[k] = iso - F (MC:1840-1855) and the sign index (MC:1846-1859)
 template <typename T>
-MC33_HD uint32_t load_cell(const GridView<T> &G, float iso, uint32_t x, uint32_t y, uint32_t z, const VRef &v) {
+MC33_HD uint32_t load_cell(const GridView<T> &G, real_t iso, uint32_t x, uint32_t y, uint32_t z, const VRef &v) {
 	uint32_t i = 0;
 	for (uint32_t k = 0; k < 8; k++) {
 		const uint32_t c = corner_code(k);
-		const float d = iso - (float)G.at(x + (c & 1), y + ((c >> 1) & 1), z + (c >> 2));
+		const real_t d = iso - (real_t)G.at(x + (c & 1), y + ((c >> 1) & 1), z + (c >> 2));
 		v[k] = d;
 		i |= sign_of(d) << (7 - k);
 	}
@@ -186,8 +196,8 @@ MC33_HD int face_tests(int *face, uint32_t ind, const VRef &v) {  // MC:347-367
 }
 
 MC33_HD int interior_test(int s, int flag13, const VRef &v) {  // MC:431-462
-	float a = v[4] - v[0], b = v[5] - v[1], c = v[6] - v[2], d = v[7] - v[3];
-	float t = a * c - b * d;
+	real_t a = v[4] - v[0], b = v[5] - v[1], c = v[6] - v[2], d = v[7] - v[3];
+	real_t t = a * c - b * d;
 	if (sign_of(t)) {
 		if (s & 1) return 0;
 	} else if (!(s & 1) || t == 0)
@@ -317,7 +327,7 @@ MC33_HD void plan_visit(CellPlan &p, const Tables &tab, const Params &P, const G
 		plan_set_tgt(p, e, make_tgt(edge_axis(e), (int)(c & 1), (int)((c >> 1) & 1), (int)(c >> 2)));
 		return;
 	}
-	const float va = v[(int)a], vb = v[(int)b];
+	const real_t va = v[(int)a], vb = v[(int)b];
 	if (va == 0 || vb == 0) {
 		// the vertex sits on a grid point: try the id sources in the reference's order (MC:791-808 ...)
 		const uint8_t *ix = tab.rule_index + 4 * e;
@@ -340,7 +350,7 @@ MC33_HD void plan_visit(CellPlan &p, const Tables &tab, const Params &P, const G
 			uint32_t pass;
 			if (w & (1u << 13)) {
 				const int fx = (int)((w >> 14) & 3) - 1, fy = (int)((w >> 16) & 3) - 1, fz = (int)((w >> 18) & 3) - 1;
-				pass = sign_of(P.iso - (float)G.at((uint32_t)((int)x + fx), (uint32_t)((int)y + fy), (uint32_t)((int)z + fz)));
+				pass = sign_of(P.iso - (real_t)G.at((uint32_t)((int)x + fx), (uint32_t)((int)y + fy), (uint32_t)((int)z + fz)));
 			} else
 				pass = sign_of(v[(int)arg]);
 			if (!pass) continue;
@@ -465,58 +475,58 @@ MC33_HD uint32_t count_triangles(const CellPlan &p, const Tables &tab, const Par
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
 MC33_HD void vertex_on_edge(const Params &P, const GridView<T> &G, uint32_t x, uint32_t y, uint32_t z, uint32_t e,
-                            const VRef &v, float *r) {  // MC:810-816 ... 1212-1220, SURVEY.md Appendix C
+                            const VRef &v, real_t *r) {  // MC:810-816 ... 1212-1220, SURVEY.md Appendix C
 	const uint32_t a = edge_a(e), b = edge_b(e), axis = edge_axis(e);
 	const uint32_t ca = corner_code(a), cb = corner_code(b);
 	const uint32_t cell[3] = {x, y, z}, lim[3] = {P.nx, P.ny, P.nz};
-	const float va = v[(int)a], vb = v[(int)b];
-	const float t = va / (va - vb);
+	const real_t va = v[(int)a], vb = v[(int)b];
+	const real_t t = va / (va - vb);
 	for (uint32_t ax = 0; ax < 3; ax++) {
 		if (ax == axis) {
-			r[ax] = (float)cell[ax] + t;
+			r[ax] = (real_t)cell[ax] + t;
 			r[3 + ax] = vb - va;
 			continue;
 		}
 		const uint32_t off = (ca >> ax) & 1u;
-		r[ax] = (float)(cell[ax] + off);
+		r[ax] = (real_t)(cell[ax] + off);
 		if (off && cell[ax] + 1 < lim[ax]) {
 			// central differences across the edge at both end points, blended along the edge
 			uint32_t pa[3] = {x + (ca & 1), y + ((ca >> 1) & 1), z + (ca >> 2)};
 			uint32_t pb[3] = {x + (cb & 1), y + ((cb >> 1) & 1), z + (cb >> 2)};
 			uint32_t lo[3] = {pa[0], pa[1], pa[2]}, hi[3] = {pa[0], pa[1], pa[2]};
 			lo[ax]--; hi[ax]++;
-			const float da = sample_diff(G.at(lo[0], lo[1], lo[2]), G.at(hi[0], hi[1], hi[2]));
+			const real_t da = sample_diff(G.at(lo[0], lo[1], lo[2]), G.at(hi[0], hi[1], hi[2]));
 			lo[0] = hi[0] = pb[0]; lo[1] = hi[1] = pb[1]; lo[2] = hi[2] = pb[2];
 			lo[ax]--; hi[ax]++;
-			const float db = sample_diff(G.at(lo[0], lo[1], lo[2]), G.at(hi[0], hi[1], hi[2]));
+			const real_t db = sample_diff(G.at(lo[0], lo[1], lo[2]), G.at(hi[0], hi[1], hi[2]));
 			r[3 + ax] = 0.5f * (da * (1 - t) + db * t);
 		} else {
 			// one-sided: difference of v across the cell at both end points
 			const uint32_t bitax = 1u << ax;
-			const float da = v[(int)corner_at(ca | bitax)] - v[(int)corner_at(ca & ~bitax)];
-			const float db = v[(int)corner_at(cb | bitax)] - v[(int)corner_at(cb & ~bitax)];
+			const real_t da = v[(int)corner_at(ca | bitax)] - v[(int)corner_at(ca & ~bitax)];
+			const real_t db = v[(int)corner_at(cb | bitax)] - v[(int)corner_at(cb & ~bitax)];
 			r[3 + ax] = da * (1 - t) + db * t;
 		}
 	}
 }
 
 template <typename T>
-MC33_HD void vertex_on_point(const Params &P, const GridView<T> &G, uint32_t x, uint32_t y, uint32_t z, float *r) {  // MC:628-649
+MC33_HD void vertex_on_point(const Params &P, const GridView<T> &G, uint32_t x, uint32_t y, uint32_t z, real_t *r) {  // MC:628-649
 	const uint32_t q[3] = {x, y, z}, lim[3] = {P.nx, P.ny, P.nz};
-	r[0] = (float)x; r[1] = (float)y; r[2] = (float)z;
+	r[0] = (real_t)x; r[1] = (real_t)y; r[2] = (real_t)z;
 	for (uint32_t ax = 0; ax < 3; ax++) {
 		uint32_t lo[3] = {x, y, z}, hi[3] = {x, y, z};
 		bool half = false;
 		if (q[ax] == 0) hi[ax] = 1;
 		else if (q[ax] == lim[ax]) lo[ax] = q[ax] - 1;
 		else { lo[ax] = q[ax] - 1; hi[ax] = q[ax] + 1; half = true; }
-		const float d = sample_diff(G.at(lo[0], lo[1], lo[2]), G.at(hi[0], hi[1], hi[2]));
+		const real_t d = sample_diff(G.at(lo[0], lo[1], lo[2]), G.at(hi[0], hi[1], hi[2]));
 		r[3 + ax] = half ? 0.5f * d : d;
 	}
 }
 
-MC33_HD void vertex_centre(uint32_t x, uint32_t y, uint32_t z, const VRef &v, float *r) {  // MC:1225-1230
-	r[0] = (float)x + 0.5f; r[1] = (float)y + 0.5f; r[2] = (float)z + 0.5f;
+MC33_HD void vertex_centre(uint32_t x, uint32_t y, uint32_t z, const VRef &v, real_t *r) {  // MC:1225-1230
+	r[0] = (real_t)x + 0.5f; r[1] = (real_t)y + 0.5f; r[2] = (real_t)z + 0.5f;
 	r[3] = v[4] + v[5] + v[6] + v[7] - v[0] - v[1] - v[2] - v[3];
 	r[4] = v[1] + v[2] + v[5] + v[6] - v[0] - v[3] - v[4] - v[7];
 	r[5] = v[2] + v[3] + v[6] + v[7] - v[0] - v[1] - v[4] - v[5];
@@ -524,19 +534,19 @@ MC33_HD void vertex_centre(uint32_t x, uint32_t y, uint32_t z, const VRef &v, fl
 
 MC33_HD float inv_sqrt_exact(float f) { return 1.0f / sqrtf(f); }  // MC:70-73 (the reference's portable form)
 
-// b <- A b or A^T b (3x3, row major), products and sums in double, rounded to float on assignment: the two
+// b <- A b or A^T b (3x3, row major), products and sums in double, rounded to MC33_real on assignment: the two
 // forms of the reference's mult_Abf (UTIL:86-112).  The triangular form skips the zero terms and writes its
 // results one by one, which matters for the rounding of nothing but is kept for -0 / non-finite inputs.
-MC33_HD void mat_vec(const double *A, float *b, bool transposed, bool triangular) {
+MC33_HD void mat_vec(const double *A, real_t *b, bool transposed, bool triangular) {
 	if (triangular) {
 		if (transposed) {
-			b[2] = (float)(A[2] * b[0] + A[5] * b[1] + A[8] * b[2]);
-			b[1] = (float)(A[1] * b[0] + A[4] * b[1]);
-			b[0] = (float)(A[0] * b[0]);
+			b[2] = (real_t)(A[2] * b[0] + A[5] * b[1] + A[8] * b[2]);
+			b[1] = (real_t)(A[1] * b[0] + A[4] * b[1]);
+			b[0] = (real_t)(A[0] * b[0]);
 		} else {
-			b[0] = (float)(A[0] * b[0] + A[1] * b[1] + A[2] * b[2]);
-			b[1] = (float)(A[4] * b[1] + A[5] * b[2]);
-			b[2] = (float)(A[8] * b[2]);
+			b[0] = (real_t)(A[0] * b[0] + A[1] * b[1] + A[2] * b[2]);
+			b[1] = (real_t)(A[4] * b[1] + A[5] * b[2]);
+			b[2] = (real_t)(A[8] * b[2]);
 		}
 		return;
 	}
@@ -544,18 +554,18 @@ MC33_HD void mat_vec(const double *A, float *b, bool transposed, bool triangular
 	if (transposed) {
 		u = A[0] * b[0] + A[3] * b[1] + A[6] * b[2];
 		v = A[1] * b[0] + A[4] * b[1] + A[7] * b[2];
-		b[2] = (float)(A[2] * b[0] + A[5] * b[1] + A[8] * b[2]);
+		b[2] = (real_t)(A[2] * b[0] + A[5] * b[1] + A[8] * b[2]);
 	} else {
 		u = A[0] * b[0] + A[1] * b[1] + A[2] * b[2];
 		v = A[3] * b[0] + A[4] * b[1] + A[5] * b[2];
-		b[2] = (float)(A[6] * b[0] + A[7] * b[1] + A[8] * b[2]);
+		b[2] = (real_t)(A[6] * b[0] + A[7] * b[1] + A[8] * b[2]);
 	}
-	b[0] = (float)u; b[1] = (float)v;
+	b[0] = (real_t)u; b[1] = (real_t)v;
 }
 
 // world position and unit normal of vertex `id` (MC:485-621)
-MC33_HD void store_vertex(const Params &P, float *r, float *V, float *N, uint32_t id) {
-	float *p = V + 3 * (uint64_t)id;
+MC33_HD void store_vertex(const Params &P, real_t *r, real_t *V, float *N, uint32_t id) {
+	real_t *p = V + 3 * (uint64_t)id;
 	if (P.store_mode == 0) {
 		p[0] = r[0]; p[1] = r[1]; p[2] = r[2];
 	} else if (P.store_mode == 3) {  // MC:607-612
@@ -566,9 +576,10 @@ MC33_HD void store_vertex(const Params &P, float *r, float *V, float *N, uint32_
 		for (int k = 0; k < 3; k++) p[k] = r[k] * P.D[k] + P.O[k];
 		if (P.store_mode == 2) { r[3] *= P.ca; r[4] *= P.cb; }
 	}
-	const float s = inv_sqrt_exact(r[3] * r[3] + r[4] * r[4] + r[5] * r[5]);
+	// MC:510-515: the squared length is MC33_real, the inverse root and the normal are float
+	const float s = inv_sqrt_exact((float)(r[3] * r[3] + r[4] * r[4] + r[5] * r[5]));
 	float *n = N + 3 * (uint64_t)id;
-	n[0] = s * r[3]; n[1] = s * r[4]; n[2] = s * r[5];
+	n[0] = s * (float)r[3]; n[1] = s * (float)r[4]; n[2] = s * (float)r[5];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -626,13 +637,13 @@ inline void build_fast_table(const uint16_t *lut, uint32_t *fast /*[256]*/) {
 	Tables tab{lut, nullptr, nullptr};
 	Params P{};
 	P.nx = P.ny = P.nz = 1u << 20;
-	GridView<float> G{nullptr, 0, 0, 0};
+	GridView<real_t> G{nullptr, 0, 0, 0};
 	for (uint32_t i = 0; i < 256; i++) {
 		fast[i] = FAST_NONE;
 		if (i == 0 || i == 255) continue;
 		const uint32_t c = lut[(i & 0x80) ? (i ^ 0xFF) : i];
 		if (c >> 12) continue;  // needs face / interior tests
-		float vb[8];
+		real_t vb[8];
 		for (int k = 0; k < 8; k++) vb[k] = ((i >> (7 - k)) & 1) ? -1.0f : 1.0f;
 		CellPlan p;
 		plan_cell(p, tab, P, G, 1, 1, 1, i, VRef{vb, 1});  // interior cell, no corner equal to iso: no rule is consulted
@@ -688,7 +699,8 @@ struct EmitCtx {
 	const uint64_t *seg_mask;
 	const Entry *entries;
 	const uint32_t *entry_seg;  // row segment of each entry
-	float *V, *N;
+	real_t *V;
+	float *N;
 	uint32_t *Tri;
 	// z-slab decomposition: cells below z_emit are ghosts (counted so that ids of the slab interface
 	// can be looked up, but written by the rank below); local vertex k is stored at k - v_skip and is
@@ -758,7 +770,7 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 		if (r != 15u) {
 			ids[(int)e] = vbase + r;
 			if (p.created & (1u << e)) {
-				float g[6];
+				real_t g[6];
 				if (e == 12) vertex_centre(x, y, z, v, g);
 				else if (p.onpoint & (1u << e)) {
 					const uint32_t cc = corner_code((p.onb & (1u << e)) ? edge_b(e) : edge_a(e));
@@ -788,14 +800,14 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 // vertex of one of the three owned edges (5: z-edge, 6: y-edge, 10: x-edge, all through corner 6) of an
 // interior cell; same arithmetic as vertex_on_edge, written out so that every index is static
 template <typename T, int E>
-MC33_HD void fast_owned_vertex(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint32_t z, const float *v, uint32_t id) {
+MC33_HD void fast_owned_vertex(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint32_t z, const real_t *v, uint32_t id) {
 	const Params &P = c.P;
 	const GridView<T> &G = c.G;
-	float r[6];
-	const float v6 = v[6];
+	real_t r[6];
+	const real_t v6 = v[6];
 	if (E == 5) {
-		const float va = v[5], t = va / (va - v6);
-		r[0] = (float)(x + 1); r[1] = (float)(y + 1); r[2] = (float)z + t;
+		const real_t va = v[5], t = va / (va - v6);
+		r[0] = (real_t)(x + 1); r[1] = (real_t)(y + 1); r[2] = (real_t)z + t;
 		r[3] = (x + 1 < P.nx) ? 0.5f * (sample_diff(G.at(x, y + 1, z), G.at(x + 2, y + 1, z)) * (1 - t) +
 		                               sample_diff(G.at(x, y + 1, z + 1), G.at(x + 2, y + 1, z + 1)) * t)
 		                      : (v[5] - v[1]) * (1 - t) + (v6 - v[2]) * t;
@@ -804,8 +816,8 @@ MC33_HD void fast_owned_vertex(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint
 		                      : (v[5] - v[4]) * (1 - t) + (v6 - v[7]) * t;
 		r[5] = v6 - va;
 	} else if (E == 6) {
-		const float va = v[7], t = va / (va - v6);
-		r[0] = (float)(x + 1); r[1] = (float)y + t; r[2] = (float)(z + 1);
+		const real_t va = v[7], t = va / (va - v6);
+		r[0] = (real_t)(x + 1); r[1] = (real_t)y + t; r[2] = (real_t)(z + 1);
 		r[3] = (x + 1 < P.nx) ? 0.5f * (sample_diff(G.at(x, y, z + 1), G.at(x + 2, y, z + 1)) * (1 - t) +
 		                               sample_diff(G.at(x, y + 1, z + 1), G.at(x + 2, y + 1, z + 1)) * t)
 		                      : (v[7] - v[3]) * (1 - t) + (v6 - v[2]) * t;
@@ -814,8 +826,8 @@ MC33_HD void fast_owned_vertex(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint
 		                               sample_diff(G.at(x + 1, y + 1, z), G.at(x + 1, y + 1, z + 2)) * t)
 		                      : (v[7] - v[4]) * (1 - t) + (v6 - v[5]) * t;
 	} else {
-		const float va = v[2], t = va / (va - v6);
-		r[0] = (float)x + t; r[1] = (float)(y + 1); r[2] = (float)(z + 1);
+		const real_t va = v[2], t = va / (va - v6);
+		r[0] = (real_t)x + t; r[1] = (real_t)(y + 1); r[2] = (real_t)(z + 1);
 		r[3] = v6 - va;
 		r[4] = (y + 1 < P.ny) ? 0.5f * (sample_diff(G.at(x, y, z + 1), G.at(x, y + 2, z + 1)) * (1 - t) +
 		                               sample_diff(G.at(x + 1, y, z + 1), G.at(x + 1, y + 2, z + 1)) * t)
@@ -860,13 +872,13 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 		Y2[q][0] = yq.a; Y2[q][1] = yq.b;
 		Z2[q][0] = zq.a; Z2[q][1] = zq.b;
 	}
-	const float iso = P.iso;
-	const float v1 = iso - (float)F[1][0], v2 = iso - (float)F[3][0], v3 = iso - (float)F[2][0];
-	const float v4 = iso - (float)F[0][1], v5 = iso - (float)F[1][1], v6 = iso - (float)F[3][1], v7 = iso - (float)F[2][1];
-	float r[6];
+	const real_t iso = P.iso;
+	const real_t v1 = iso - (real_t)F[1][0], v2 = iso - (real_t)F[3][0], v3 = iso - (real_t)F[2][0];
+	const real_t v4 = iso - (real_t)F[0][1], v5 = iso - (real_t)F[1][1], v6 = iso - (real_t)F[3][1], v7 = iso - (real_t)F[2][1];
+	real_t r[6];
 	if (r5 != 15u) {  // edge 5: (x+1, y+1, z) -> (x+1, y+1, z+1)
-		const float t = v5 / (v5 - v6);
-		r[0] = (float)(x + 1); r[1] = (float)(y + 1); r[2] = (float)z + t;
+		const real_t t = v5 / (v5 - v6);
+		r[0] = (real_t)(x + 1); r[1] = (real_t)(y + 1); r[2] = (real_t)z + t;
 		r[3] = xin ? 0.5f * (sample_diff(F[1][0], F[1][2]) * (1 - t) + sample_diff(F[3][0], F[3][2]) * t)
 		           : (v5 - v1) * (1 - t) + (v6 - v2) * t;
 		r[4] = yin ? 0.5f * (sample_diff(F[0][1], Y2[0][1]) * (1 - t) + sample_diff(F[2][1], Y2[1][1]) * t)
@@ -875,8 +887,8 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 		store_vertex(P, r, c.V, c.N, vbase + r5 - c.v_skip);
 	}
 	if (r6 != 15u) {  // edge 6: (x+1, y, z+1) -> (x+1, y+1, z+1)
-		const float t = v7 / (v7 - v6);
-		r[0] = (float)(x + 1); r[1] = (float)y + t; r[2] = (float)(z + 1);
+		const real_t t = v7 / (v7 - v6);
+		r[0] = (real_t)(x + 1); r[1] = (real_t)y + t; r[2] = (real_t)(z + 1);
 		r[3] = xin ? 0.5f * (sample_diff(F[2][0], F[2][2]) * (1 - t) + sample_diff(F[3][0], F[3][2]) * t)
 		           : (v7 - v3) * (1 - t) + (v6 - v2) * t;
 		r[4] = v6 - v7;
@@ -885,8 +897,8 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 		store_vertex(P, r, c.V, c.N, vbase + r6 - c.v_skip);
 	}
 	if (r10 != 15u) {  // edge 10: (x, y+1, z+1) -> (x+1, y+1, z+1)
-		const float t = v2 / (v2 - v6);
-		r[0] = (float)x + t; r[1] = (float)(y + 1); r[2] = (float)(z + 1);
+		const real_t t = v2 / (v2 - v6);
+		r[0] = (real_t)x + t; r[1] = (real_t)(y + 1); r[2] = (real_t)(z + 1);
 		r[3] = v6 - v2;
 		r[4] = yin ? 0.5f * (sample_diff(F[2][0], Y2[1][0]) * (1 - t) + sample_diff(F[2][1], Y2[1][1]) * t)
 		           : (v2 - v3) * (1 - t) + (v6 - v7) * t;

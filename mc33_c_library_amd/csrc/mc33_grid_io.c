@@ -107,6 +107,9 @@ _GRD *read_grd(const char *filename) { /* UTIL:181-263 */
 #ifdef INTEGER_GRD
 				double v = 0; /* the reference scans "%f" into the integer sample (undefined); here: value, converted */
 				const int got = fscanf(f, "%lf", &v);
+#elif GRD_TYPE_SIZE == 8
+				double v = 0;
+				const int got = fscanf(f, "%lf", &v);
 #else
 				float v = 0; /* decimal -> float in one rounding, as the reference's "%f" */
 				const int got = fscanf(f, "%f", &v);

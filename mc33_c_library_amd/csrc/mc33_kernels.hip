@@ -2,6 +2,7 @@
 // of the MI355X Marching Cubes 33 extractor.  One shared object per grid sample type, like the
 // reference's one-type-per-compile model (reference include/marching_cubes_33.h:57-88):
 //     default            -> float samples          (libMC33_f32.so)
+//     -DMC33_GRD_F64     -> double samples AND double arithmetic / vertices (libMC33_f64.so)
 //     -DMC33_GRD_U16     -> unsigned short samples  (libMC33_u16.so)
 //
 // Passes ("MC:" = reference source/marching_cubes_33.c):
@@ -25,6 +26,9 @@
 #include <vector>
 
 #include "../../include/mc33_hip.h"
+#ifdef MC33_GRD_F64
+#define MC33_REAL_DOUBLE  // MC33_real is double in the double build (reference marching_cubes_33.h:80-82)
+#endif
 #include "mc33_cell.h"
 #include "mc33_lut_data.h"
 #include "mc33_rules_data.h"
@@ -40,6 +44,9 @@ typedef uint8_t sample_t;
 #elif defined(MC33_GRD_U32)
 typedef uint32_t sample_t;
 #define MC33_SAMPLE_BYTES 4
+#elif defined(MC33_GRD_F64)
+typedef double sample_t;
+#define MC33_SAMPLE_BYTES 8
 #else
 typedef float sample_t;
 #define MC33_SAMPLE_BYTES 4
@@ -112,6 +119,10 @@ static void fast_record_table(const uint32_t *fast, uint4 *out) {
 	}
 }
 
+__device__ __forceinline__ float real_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double real_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float real_abs(float a) { return fabsf(a); }
+__device__ __forceinline__ double real_abs(double a) { return fabs(a); }
 __device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return (uint64_t)hi << 32 | lo; }
 __device__ __forceinline__ uint32_t row_above(uint32_t v) {  // lane r <- lane r+1 (lane 63 <- 0): DPP wave_shl:1
 	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
 	const uint32_t nrows = min(64u, P.ny + 1 - y0);  // sample rows of this tile
 	const uint32_t z_lo = tile.z_lo, z_hi = tile.z_hi;
-	const float iso = P.iso;
+	const real_t iso = P.iso;
 
 	// per-lane byte offsets of its four samples inside a row (clamped into the row: bits of samples
 	// beyond the grid belong to cells that the valid masks remove)
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	uint32_t c_lo[4] = {0, 0, 0, 0}, c_hi[4] = {0, 0, 0, 0};
 	uint32_t cur_h = 0, prev_h = 0;
 	bool cur_z = false, prev_z = false;
-	float zmin = 1.0f;  // min |iso - F| over the lane's samples of the plane being assembled
+	real_t zmin = 1;  // min |iso - F| over the lane's samples of the plane being assembled
 
 	// The tile is consumed as a linear stream of batches of 4 sample rows (16 coalesced 256-byte loads per
 	// wave), plane after plane.  Two register buffers: the loads of batch t+1 are in flight while batch t
@@ -213,12 +224,14 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 #define MC33_LOAD(rs, vo, so) ((float)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rs, vo, so, 0))
 #elif defined(MC33_GRD_U32)
 #define MC33_LOAD(rs, vo, so) ((float)(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0))
+#elif defined(MC33_GRD_F64)
+#define MC33_LOAD(rs, vo, so) (__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0)))
 #else
 #define MC33_LOAD(rs, vo, so) (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0)))
 #endif
 	// every batch is exactly 17 loads, whatever the position in the tile (the wait counts the compiler
 	// derives are then exact and the prefetched batch really stays in flight)
-	auto issue = [&](float (&d)[16], float &hv, uint32_t p, uint32_t bi) {
+	auto issue = [&](real_t (&d)[16], real_t &hv, uint32_t p, uint32_t bi) {
 		const sample_t *base = a.G.p + (uint64_t)(p - a.G.z0) * a.G.slice + (uint64_t)y0 * a.G.pitch;
 		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, tile_bytes, 0x00020000);
 		const uint32_t r = bi * 4u;
@@ -231,8 +244,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		hv = MC33_LOAD(rs, (lane >> 2) == bi ? xh : 0xFFFFFFF0u, 0u);
 	};
 
-	float halo = 0.f;  // lane r: halo sample of row r of the plane being assembled
-	auto process = [&](const float (&dd)[16], const float &hv, uint32_t p, uint32_t bi) {
+	real_t halo = 0;  // lane r: halo sample of row r of the plane being assembled
+	auto process = [&](const real_t (&dd)[16], const real_t &hv, uint32_t p, uint32_t bi) {
 		const uint32_t r = bi * 4u;
 		halo = (lane >> 2) == bi ? hv : halo;
 #pragma unroll
@@ -240,10 +253,10 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 			uint32_t m[8];
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
-				const float d = iso - dd[rr * 4 + k];                    // MC:1852-1855
-				const uint64_t bb = __ballot(__float_as_int(d) < 0);      // MC:1856-1859 (sign bit)
+				const real_t d = iso - dd[rr * 4 + k];                   // MC:1852-1855
+				const uint64_t bb = __ballot(sign_of(d) != 0);            // MC:1856-1859 (sign bit)
 				m[2 * k] = (uint32_t)bb; m[2 * k + 1] = (uint32_t)(bb >> 32);
-				zmin = fminf(zmin, fabsf(d));
+				zmin = real_min(zmin, real_abs(d));
 			}
 			// park the bit row of sample row r+rr in lane r+rr: v_writelane takes its lane select from M0
 			// when the data operand is an SGPR too (one SGPR per VOP3 on gfx9-class encodings)
@@ -262,11 +275,11 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 #pragma unroll
 		for (int k = 0; k < 4; k++) { cur[k] = u64(c_lo[k], c_hi[k]); c_lo[k] = c_hi[k] = 0; }
 		{
-			const float dh = iso - halo;
-			cur_h = (uint32_t)(__float_as_int(dh) < 0);
-			if (lane < nrows) zmin = fminf(zmin, fabsf(dh));  // lanes past the tile never loaded a halo sample
-			cur_z = __ballot(zmin == 0.0f) != 0ull;  // some sample of this plane of the tile equals the isovalue
-			zmin = 1.0f;
+			const real_t dh = iso - halo;
+			cur_h = sign_of(dh);
+			if (lane < nrows) zmin = real_min(zmin, real_abs(dh));  // lanes past the tile never loaded a halo sample
+			cur_z = __ballot(zmin == 0) != 0ull;  // some sample of this plane of the tile equals the isovalue
+			zmin = 1;
 		}
 		if (p > z_lo && !(a.debug & 2u)) {
 			uint64_t act[4];
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		prev_z = cur_z;
 	};
 
-	float dA[16], dB[16], hA = 0.f, hB = 0.f;
+	real_t dA[16], dB[16], hA = 0, hB = 0;
 	uint32_t ip = z_lo, ib = 0, pp = z_lo, pb = 0;  // (plane, batch) of the next issue / of the next process
 	// past the end of the tile the prefetch simply re-reads the last batch (it is never processed)
 #define MC33_ADV(p_, b_) do { if (++(b_) == NB) { (b_) = 0; ++(p_); } } while (0)
@@ -601,8 +614,8 @@ struct SlowArgs {
 };
 
 __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
-	__shared__ float s_v[8][256];
-	__shared__ float s_w[8][256];
+	__shared__ real_t s_v[8][256];
+	__shared__ real_t s_w[8][256];
 	if (a.ctr->entry_cursor > a.entry_cap || a.ctr->mask_cursor > a.entry_cap) return;  // the sweep will be repeated with more room
 	const uint32_t n = a.ctr->slow_cursor;
 	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
@@ -826,8 +839,8 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_emit_slow(const EmitArgs a) {
-	__shared__ float s_v[8][256];
-	__shared__ float s_w[8][256];
+	__shared__ real_t s_v[8][256];
+	__shared__ real_t s_w[8][256];
 	__shared__ uint32_t s_id[13][256];
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
@@ -1084,15 +1097,15 @@ static int check_range(mc33hip_ctx *c, const mc33hip_range *r) {
 	return 0;
 }
 
-static void fill_params(mc33hip_ctx *c, float iso, const mc33hip_range *r) {
+static void fill_params(mc33hip_ctx *c, double iso, const mc33hip_range *r) {
 	const mc33hip_grid_desc &d = c->desc;
 	Params &P = c->P;
 	P.nx = d.npx - 1; P.ny = d.npy - 1; P.nz = d.nz_total;
 	P.nseg = (P.nx + SEG_CELLS - 1) / SEG_CELLS;
 	P.zs = r->z_begin - (r->ghost_below ? 1u : 0u);
-	P.iso = iso;
+	P.iso = (real_t)iso;
 	// store selection and float copies: MC:1772-1782
-	if (d.d[0] != d.d[1] || d.d[1] != d.d[2]) { P.store_mode = 2; P.ca = (float)(d.d[2] / d.d[0]); P.cb = (float)(d.d[2] / d.d[1]); }
+	if (d.d[0] != d.d[1] || d.d[1] != d.d[2]) { P.store_mode = 2; P.ca = (real_t)(d.d[2] / d.d[0]); P.cb = (real_t)(d.d[2] / d.d[1]); }
 	else { P.store_mode = (d.d[0] == 1 && d.r0[0] == 0 && d.r0[1] == 0 && d.r0[2] == 0) ? 0 : 1; P.ca = P.cb = 1.0f; }
 	P.triangular = 0;
 	for (int k = 0; k < 9; k++) P.A[k] = P.Ai[k] = 0.0;
@@ -1105,7 +1118,7 @@ static void fill_params(mc33hip_ctx *c, float iso, const mc33hip_range *r) {
 				P.Ai[3 * j + i] = c->grd_Ai[3 * j + i] / d.d[j];
 			}
 	}
-	for (int k = 0; k < 3; k++) { P.O[k] = (float)d.r0[k]; P.D[k] = (float)d.d[k]; }
+	for (int k = 0; k < 3; k++) { P.O[k] = (real_t)d.r0[k]; P.D[k] = (real_t)d.d[k]; }
 	c->range = *r;
 	c->nsegs = (uint64_t)(r->z_end - P.zs) * P.ny * P.nseg;
 	c->ghost_segs = r->ghost_below ? (uint64_t)P.ny * P.nseg : 0;
@@ -1338,7 +1351,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.c.G.p = c->d_grid; a.c.G.pitch = (uint32_t)c->pitch; a.c.G.z0 = c->desc.plane0; a.c.G.slice = c->slice;
 	a.c.seg_base = c->seg_base; a.c.seg_dir = c->seg_dir; a.c.seg_mask = c->seg_mask;
 	a.c.entries = c->entries; a.c.entry_seg = c->entry_seg;
-	a.c.V = (float *)dV; a.c.N = (float *)dN; a.c.Tri = (uint32_t *)dT;
+	a.c.V = (real_t *)dV; a.c.N = (float *)dN; a.c.Tri = (uint32_t *)dT;
 	a.c.z_emit = c->range.z_begin; a.c.v_skip = a.c.t_skip = a.c.id_delta = 0;
 	a.ctr = c->d_ctr;
 	a.slow_list = c->slow_list;
@@ -1427,7 +1440,7 @@ static void read_timing(mc33hip_ctx *c, bool with_emit, unsigned launches) {
 	t.sweep_launches = launches;
 }
 
-extern "C" int mc33hip_count(mc33hip_ctx *c, float iso, const mc33hip_range *range, mc33hip_counts *out) {
+extern "C" int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *range, mc33hip_counts *out) {
 	if (!c) return MC33HIP_EINVAL;
 	int rc = use_device(c);
 	if (rc) return rc;
@@ -1474,7 +1487,7 @@ extern "C" int mc33hip_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsign
 	return enqueue_emit(c, dV, dN, dT, capV, capT);
 }
 
-extern "C" int mc33hip_extract(mc33hip_ctx *c, float iso, const mc33hip_range *range, void *dV, void *dN, void *dT,
+extern "C" int mc33hip_extract(mc33hip_ctx *c, double iso, const mc33hip_range *range, void *dV, void *dN, void *dT,
                                unsigned long long capV, unsigned long long capT, mc33hip_counts *out) {
 	if (!c) return MC33HIP_EINVAL;
 	int rc = use_device(c);

@@ -17,6 +17,13 @@
 
 #define SUP_MAGIC_FLOAT 0x7075732e  /* ".sup" */
 #define SUP_MAGIC_DOUBLE 0x6575732e /* ".sud" */
+#if GRD_TYPE_SIZE == 8 /* the double build writes ".sud" and converts ".sup" files when reading (MC:128-131) */
+#define SUP_MAGIC_OWN SUP_MAGIC_DOUBLE
+typedef float other_real;
+#else
+#define SUP_MAGIC_OWN SUP_MAGIC_FLOAT
+typedef double other_real;
+#endif
 
 /* one fwrite of `bytes` bytes, reference style: an item count of 1, so a zero-length block "fails" */
 static size_t put_block(FILE *f, const void *p, size_t bytes) { return fwrite(p, bytes, 1, f); }
@@ -27,7 +34,7 @@ int write_bin_s(surface *S, const char *filename) { /* MC:139-157 */
 	FILE *f = fopen(filename, "wb");
 	if (!f)
 		return -1;
-	const int32_t head[1] = {SUP_MAGIC_FLOAT};
+	const int32_t head[1] = {SUP_MAGIC_OWN};
 	put_block(f, head, sizeof head);
 	put_block(f, &S->iso, sizeof(MC33_real));
 	put_block(f, &S->nV, sizeof(int32_t));
@@ -51,9 +58,9 @@ surface *read_bin_s(const char *filename) { /* MC:159-219 */
 		fclose(f);
 		return 0;
 	}
-	const int wide = magic == SUP_MAGIC_DOUBLE; /* written by a double build: iso and V are doubles */
+	const int wide = magic != SUP_MAGIC_OWN; /* written by the build of the other precision: iso and V are converted */
 	if (wide) {
-		double iso = 0;
+		other_real iso = 0;
 		get_block(f, &iso, sizeof iso);
 		S->iso = (MC33_real)iso;
 	} else
@@ -71,7 +78,7 @@ surface *read_bin_s(const char *filename) { /* MC:159-219 */
 		get_block(f, S->T, (size_t)S->nT * 3 * sizeof(int32_t));
 		if (wide) {
 			for (unsigned int j = 0; j < S->nV; j++) {
-				double v[3];
+				other_real v[3];
 				get_block(f, v, sizeof v);
 				S->V[j][0] = (MC33_real)v[0]; S->V[j][1] = (MC33_real)v[1]; S->V[j][2] = (MC33_real)v[2];
 			}

@@ -135,28 +135,35 @@ typedef struct {
 	const mc33o_sample *F;
 	uint32_t px, py, pz; /* points per axis */
 	uint32_t nx, ny, nz; /* cells per axis  */
-	float iso;
-	float O[3], D[3], ca, cb;
+	mc33o_real iso;
+	mc33o_real O[3], D[3], ca, cb;
 	int store_mode;      /* 0: spn0 (MC:485), 1: spnA (MC:518), 2: spnB (MC:551), 3: spnC (MC:587) */
 	double A[3][3], Ai[3][3]; /* spnC: _A[j][i]*d[i] and A_[j][i]/d[j] (MC:1763-1770) */
 	int triangular;      /* spnC: mult_Abf points at _multTSA_bf (UTIL:86-97) instead of _multA_bf (UTIL:99-112) */
 	uint32_t nV, nT, capV, capT;
-	float *V, *N;
+	mc33o_real *V;
+	float *N;
 	uint32_t *T;
 	int fault;
 	uint32_t *idX[2], *idY[2], *idZ; /* ids of x/y edges on the two live planes, z edges of the slice */
 } oracle_ctx;
 
-static inline uint32_t sign_of(float f) { uint32_t u; memcpy(&u, &f, 4); return u >> 31; } /* MC:406-408 */
+static inline uint32_t sign_of(mc33o_real f) { /* MC:402-408 */
+#ifdef MC33_ORACLE_F64
+	uint64_t u; memcpy(&u, &f, 8); return (uint32_t)(u >> 63);
+#else
+	uint32_t u; memcpy(&u, &f, 4); return u >> 31;
+#endif
+}
 
 static inline mc33o_sample sample(const oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z) {
 	return c->F[((size_t)z * c->py + y) * c->px + x];
 }
 
-/* difference of two samples as the reference's expression yields it: float for float grids,
+/* difference of two samples as the reference's expression yields it: float / double for float / double grids,
  * int (then converted) for unsigned char / short grids (integer promotion), unsigned modulo 2^32 for
  * unsigned int grids (no promotion) */
-static inline float sdiff(mc33o_sample a, mc33o_sample b) {
+static inline mc33o_real sdiff(mc33o_sample a, mc33o_sample b) {
 #if defined(MC33_ORACLE_U16) || defined(MC33_ORACLE_U8)
 	return (float)((int)a - (int)b);
 #elif defined(MC33_ORACLE_U32)
@@ -174,8 +181,8 @@ static uint32_t *id_slot(oracle_ctx *c, int axis, uint32_t x, uint32_t y, uint32
 	}
 }
 
-/* c = A b or A^T b in double, rounded to float on assignment: the two forms of mult_Abf (UTIL:86-112) */
-static void mat_vec(const double (*A)[3], float *b, int transposed, int triangular) {
+/* c = A b or A^T b in double, rounded to MC33_real on assignment: the two forms of mult_Abf (UTIL:86-112) */
+static void mat_vec(const double (*A)[3], mc33o_real *b, int transposed, int triangular) {
 	if (triangular) {
 		if (transposed) {
 			b[2] = A[0][2] * b[0] + A[1][2] * b[1] + A[2][2] * b[2];
@@ -202,11 +209,11 @@ static void mat_vec(const double (*A)[3], float *b, int transposed, int triangul
 }
 
 /* append one vertex: r[0..2] grid-index position, r[3..5] gradient (MC:485-621) */
-static uint32_t emit_vertex(oracle_ctx *c, float *r) {
+static uint32_t emit_vertex(oracle_ctx *c, mc33o_real *r) {
 	uint32_t id = c->nV;
 	if (id == c->capV) {
 		uint32_t ncap = c->capV * 2;
-		float *nv = (float *)realloc(c->V, (size_t)ncap * 3 * sizeof(float));
+		mc33o_real *nv = (mc33o_real *)realloc(c->V, (size_t)ncap * 3 * sizeof(mc33o_real));
 		if (nv) c->V = nv;
 		float *nn = (float *)realloc(c->N, (size_t)ncap * 3 * sizeof(float));
 		if (nn) c->N = nn;
@@ -214,7 +221,7 @@ static uint32_t emit_vertex(oracle_ctx *c, float *r) {
 		c->capV = ncap;
 	}
 	c->nV++;
-	float *p = c->V + 3 * (size_t)id;
+	mc33o_real *p = c->V + 3 * (size_t)id;
 	if (c->store_mode == 0) {
 		p[0] = r[0]; p[1] = r[1]; p[2] = r[2];
 	} else if (c->store_mode == 3) { /* MC:607-612 */
@@ -225,43 +232,44 @@ static uint32_t emit_vertex(oracle_ctx *c, float *r) {
 		for (int k = 0; k < 3; k++) p[k] = r[k] * c->D[k] + c->O[k];
 		if (c->store_mode == 2) { r[3] *= c->ca; r[4] *= c->cb; }
 	}
-	float s = 1.0f / sqrtf(r[3] * r[3] + r[4] * r[4] + r[5] * r[5]); /* MC:70-73 exact form */
+	/* MC:510-515 with the exact form of invSqrt (MC:70-73): the sum is MC33_real, the root and the normal are float */
+	float s = 1.0f / sqrtf((float)(r[3] * r[3] + r[4] * r[4] + r[5] * r[5]));
 	float *n = c->N + 3 * (size_t)id;
-	n[0] = s * r[3]; n[1] = s * r[4]; n[2] = s * r[5];
+	n[0] = s * (float)r[3]; n[1] = s * (float)r[4]; n[2] = s * (float)r[5];
 	return id;
 }
 
 /* vertex exactly on grid point (x,y,z): MC:628-649 */
 static uint32_t emit_on_point(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z) {
-	float r[6];
+	mc33o_real r[6];
 	const uint32_t q[3] = {x, y, z}, lim[3] = {c->nx, c->ny, c->nz};
-	r[0] = (float)x; r[1] = (float)y; r[2] = (float)z;
+	r[0] = (mc33o_real)x; r[1] = (mc33o_real)y; r[2] = (mc33o_real)z;
 	for (int ax = 0; ax < 3; ax++) {
 		uint32_t lo[3] = {x, y, z}, hi[3] = {x, y, z};
-		float w;
+		mc33o_real w;
 		if (q[ax] == 0) { hi[ax] = 1; w = 1.0f; }
 		else if (q[ax] == lim[ax]) { lo[ax] = q[ax] - 1; w = 1.0f; }
 		else { lo[ax] = q[ax] - 1; hi[ax] = q[ax] + 1; w = 0.5f; }
-		float dlt = sdiff(sample(c, lo[0], lo[1], lo[2]), sample(c, hi[0], hi[1], hi[2]));
+		mc33o_real dlt = sdiff(sample(c, lo[0], lo[1], lo[2]), sample(c, hi[0], hi[1], hi[2]));
 		r[3 + ax] = (w == 1.0f) ? dlt : 0.5f * dlt;
 	}
 	return emit_vertex(c, r);
 }
 
 /* regular vertex on edge e of cell (x,y,z): MC:810-816 ... 1212-1220 and SURVEY Appendix C */
-static uint32_t emit_on_edge(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, int e, const float *v) {
+static uint32_t emit_on_edge(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, int e, const mc33o_real *v) {
 	const edge_rule *E = &EDGE[e];
 	const uint32_t cell[3] = {x, y, z}, lim[3] = {c->nx, c->ny, c->nz};
 	const uint8_t *oa = CORNER_OFF[E->a], *ob = CORNER_OFF[E->b];
-	float r[6];
-	float t = v[E->a] / (v[E->a] - v[E->b]);
+	mc33o_real r[6];
+	mc33o_real t = v[E->a] / (v[E->a] - v[E->b]);
 	for (int ax = 0; ax < 3; ax++) {
 		if (ax == E->axis) {
-			r[ax] = (float)cell[ax] + t;
+			r[ax] = (mc33o_real)cell[ax] + t;
 			r[3 + ax] = v[E->b] - v[E->a];
 			continue;
 		}
-		r[ax] = (float)(cell[ax] + oa[ax]);
+		r[ax] = (mc33o_real)(cell[ax] + oa[ax]);
 		if (oa[ax] == 1 && cell[ax] + 1 < lim[ax]) {
 			/* central differences around the edge, blended along it */
 			uint32_t pa[3] = {x + oa[0], y + oa[1], z + oa[2]}, pb[3] = {x + ob[0], y + ob[1], z + ob[2]};
@@ -269,16 +277,16 @@ static uint32_t emit_on_edge(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, 
 			memcpy(al, pa, sizeof pa); memcpy(ah, pa, sizeof pa);
 			memcpy(bl, pb, sizeof pb); memcpy(bh, pb, sizeof pb);
 			al[ax]--; ah[ax]++; bl[ax]--; bh[ax]++;
-			float da = sdiff(sample(c, al[0], al[1], al[2]), sample(c, ah[0], ah[1], ah[2]));
-			float db = sdiff(sample(c, bl[0], bl[1], bl[2]), sample(c, bh[0], bh[1], bh[2]));
+			mc33o_real da = sdiff(sample(c, al[0], al[1], al[2]), sample(c, ah[0], ah[1], ah[2]));
+			mc33o_real db = sdiff(sample(c, bl[0], bl[1], bl[2]), sample(c, bh[0], bh[1], bh[2]));
 			r[3 + ax] = 0.5f * (da * (1 - t) + db * t);
 		} else {
 			/* one-sided: difference of v across the cell at both end points */
 			uint8_t a_lo[3] = {oa[0], oa[1], oa[2]}, a_hi[3] = {oa[0], oa[1], oa[2]};
 			uint8_t b_lo[3] = {ob[0], ob[1], ob[2]}, b_hi[3] = {ob[0], ob[1], ob[2]};
 			a_lo[ax] = 0; a_hi[ax] = 1; b_lo[ax] = 0; b_hi[ax] = 1;
-			float da = v[CORNER_AT[a_hi[0]][a_hi[1]][a_hi[2]]] - v[CORNER_AT[a_lo[0]][a_lo[1]][a_lo[2]]];
-			float db = v[CORNER_AT[b_hi[0]][b_hi[1]][b_hi[2]]] - v[CORNER_AT[b_lo[0]][b_lo[1]][b_lo[2]]];
+			mc33o_real da = v[CORNER_AT[a_hi[0]][a_hi[1]][a_hi[2]]] - v[CORNER_AT[a_lo[0]][a_lo[1]][a_lo[2]]];
+			mc33o_real db = v[CORNER_AT[b_hi[0]][b_hi[1]][b_hi[2]]] - v[CORNER_AT[b_lo[0]][b_lo[1]][b_lo[2]]];
 			r[3 + ax] = da * (1 - t) + db * t;
 		}
 	}
@@ -286,8 +294,8 @@ static uint32_t emit_on_edge(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, 
 }
 
 /* cell-centre vertex (pattern nibble 0xC): MC:1225-1230 */
-static uint32_t emit_centre(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, const float *v) {
-	float r[6];
+static uint32_t emit_centre(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, const mc33o_real *v) {
+	mc33o_real r[6];
 	r[0] = x + 0.5f; r[1] = y + 0.5f; r[2] = z + 0.5f;
 	r[3] = v[4] + v[5] + v[6] + v[7] - v[0] - v[1] - v[2] - v[3];
 	r[4] = v[1] + v[2] + v[5] + v[6] - v[0] - v[3] - v[4] - v[7];
@@ -305,14 +313,14 @@ static const uint8_t FACE_DIAG_HI[6] = {0x84, 0x42, 0x12, 0x81, 0xA0, 0x0A}; /* 
 static const uint8_t FACE_DIAG_LO[6] = {0x48, 0x24, 0x21, 0x18, 0x50, 0x05};
 static const uint8_t FACE_KEYBIT[6] = {0x80, 0x02, 0x02, 0x80, 0x80, 0x02};  /* v0 for faces 0,3,4; v6 for 1,2,5 */
 
-static inline int face_less(int f, const float *v) {
+static inline int face_less(int f, const mc33o_real *v) {
 	const uint8_t *q = FACE_PROD[f];
 	return v[q[0]] * v[q[1]] < v[q[2]] * v[q[3]];
 }
 /* MC:371-386 */
-static inline unsigned face_test_one(int f, const float *v) { return face_less(f, v) ? FACE_DIAG_LO[f] : FACE_DIAG_HI[f]; }
+static inline unsigned face_test_one(int f, const mc33o_real *v) { return face_less(f, v) ? FACE_DIAG_LO[f] : FACE_DIAG_HI[f]; }
 /* MC:347-367 */
-static int face_tests(int *face, unsigned ind, const float *v) {
+static int face_tests(int *face, unsigned ind, const mc33o_real *v) {
 	int sum = 0;
 	for (int f = 0; f < 6; f++) {
 		int r = 0;
@@ -327,9 +335,9 @@ static int face_tests(int *face, unsigned ind, const float *v) {
 	return sum;
 }
 /* MC:431-462 */
-static int interior_test(int s, int flag13, const float *v) {
-	float a = v[4] - v[0], b = v[5] - v[1], cc = v[6] - v[2], d = v[7] - v[3];
-	float t = a * cc - b * d;
+static int interior_test(int s, int flag13, const mc33o_real *v) {
+	mc33o_real a = v[4] - v[0], b = v[5] - v[1], cc = v[6] - v[2], d = v[7] - v[3];
+	mc33o_real t = a * cc - b * d;
 	if (sign_of(t)) { if (s & 1) return 0; }
 	else if (!(s & 1) || t == 0) return 0;
 	t = 0.5f * (v[3] * b - v[2] * a + v[1] * d - v[0] * cc) / t;
@@ -343,7 +351,7 @@ static int interior_test(int s, int flag13, const float *v) {
 }
 
 /* MC:683-779: table word -> offset of the triangle pattern (the walk starts at offset+1, MC:781) */
-static unsigned pattern_offset(unsigned i, const float *v, unsigned *flip_m, unsigned *flip_n) {
+static unsigned pattern_offset(unsigned i, const mc33o_real *v, unsigned *flip_m, unsigned *flip_n) {
 	unsigned c, m, n;
 	if (i & 0x80) { c = mc33o_lut[i ^ 0xFF]; m = (c & 0x800) == 0; n = !m; }
 	else { c = mc33o_lut[i]; n = (c & 0x800) == 0; m = !n; }
@@ -424,7 +432,7 @@ static int need_ok(const oracle_ctx *c, unsigned need, uint32_t x, uint32_t y, u
 
 /* id of the vertex of cut edge e whose end point (corner `zc`) has v == 0; *keep_slot is set when
  * the id came from the slice below and the edge's own slot must not be rewritten (MC:836-838 etc.) */
-static uint32_t id_for_vertex_on_corner(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, const float *v,
+static uint32_t id_for_vertex_on_corner(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, const mc33o_real *v,
                                         uint32_t *p, const id_source *list, int n, int zc, int *keep_slot) {
 	for (int k = 0; k < n; k++) {
 		const id_source *s = &list[k];
@@ -435,7 +443,7 @@ static uint32_t id_for_vertex_on_corner(oracle_ctx *c, uint32_t x, uint32_t y, u
 		}
 		unsigned pass;
 		if (s->guard == GUARD_CORNER) pass = sign_of(v[s->gcorner]);
-		else pass = sign_of(c->iso - (float)sample(c, x + s->fx, y + s->fy, z + s->fz));
+		else pass = sign_of(c->iso - (mc33o_real)sample(c, x + s->fx, y + s->fy, z + s->fz));
 		if (!pass) continue;
 		uint32_t id = *id_slot(c, s->axis, x + s->sx, y + s->sy, z + s->sz);
 		if (s->also != 0xFF) p[s->also] = id;
@@ -455,7 +463,7 @@ static void add_triangle(oracle_ctx *c, uint32_t a, uint32_t b, uint32_t d) {
 	t[0] = a; t[1] = b; t[2] = d;
 }
 
-static void process_cell(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, unsigned i, const float *v) {
+static void process_cell(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, unsigned i, const mc33o_real *v) {
 	uint32_t p[13];
 	for (int k = 0; k < 13; k++) p[k] = NOID;
 	unsigned m, n;
@@ -497,23 +505,23 @@ static void process_cell(oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, unsi
 /* ------------------------------------------------------------------------------------------------
  * Sweep over all cells, x fastest (MC:1816-1889)
  * ---------------------------------------------------------------------------------------------- */
-static unsigned cell_values(const oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, float *v) {
+static unsigned cell_values(const oracle_ctx *c, uint32_t x, uint32_t y, uint32_t z, mc33o_real *v) {
 	unsigned i = 0;
 	for (int k = 0; k < 8; k++) {
-		v[k] = c->iso - (float)sample(c, x + CORNER_OFF[k][0], y + CORNER_OFF[k][1], z + CORNER_OFF[k][2]); /* MC:1840-1855 */
+		v[k] = c->iso - (mc33o_real)sample(c, x + CORNER_OFF[k][0], y + CORNER_OFF[k][1], z + CORNER_OFF[k][2]); /* MC:1840-1855 */
 		i |= sign_of(v[k]) << (7 - k);                                                              /* MC:1846-1859 */
 	}
 	return i;
 }
 
 int mc33o_calculate_isosurface(const mc33o_sample *data, uint32_t npx, uint32_t npy, uint32_t npz,
-                               const double r0[3], const double d[3], float iso, mc33o_surface *out) {
+                               const double r0[3], const double d[3], mc33o_real iso, mc33o_surface *out) {
 	return mc33o_calculate_isosurface_inclined(data, npx, npy, npz, r0, d, 0, 0, 0, iso, out);
 }
 
 int mc33o_calculate_isosurface_inclined(const mc33o_sample *data, uint32_t npx, uint32_t npy, uint32_t npz,
                                         const double r0[3], const double d[3], const double *grd_A, const double *grd_Ai,
-                                        int triangular, float iso, mc33o_surface *out) {
+                                        int triangular, mc33o_real iso, mc33o_surface *out) {
 	oracle_ctx c;
 	memset(&c, 0, sizeof c);
 	memset(out, 0, sizeof *out);
@@ -522,7 +530,7 @@ int mc33o_calculate_isosurface_inclined(const mc33o_sample *data, uint32_t npx, 
 	c.nx = npx - 1; c.ny = npy - 1; c.nz = npz - 1;
 	c.iso = iso;
 	/* store selection: MC:1772-1782 */
-	if (d[0] != d[1] || d[1] != d[2]) { c.store_mode = 2; c.ca = (float)(d[2] / d[0]); c.cb = (float)(d[2] / d[1]); }
+	if (d[0] != d[1] || d[1] != d[2]) { c.store_mode = 2; c.ca = (mc33o_real)(d[2] / d[0]); c.cb = (mc33o_real)(d[2] / d[1]); }
 	else c.store_mode = (d[0] == 1 && r0[0] == 0 && r0[1] == 0 && r0[2] == 0) ? 0 : 1;
 	if (grd_A && grd_Ai) { /* G->nonortho: MC:1763-1770 */
 		c.store_mode = 3;
@@ -533,9 +541,9 @@ int mc33o_calculate_isosurface_inclined(const mc33o_sample *data, uint32_t npx, 
 				c.Ai[j][i] = grd_Ai[3 * j + i] / d[j];
 			}
 	}
-	for (int k = 0; k < 3; k++) { c.O[k] = (float)r0[k]; c.D[k] = (float)d[k]; }
+	for (int k = 0; k < 3; k++) { c.O[k] = (mc33o_real)r0[k]; c.D[k] = (mc33o_real)d[k]; }
 	c.capV = c.capT = 4096;
-	c.V = (float *)malloc((size_t)c.capV * 12);
+	c.V = (mc33o_real *)malloc((size_t)c.capV * 3 * sizeof(mc33o_real));
 	c.N = (float *)malloc((size_t)c.capV * 12);
 	c.T = (uint32_t *)malloc((size_t)c.capT * 12);
 	size_t nX = (size_t)(c.ny + 1) * c.nx, nY = (size_t)c.ny * (c.nx + 1), nZ = (size_t)(c.ny + 1) * (c.nx + 1);
@@ -546,7 +554,7 @@ int mc33o_calculate_isosurface_inclined(const mc33o_sample *data, uint32_t npx, 
 	c.idZ = (uint32_t *)malloc(nZ * 4);
 	int ok = c.V && c.N && c.T && c.idX[0] && c.idX[1] && c.idY[0] && c.idY[1] && c.idZ;
 	if (ok) {
-		float v[8];
+		mc33o_real v[8];
 		for (uint32_t z = 0; z < c.nz; z++)
 			for (uint32_t y = 0; y < c.ny; y++)
 				for (uint32_t x = 0; x < c.nx; x++) {
@@ -567,7 +575,7 @@ void mc33o_free_surface(mc33o_surface *s) {
 	memset(s, 0, sizeof *s);
 }
 
-int mc33o_classify(const mc33o_sample *data, uint32_t npx, uint32_t npy, uint32_t npz, float iso,
+int mc33o_classify(const mc33o_sample *data, uint32_t npx, uint32_t npy, uint32_t npz, mc33o_real iso,
                    uint8_t *index_out, uint16_t *pattern_out) {
 	oracle_ctx c;
 	memset(&c, 0, sizeof c);
@@ -575,7 +583,7 @@ int mc33o_classify(const mc33o_sample *data, uint32_t npx, uint32_t npy, uint32_
 	c.F = data; c.px = npx; c.py = npy; c.pz = npz;
 	c.nx = npx - 1; c.ny = npy - 1; c.nz = npz - 1;
 	c.iso = iso;
-	float v[8];
+	mc33o_real v[8];
 	size_t q = 0;
 	for (uint32_t z = 0; z < c.nz; z++)
 		for (uint32_t y = 0; y < c.ny; y++)

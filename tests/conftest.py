@@ -14,7 +14,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-DTYPES = ("f32", "u16", "u8", "u32")  # one library per GRD_data_type, like the reference's compile-time variants
+DTYPES = ("f32", "u16", "u8", "u32", "f64")  # one library per GRD_data_type, like the reference's compile-time variants
 
 
 def _have(path):

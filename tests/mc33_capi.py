@@ -38,9 +38,8 @@ class USER(C.Union):
     _fields_ = [("p", C.c_void_p), ("ul", C.c_longlong), ("i", C.c_int * 2), ("df", C.c_double)]
 
 
-class SURFACE(C.Structure):
-    """surface (marching_cubes_33.h:133-152); 64 bytes."""
-    _fields_ = [
+def _surface_fields(real):
+    return [
         ("T", C.c_void_p),
         ("V", C.c_void_p),
         ("N", C.c_void_p),
@@ -49,14 +48,23 @@ class SURFACE(C.Structure):
         ("nT", C.c_uint),
         ("capt", C.c_uint),
         ("capv", C.c_uint),
-        ("iso", C.c_float),
+        ("iso", real),
         ("user", USER),
     ]
 
 
-class MC33(C.Structure):
-    """Public prefix of MC33 (marching_cubes_33.h:154-179); 304 bytes."""
-    _fields_ = [
+class SURFACE(C.Structure):
+    """surface (marching_cubes_33.h:133-152); 64 bytes."""
+    _fields_ = _surface_fields(C.c_float)
+
+
+class SURFACE64(C.Structure):
+    """surface of a double build (GRD_TYPE_SIZE 8: MC33_real = double, V is double[3]); 64 bytes as well."""
+    _fields_ = _surface_fields(C.c_double)
+
+
+def _mc33_fields(real):
+    return [
         ("T", C.c_void_p),
         ("V", C.c_void_p),
         ("N", C.c_void_p),
@@ -65,13 +73,13 @@ class MC33(C.Structure):
         ("nT", C.c_uint),
         ("capt", C.c_uint),
         ("capv", C.c_uint),
-        ("iso", C.c_float),
+        ("iso", real),
         ("memoryfault", C.c_int),
         ("F", C.c_void_p),
-        ("O", C.c_float * 3),
-        ("D", C.c_float * 3),
-        ("ca", C.c_float),
-        ("cb", C.c_float),
+        ("O", real * 3),
+        ("D", real * 3),
+        ("ca", real),
+        ("cb", real),
         ("nx", C.c_uint),
         ("ny", C.c_uint),
         ("nz", C.c_uint),
@@ -86,6 +94,19 @@ class MC33(C.Structure):
     ]
 
 
+class MC33(C.Structure):
+    """Public prefix of MC33 (marching_cubes_33.h:154-179); 304 bytes."""
+    _fields_ = _mc33_fields(C.c_float)
+
+
+class MC3364(C.Structure):
+    """MC33 of a double build; 344 bytes (measured against the reference header with -DGRD_TYPE_SIZE=8)."""
+    _fields_ = _mc33_fields(C.c_double)
+
+
+assert C.sizeof(SURFACE64) == 64 and SURFACE64.iso.offset == 48 and SURFACE64.user.offset == 56
+assert C.sizeof(MC3364) == 344 and MC3364.memoryfault.offset == 56 and MC3364.O.offset == 72 and MC3364.nx.offset == 136
+assert MC3364.store.offset == 152 and MC3364.Dx.offset == 304
 assert C.sizeof(GRD) == 416 and C.sizeof(SURFACE) == 64 and C.sizeof(MC33) == 304
 assert GRD.d.offset == 48 and GRD.nonortho.offset == 96 and GRD.internal_data.offset == 252
 assert SURFACE.iso.offset == 48 and SURFACE.user.offset == 56
@@ -116,7 +137,7 @@ class Surface:
         self.color, self.iso, self.capv, self.capt = color, iso, capv, capt
 
 
-NP_DTYPES = {"f32": np.float32, "u8": np.uint8, "u16": np.uint16, "u32": np.uint32}  # GRD_data_type per library
+NP_DTYPES = {"f32": np.float32, "u8": np.uint8, "u16": np.uint16, "u32": np.uint32, "f64": np.float64}  # GRD_data_type per library
 
 
 class MC33Lib:
@@ -126,6 +147,9 @@ class MC33Lib:
         self.path = path
         self.dtype = dtype
         self.np_dtype = NP_DTYPES[dtype]
+        # MC33_real: double only in the double build (marching_cubes_33.h:80-85)
+        self.real, self.np_real = (C.c_double, np.float64) if dtype == "f64" else (C.c_float, np.float32)
+        self.SURFACE, self.MC33 = (SURFACE64, MC3364) if dtype == "f64" else (SURFACE, MC33)
         if os.path.basename(path).startswith("libMC33_"):
             preload_torch()
         # RTLD_LOCAL (default): several of these libraries define the same symbols.
@@ -133,18 +157,18 @@ class MC33Lib:
         L = self.lib
         L.grid_from_data_pointer.restype = C.POINTER(GRD)
         L.grid_from_data_pointer.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_void_p]
-        L.create_MC33.restype = C.POINTER(MC33)
+        L.create_MC33.restype = C.POINTER(self.MC33)
         L.create_MC33.argtypes = [C.POINTER(GRD)]
-        L.calculate_isosurface.restype = C.POINTER(SURFACE)
-        L.calculate_isosurface.argtypes = [C.POINTER(MC33), C.c_float]
+        L.calculate_isosurface.restype = C.POINTER(self.SURFACE)
+        L.calculate_isosurface.argtypes = [C.POINTER(self.MC33), self.real]
         L.size_of_isosurface.restype = C.c_ulonglong
-        L.size_of_isosurface.argtypes = [C.POINTER(MC33), C.c_float, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+        L.size_of_isosurface.argtypes = [C.POINTER(self.MC33), self.real, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
         L.free_MC33.restype = None
-        L.free_MC33.argtypes = [C.POINTER(MC33)]
+        L.free_MC33.argtypes = [C.POINTER(self.MC33)]
         L.free_surface_memory.restype = None
-        L.free_surface_memory.argtypes = [C.POINTER(SURFACE)]
+        L.free_surface_memory.argtypes = [C.POINTER(self.SURFACE)]
         L.adjustvectorlenght_s.restype = None
-        L.adjustvectorlenght_s.argtypes = [C.POINTER(SURFACE)]
+        L.adjustvectorlenght_s.argtypes = [C.POINTER(self.SURFACE)]
         L.free_memory_grd.restype = None
         L.free_memory_grd.argtypes = [C.POINTER(GRD)]
 
@@ -180,9 +204,9 @@ class MC33Lib:
         def arr(ptr, n, dt):
             if n == 0 or not ptr:
                 return np.zeros((0, 3), dt)
-            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (n * 12,)).view(dt).reshape(n, 3).copy()
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (n * 3 * np.dtype(dt).itemsize,)).view(dt).reshape(n, 3).copy()
 
-        V = arr(s.V, nV, np.float32)
+        V = arr(s.V, nV, self.np_real)
         N = arr(s.N, nV, np.float32)
         T = arr(s.T, nT, np.uint32)
         if nV and s.color:
@@ -206,7 +230,7 @@ class MC33Lib:
             if not M:
                 raise MemoryError("create_MC33 returned NULL")
             try:
-                S = self.lib.calculate_isosurface(M, C.c_float(iso))
+                S = self.lib.calculate_isosurface(M, self.real(iso))
                 if not S:
                     raise MemoryError("calculate_isosurface returned NULL (memoryfault=%d)" % M.contents.memoryfault)
                 try:
@@ -224,7 +248,7 @@ class MC33Lib:
         try:
             M = self.lib.create_MC33(G)
             nV, nT = C.c_uint(0), C.c_uint(0)
-            sz = self.lib.size_of_isosurface(M, C.c_float(iso), C.byref(nV), C.byref(nT))
+            sz = self.lib.size_of_isosurface(M, self.real(iso), C.byref(nV), C.byref(nT))
             self.lib.free_MC33(M)
             return nV.value, nT.value, sz
         finally:

@@ -6,7 +6,8 @@ RTOL = 1e-5  # BASELINE.json north_star: "interpolated float positions/normals w
 
 
 def bits_equal(a, b):
-    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    u = np.uint64 if a.dtype == np.float64 else np.uint32
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(u), b.view(u))
 
 
 def max_rel(a, b, scale):

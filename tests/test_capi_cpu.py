@@ -19,7 +19,7 @@ def declared_functions(header):
     return sorted(names - {"defined", "sizeof", "int", "double", "float", "unsigned", "void", "char", "long", "short"})
 
 
-@pytest.mark.parametrize("dtype", ["f32", "u16", "u8", "u32"])
+@pytest.mark.parametrize("dtype", ["f32", "u16", "u8", "u32", "f64"])
 def test_library_exports_every_declared_symbol(dtype):
     path = product_path(dtype)
     assert os.path.exists(path), "build the HIP libraries first (python -m mc33_c_library_amd.build)"

@@ -232,3 +232,27 @@ def test_uchar_and_uint_grids(products, reflibs, seed):
     for data, iso in ((fx.noise_u32(24, seed), 2147483648.0), (fx.noise_u32(24, seed, 7), 3.0), (fx.noise_u32(24, seed, 7), 2.5),
                       (fx.cos_field_int(70, np.uint32, 0.6e9, 2.0e9), 2.2e9)):
         check(products, reflibs, "u32", data, iso, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0), label="u32")
+
+
+@pytest.mark.parametrize("seed", [1, 3])
+def test_double_grids(products, reflibs, seed):
+    """GRD_TYPE_SIZE 8 library (reference marching_cubes_33.h:80-82): double samples, double tests / interpolation /
+    vertex positions, float normals; all stores including the inclined one."""
+    P, R = products["f64"], reflibs["f64"]
+
+    def chk(data, iso, r0=None, d=None, label="", inclined=None):
+        got = P.isosurface(data, iso, r0, d, inclined=inclined)
+        ref = R.isosurface(data, iso, r0, d, inclined=inclined)
+        assert got.V.dtype == np.float64
+        ev, en, vb, nb = assert_surface_parity(got, ref, float(max(data.shape)), label)
+        print("%-28s nV %8d nT %8d  maxrel V %.2e N %.2e  bit-exact V %s N %s" % (label, got.nV, got.nT, ev, en, vb, nb))
+        assert vb and nb, label + ": double build is expected to be bit-identical"
+        return got
+
+    chk(fx.noise_f32(24, seed).astype(np.float64) * 1.000000123, 0.0, label="f64 noise")
+    chk(fx.noise_quant(24, seed).astype(np.float64), 1.0, label="f64 degenerate")
+    got = chk(fx.cos_field(130, dtype=np.float64)[0], 0.1, (-4.0, -4.0, -4.0), (8 / 129,) * 3, label="f64 cos130")
+    assert got.nV > 50000
+    chk(fx.cos_field(40, dtype=np.float64)[0], -0.5, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0), label="f64 spnB")
+    chk(fx.cos_field(40, dtype=np.float64)[0], 0.1, (0.0, 0.0, 0.0), (0.2, 0.3, 0.45), label="f64 inclined", inclined=fx.general_matrices())
+    chk(fx.noise_f32(0, seed, shape=(3, 5, 300)).astype(np.float64), 0.0, label="f64 ragged")

@@ -13,7 +13,7 @@ from mc33_capi import GRD, MC33Lib, product_path
 
 @pytest.fixture(scope="module")
 def prods():
-    return {"f32": MC33Lib(product_path("f32"), "f32"), "u16": MC33Lib(product_path("u16"), "u16")}
+    return {d: MC33Lib(product_path(d), d) for d in ("f32", "u16", "f64")}
 
 
 def declare(lib):
@@ -118,14 +118,14 @@ def write_grd_binary(path, dtype, N, L, r0, d, data, inclined=None, title=b"bina
         f.write(np.ascontiguousarray(data, dtype).tobytes())
 
 
-@pytest.mark.parametrize("dtype", ["f32", "u16"])
+@pytest.mark.parametrize("dtype", ["f32", "u16", "f64"])
 @pytest.mark.parametrize("inclined", [False, True])
 def test_read_grd_binary(prods, reflibs, tmp_path, dtype, inclined):
     import fixtures as fx
     P, R = declare(prods[dtype]), declare(reflibs[dtype])
     N = (6, 3, 4)
     rng = np.random.RandomState(2)
-    data = rng.normal(size=(5, 4, 7)).astype(np.float32) if dtype == "f32" else rng.randint(0, 65535, (5, 4, 7)).astype(np.uint16)
+    data = rng.normal(size=(5, 4, 7)).astype(prods[dtype].np_dtype) if dtype != "u16" else rng.randint(0, 65535, (5, 4, 7)).astype(np.uint16)
     path = str(tmp_path / "b.grb")
     write_grd_binary(path, prods[dtype].np_dtype, N, (3.0, 1.5, 2.0), (0.0, 0.0, 0.0) if inclined else (1.0, -2.0, 0.5),
                      (0.5, 0.5, 0.5), data, fx.general_matrices() if inclined else None)
@@ -158,7 +158,7 @@ def test_read_scanfiles(prods, reflibs, tmp_path, dtype, nfiles, order):
     assert not P.read_scanfiles(str(tmp_path / "nothing.1").encode(), res, 0)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "u16"])
+@pytest.mark.parametrize("dtype", ["f32", "u16", "f64"])
 @pytest.mark.parametrize("byte,isfloat", [(1, 0), (2, 0), (-2, 0), (4, 0), (-4, 0), (4, 1), (-4, 1), (8, 1), (-8, 1)])
 def test_read_raw_file(prods, reflibs, tmp_path, dtype, byte, isfloat):
     P, R = declare(prods[dtype]), declare(reflibs[dtype])
@@ -174,9 +174,10 @@ def test_read_raw_file(prods, reflibs, tmp_path, dtype, byte, isfloat):
     open(path, "wb").write((raw.byteswap() if byte < 0 else raw).tobytes())
     N = (C.c_uint * 3)(*n)
     Gp, Gr = P.read_raw_file(path.encode(), N, byte, isfloat), R.read_raw_file(path.encode(), N, byte, isfloat)
-    if (dtype, byte, isfloat) == ("f32", -4, 1):
-        # the reference's float build has no code for byte-swapped 4-byte floats (MC33_util_grd.c:488-498 is
-        # compiled for integer / double grids only) and hands back unset rows; the product converts them
+    if (dtype, byte, isfloat) in (("f32", -4, 1), ("f64", -8, 1)):
+        # the reference has no code for byte-swapped samples of the library's own floating type (MC33_util_grd.c:
+        # 474-498: the conversion loops are compiled for the OTHER widths only) and hands back unset rows; the
+        # product converts them
         got = samples(prods[dtype], Gp)
     else:
         got = same_grid(prods[dtype], Gp, reflibs[dtype], Gr)

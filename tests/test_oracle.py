@@ -103,3 +103,20 @@ def test_oracle_bit_exact_vs_reference_uchar_and_uint(oracles, reflibs, seed):
         ref = reflibs["u32"].isosurface(data, iso, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0))
         assert ref.nV > 100
         assert _same(oracles["u32"].isosurface(data, iso, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0)), ref)
+
+
+@pytest.mark.parametrize("seed", [1, 3])
+def test_oracle_bit_exact_vs_reference_double(oracles, reflibs, seed):
+    """GRD_TYPE_SIZE 8 (reference marching_cubes_33.h:80-82): double samples, double arithmetic in the tests and the
+    interpolation, double vertex positions, float normals."""
+    O, R = oracles["f64"], reflibs["f64"]
+    for data, iso, r0, d in ((fx.noise_f32(24, seed).astype(np.float64) * 1.000000123, 0.0, None, None),
+                             (fx.noise_quant(24, seed).astype(np.float64), 1.0, None, None),
+                             (fx.cos_field(40, dtype=np.float64)[0], 0.1, (-4.0, -4.0, -4.0), (0.2, 0.2, 0.2)),
+                             (fx.cos_field(30, dtype=np.float64)[0], -0.5, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0))):
+        ref = R.isosurface(data, iso, r0, d)
+        assert ref.V.dtype == np.float64 and ref.nV > 500
+        assert _same(O.isosurface(data, iso, r0, d), ref)
+    mats = fx.general_matrices()
+    data = fx.cos_field(24, dtype=np.float64)[0]
+    assert _same(O.isosurface(data, 0.1, (0, 0, 0), (0.2, 0.3, 0.45), inclined=mats), R.isosurface(data, 0.1, (0, 0, 0), (0.2, 0.3, 0.45), inclined=mats))

@@ -130,3 +130,45 @@ def test_read_bin_sets_capacities(prod, tmp_path):
     assert P.write_txt_s(Sp, str(tmp_path / "c.txt").encode()) == 0
     prod.lib.free_surface_memory(Sp)
     del keep
+
+
+def test_double_build_files(reflibs, tmp_path):
+    """libMC33_f64 (MC33_real = double): the binary container becomes ".sud" with double iso / V, the text formats
+    print the doubles; a ".sup" file of a float build is read and widened (MC:128-136, 178-204)."""
+    from mc33_capi import SURFACE64
+    P64, R64 = MC33Lib(product_path("f64"), "f64"), reflibs["f64"]
+    Pl, Rl = declare(P64), declare(R64)
+    for L in (Pl, Rl):
+        for n in ("write_bin_s", "write_txt_s", "write_obj_s"):
+            getattr(L, n).argtypes = [C.POINTER(SURFACE64), C.c_char_p]
+        L.write_ply_s.argtypes = [C.POINTER(SURFACE64), C.c_char_p, C.c_char_p, C.c_char_p]
+        L.read_bin_s.restype = C.POINTER(SURFACE64)
+    rng = np.random.RandomState(21)
+    nV, nT = 57, 40
+    V = rng.uniform(-50, 50, (nV, 3)) * 1.0000001234567
+    N = rng.normal(size=(nV, 3)).astype(np.float32)
+    T = rng.randint(0, nV, (nT, 3)).astype(np.uint32)
+    col = rng.randint(-2**31, 2**31 - 1, nV).astype(np.int32)
+    S = SURFACE64()
+    S.T, S.V, S.N, S.color = T.ctypes.data, V.ctypes.data, N.ctypes.data, col.ctypes.data
+    S.nV, S.nT, S.capv, S.capt, S.iso = nV, nT, nV, nT, 0.1234567890123
+    for fn, ext in (("write_bin_s", "sud"), ("write_txt_s", "txt"), ("write_obj_s", "obj")):
+        a, b = str(tmp_path / ("p." + ext)).encode(), str(tmp_path / ("r." + ext)).encode()
+        assert getattr(Pl, fn)(C.byref(S), a) == getattr(Rl, fn)(C.byref(S), b) == 0
+        assert open(a, "rb").read() == open(b, "rb").read(), fn
+    a, b = str(tmp_path / "p.ply").encode(), str(tmp_path / "r.ply").encode()
+    assert Pl.write_ply_s(C.byref(S), a, b"x", None) == Rl.write_ply_s(C.byref(S), b, b"x", None) == 0
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert open(str(tmp_path / "p.sud"), "rb").read()[:4] == struct.pack("<i", 0x6575732e)
+    # a float-build file read by the double build
+    Sf, keep = make_surface(33, 12, seed=5, iso=0.75)
+    f32 = declare(reflibs["f32"])
+    sup = str(tmp_path / "f.sup").encode()
+    assert f32.write_bin_s(C.byref(Sf), sup) == 0
+    for L, lib in ((Pl, P64), (Rl, R64)):
+        Sp = L.read_bin_s(sup)
+        assert Sp
+        s = lib.copy_surface(Sp)
+        assert (s.nV, s.nT, s.iso) == (33, 12, 0.75) and s.V.dtype == np.float64
+        assert np.array_equal(s.V, keep[1].astype(np.float64)) and np.array_equal(s.T, keep[0])
+        lib.lib.free_surface_memory(Sp)
