@@ -12,8 +12,9 @@
  *   -DINTEGER_GRD -DGRD_TYPE_SIZE=2 GRD_data_type = unsigned short, MC33_real = float
  *   -DINTEGER_GRD -DGRD_TYPE_SIZE=4 GRD_data_type = unsigned int,   MC33_real = float
  *   -DGRD_TYPE_SIZE=8               GRD_data_type = double,         MC33_real = double (vertices, isovalue)
- * One library per variant, like the reference's one-type-per-compile model.  GRD_ORTHOGONAL is not built
- * (out of scope).
+ *   -DGRD_ORTHOGONAL (with any of the above): _GRD and MC33 without the inclined-grid members (reference
+ *   header :116-120, :173-175); link the libMC33_<type>_ortho.so flavour.
+ * One library per variant, like the reference's one-type-per-compile model.
  */
 #ifndef marching_cubes_33_h
 #define marching_cubes_33_h
@@ -42,9 +43,6 @@ typedef float MC33_real;
 #  define GRD_TYPE_SIZE 4
 #endif
 
-#ifdef GRD_ORTHOGONAL
-#  error "GRD_ORTHOGONAL changes the struct layout and is not provided by this build"
-#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -57,9 +55,11 @@ typedef struct {
 	unsigned int N[3];       /* intervals in x, y, z                                               */
 	double r0[3], d[3];      /* origin, spacing                                                    */
 	float L[3];              /* extent (unused by the isosurface path)                             */
+#ifndef GRD_ORTHOGONAL
 	float Ang[3];
 	int nonortho;            /* inclined grid: positions / normals go through _A / A_ (MC33_spnC)  */
 	double _A[3][3], A_[3][3]; /* fractional -> cartesian cell matrix (unit edges) and its inverse  */
+#endif
 	int periodic;
 	int internal_data;       /* 1: rows were allocated by alloc_F and are freed by free_memory_grd */
 	char title[160];
@@ -102,7 +102,9 @@ typedef struct {
 	MC33_real O[3], D[3], ca, cb;
 	unsigned int nx, ny, nz;
 	unsigned int (*store)(void *, MC33_real *);
+#ifndef GRD_ORTHOGONAL
 	double _A[3][3], A_[3][3];
+#endif
 	unsigned int **Dx, **Dy, **Ux, **Uy, **Lz;
 } MC33;
 

@@ -33,8 +33,9 @@ VARIANTS = {
 }
 
 
-def lib_path(dtype):
-    return os.path.join(PKG, "libMC33_%s.so" % dtype)
+def lib_path(dtype, ortho=False):
+    """ortho: the GRD_ORTHOGONAL flavour of the C API (structs without the inclined-grid members)."""
+    return os.path.join(PKG, "libMC33_%s%s.so" % (dtype, "_ortho" if ortho else ""))
 
 
 def _newer(target, deps):
@@ -75,6 +76,18 @@ def build(dtype, force=False, verbose_resources=False):
     out = lib_path(dtype)
     if relink or _newer(out, objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    # GRD_ORTHOGONAL flavour: same kernels, the host C compiled against the smaller structs
+    oobjs, relink = [hip_obj], force
+    for name in C_SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(BUILD, "%s_%s_ortho.o" % (os.path.splitext(name)[0], dtype))
+        if force or _newer(obj, [src] + incs):
+            _run([GCC] + C_FLAGS + var["c"] + ["-DGRD_ORTHOGONAL", "-c", src, "-o", obj])
+            relink = True
+        oobjs.append(obj)
+    oout = lib_path(dtype, ortho=True)
+    if relink or _newer(oout, oobjs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + oobjs + ["-o", oout])
     return out
 
 

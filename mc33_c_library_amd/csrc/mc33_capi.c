@@ -19,16 +19,26 @@
 #include "../../include/mc33_hip.h"
 
 /* layout contract with programs compiled against the reference header */
+#ifdef GRD_ORTHOGONAL /* measured against the reference header compiled with -DGRD_ORTHOGONAL */
+_Static_assert(sizeof(_GRD) == 256 && offsetof(_GRD, d) == 48 && offsetof(_GRD, periodic) == 84 &&
+               offsetof(_GRD, internal_data) == 88 && offsetof(_GRD, title) == 92, "_GRD layout differs from the reference (GRD_ORTHOGONAL)");
+#else
 _Static_assert(sizeof(_GRD) == 416 && offsetof(_GRD, d) == 48 && offsetof(_GRD, nonortho) == 96 &&
                offsetof(_GRD, internal_data) == 252, "_GRD layout differs from the reference");
+#endif
 _Static_assert(sizeof(surface) == 64 && offsetof(surface, iso) == 48 && offsetof(surface, user) == 56,
                "surface layout differs from the reference");
-#if GRD_TYPE_SIZE == 8 /* measured against the reference header compiled with -DGRD_TYPE_SIZE=8 */
-_Static_assert(sizeof(MC33) == 344 && offsetof(MC33, memoryfault) == 56 && offsetof(MC33, O) == 72 && offsetof(MC33, nx) == 136 &&
-               offsetof(MC33, store) == 152 && offsetof(MC33, Dx) == 304, "MC33 layout differs from the reference (double build)");
+#ifdef GRD_ORTHOGONAL
+#define MC33_MATS 0 /* bytes of _A, A_ missing from MC33 */
 #else
-_Static_assert(sizeof(MC33) == 304 && offsetof(MC33, memoryfault) == 52 && offsetof(MC33, nx) == 96 &&
-               offsetof(MC33, Dx) == 264, "MC33 layout differs from the reference");
+#define MC33_MATS 144
+#endif
+#if GRD_TYPE_SIZE == 8 /* measured against the reference header compiled with -DGRD_TYPE_SIZE=8 */
+_Static_assert(sizeof(MC33) == 200 + MC33_MATS && offsetof(MC33, memoryfault) == 56 && offsetof(MC33, O) == 72 && offsetof(MC33, nx) == 136 &&
+               offsetof(MC33, store) == 152 && offsetof(MC33, Dx) == 160 + MC33_MATS, "MC33 layout differs from the reference (double build)");
+#else
+_Static_assert(sizeof(MC33) == 160 + MC33_MATS && offsetof(MC33, memoryfault) == 52 && offsetof(MC33, nx) == 96 &&
+               offsetof(MC33, store) == 112 && offsetof(MC33, Dx) == 120 + MC33_MATS, "MC33 layout differs from the reference");
 #endif
 
 #ifndef DEFAULT_SURFACE_COLOR
@@ -69,6 +79,7 @@ MC33 *create_MC33(_GRD *G) {
 		M->O[j] = (MC33_real)G->r0[j];
 		M->D[j] = (MC33_real)G->d[j];
 	}
+#ifndef GRD_ORTHOGONAL
 	if (G->nonortho) { /* MC:1763-1770: the matrices MC33_spnC multiplies with */
 		for (int j = 0; j != 3; j++)
 			for (int i = 0; i != 3; i++) {
@@ -78,7 +89,9 @@ MC33 *create_MC33(_GRD *G) {
 		p->inclined = 1;
 		memcpy(p->grd_A, G->_A, sizeof p->grd_A);
 		memcpy(p->grd_Ai, G->A_, sizeof p->grd_Ai);
-	} else if (G->d[0] != G->d[1] || G->d[1] != G->d[2]) { /* MC:1772-1775 */
+	} else
+#endif
+	if (G->d[0] != G->d[1] || G->d[1] != G->d[2]) { /* MC:1772-1775 */
 		M->ca = (MC33_real)(G->d[2] / G->d[0]);
 		M->cb = (MC33_real)(G->d[2] / G->d[1]);
 	}
@@ -278,10 +291,19 @@ void adjustvectorlenght_s(surface *S) { /* MC:94-127: shrink the four arrays to 
 }
 
 /* ---- grid container helpers (UTIL:125-169, 585-686), needed by callers that build grids ---------- */
-static void ident3(double (*A)[3]) {
-	for (int i = 0; i != 3; i++)
-		for (int j = 0; j != 3; j++)
-			A[i][j] = i == j ? 1.0 : 0.0;
+/* cell angles 90 degrees, identity cell matrices (the members do not exist in GRD_ORTHOGONAL builds) */
+static void set_orthogonal(_GRD *Z) {
+#ifndef GRD_ORTHOGONAL
+	Z->nonortho = 0;
+	memset(Z->_A, 0, sizeof Z->_A);
+	memset(Z->A_, 0, sizeof Z->A_);
+	for (int i = 0; i != 3; i++) {
+		Z->Ang[i] = 90.0f;
+		Z->_A[i][i] = Z->A_[i][i] = 1.0;
+	}
+#else
+	(void)Z;
+#endif
 }
 
 void free_memory_grd(_GRD *Z) { /* UTIL:125-145 */
@@ -335,10 +357,8 @@ _GRD *grid_from_data_pointer(unsigned int Nx, unsigned int Ny, unsigned int Nz, 
 		Z->L[i] = (float)Z->N[i];
 		Z->d[i] = 1.0;
 		Z->r0[i] = 0.0;
-		Z->Ang[i] = 90.0f;
 	}
-	ident3(Z->_A);
-	ident3(Z->A_);
+	set_orthogonal(Z);
 	return Z;
 }
 
@@ -372,9 +392,7 @@ _GRD *generate_grid_from_fn(double xi, double yi, double zi, double xf, double y
 	}
 	for (int i = 0; i != 3; i++) {
 		Z->L[i] = (float)(Z->N[i] * Z->d[i]);
-		Z->Ang[i] = 90.0f;
 	}
-	ident3(Z->_A);
-	ident3(Z->A_);
+	set_orthogonal(Z);
 	return Z;
 }

@@ -23,10 +23,12 @@
 
 #include "../../include/marching_cubes_33.h"
 
+#ifndef GRD_ORTHOGONAL
 static void identity3(double (*A)[3]) {
 	memset(A, 0, 9 * sizeof(double));
 	A[0][0] = A[1][1] = A[2][2] = 1.0;
 }
+#endif
 
 /* a _GRD with the defaults every reader starts from: unit spacing, origin 0, orthogonal */
 static _GRD *blank_grid(void) {
@@ -35,8 +37,10 @@ static _GRD *blank_grid(void) {
 		return 0;
 	Z->internal_data = 1;
 	Z->d[0] = Z->d[1] = Z->d[2] = 1.0;
+#ifndef GRD_ORTHOGONAL
 	identity3(Z->_A);
 	identity3(Z->A_);
+#endif
 	return Z;
 }
 
@@ -76,9 +80,11 @@ _GRD *read_grd(const char *filename) { /* UTIL:181-263 */
 	for (int i = 0; i != 3; i++) {
 		Z->d[i] = Z->L[i] / Z->N[i];
 		Z->r0[i] = lo[i] * Z->d[i];
-		Z->Ang[i] = ang[i];
 	}
 	Z->periodic = (lo[0] == 0) | (lo[1] == 0) << 1 | (lo[2] == 0) << 2;
+#ifndef GRD_ORTHOGONAL
+	for (int i = 0; i != 3; i++)
+		Z->Ang[i] = ang[i];
 	if (ang[0] != 90 || ang[1] != 90 || ang[2] != 90) { /* cell matrix of a triclinic cell with unit edges (UTIL:218-236) */
 		const double rad = 3.14159265358979323846 / 180.0;
 		const double ca = cos(ang[0] * rad), cb = cos(ang[1] * rad), gam = ang[2] * rad, sg = sin(gam), cg = cos(gam);
@@ -94,6 +100,7 @@ _GRD *read_grd(const char *filename) { /* UTIL:181-263 */
 		Z->A_[1][2] = -p * isg * iq;
 		Z->A_[2][2] = sg * iq;
 	}
+#endif /* GRD_ORTHOGONAL builds read the samples of an inclined cell as if it were orthogonal, like the reference */
 	if (alloc_F(Z)) {
 		fclose(f);
 		free_memory_grd(Z);
@@ -146,6 +153,7 @@ _GRD *read_grd_binary(const char *filename) { /* UTIL:267-317 */
 	got += fread(Z->r0, sizeof Z->r0, 1, f);
 	got += fread(Z->d, sizeof Z->d, 1, f);
 	got += fread(&inclined, sizeof inclined, 1, f);
+#ifndef GRD_ORTHOGONAL
 	Z->nonortho = inclined;
 	if (inclined) {
 		got += fread(Z->Ang, sizeof Z->Ang, 1, f);
@@ -153,6 +161,11 @@ _GRD *read_grd_binary(const char *filename) { /* UTIL:267-317 */
 		got += fread(Z->A_, sizeof Z->A_, 1, f);
 		mult_Abf = _multA_bf; /* the matrices of a file need not be triangular (UTIL:297) */
 	}
+#else
+	if (inclined) { /* skip Ang, _A, A_ (UTIL:304-307) */
+		got += fseek(f, 3 * (long)sizeof(float) + 18 * (long)sizeof(double), SEEK_CUR) == 0 ? 3 : 0;
+	}
+#endif
 	Z->periodic = Z->r0[0] == 0 && Z->r0[1] == 0 && Z->r0[2] == 0;
 	if (got != (inclined ? 9u : 6u) || alloc_F(Z)) {
 		fclose(f);

@@ -88,3 +88,11 @@ def test_surface_helpers_without_gpu():
     lib.lib.free_MC33(None)
     lib.lib.adjustvectorlenght_s(None)
     assert not lib.lib.create_MC33(None)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u16", "u8", "u32", "f64"])
+def test_orthogonal_flavour_exports_the_same_api(dtype):
+    lib = C.CDLL(product_path(dtype, ortho=True))
+    from mc33_c_library_amd import HIP_API, REFERENCE_API
+    for n in HIP_API + REFERENCE_API:
+        assert hasattr(lib, n), n

@@ -256,3 +256,18 @@ def test_double_grids(products, reflibs, seed):
     chk(fx.cos_field(40, dtype=np.float64)[0], -0.5, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0), label="f64 spnB")
     chk(fx.cos_field(40, dtype=np.float64)[0], 0.1, (0.0, 0.0, 0.0), (0.2, 0.3, 0.45), label="f64 inclined", inclined=fx.general_matrices())
     chk(fx.noise_f32(0, seed, shape=(3, 5, 300)).astype(np.float64), 0.0, label="f64 ragged")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u16"])
+def test_grd_orthogonal_flavour(reflibs, dtype):
+    """Callers compiled with -DGRD_ORTHOGONAL see smaller _GRD / MC33 structs (reference marching_cubes_33.h:116-120,
+    :173-175): the libMC33_<type>_ortho.so flavour against the reference built the same way."""
+    from mc33_capi import MC33Lib, product_path, ref_path
+    P, R = MC33Lib(product_path(dtype, ortho=True), dtype, ortho=True), MC33Lib(ref_path(dtype, ortho=True), dtype, ortho=True)
+    cases = ([(fx.cos_field(70)[0], 0.0, (-4.0, -4.0, -4.0), (8 / 69,) * 3), (fx.noise_quant(24, 2), 1.0, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0))]
+             if dtype == "f32" else [(fx.noise_u16(24, 3, 7), 3.0, None, None), (fx.cos_field_u16(60, 50, 40), 25268.5, None, (0.5, 0.5, 0.5))])
+    for data, iso, r0, d in cases:
+        got, ref = P.isosurface(data, iso, r0, d), R.isosurface(data, iso, r0, d)
+        ev, en, vb, nb = assert_surface_parity(got, ref, float(max(data.shape)), "ortho " + dtype)
+        assert vb and nb and got.nV > 1000
+        assert (got.nV, got.nT) == (reflibs[dtype].isosurface(data, iso, r0, d).nV, ref.nT)  # and the same surface as the full-layout build
