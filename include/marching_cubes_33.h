@@ -125,6 +125,12 @@ void free_MC33(MC33 *M);
 void free_surface_memory(surface *S);
 void adjustvectorlenght_s(surface *S);
 
+/* --- extension (not in the reference): several isovalues of the grid that is resident in HBM ------- */
+/* out[k] = what calculate_isosurface(M, iso[k]) would return (NULL where it failed; caller frees each with
+ * free_surface_memory).  The device-to-host copy of surface k runs beside the extraction of surface k+1.
+ * Returns the number of surfaces produced. */
+unsigned int calculate_isosurfaces(MC33 *M, const MC33_real *iso, unsigned int n, surface **out);
+
 /* --- surface files (reference header :193-222), host C: csrc/mc33_surface_io.c -------------------- */
 int write_bin_s(surface *S, const char *filename);   /* ".sup" binary container; 0 on success, -1 on failure */
 surface *read_bin_s(const char *filename);           /* NULL on failure; also reads ".sud" (double) files      */

@@ -106,6 +106,10 @@ int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t);  /* waits for a pend
 
 /* Device-to-host copy helper for callers without a HIP runtime of their own (blocking). */
 int mc33hip_download(mc33hip_ctx *c, void *host_dst, const void *device_src, size_t bytes);
+/* The same on a stream of the context's own that neither waits for nor delays the work queued by the other entry
+ * points: the download of one result can run while the next extraction is computed (calculate_isosurfaces does
+ * that from a helper thread).  The source must not be written meanwhile.  Blocking; callable from any thread. */
+int mc33hip_download_concurrent(mc33hip_ctx *c, void *host_dst, const void *device_src, size_t bytes);
 /* Plain device allocations on the context's device (for language bindings). */
 int mc33hip_device_alloc(mc33hip_ctx *c, void **dptr, size_t bytes);
 int mc33hip_device_free(mc33hip_ctx *c, void *dptr);

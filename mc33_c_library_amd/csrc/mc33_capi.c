@@ -11,6 +11,7 @@
  * Deliberate difference: the grid is copied to HBM in create_MC33 and stays resident.  A caller that
  * rewrites G->F between calls sets MC33_HIP_REUPLOAD=1 (re-upload before every extraction).
  */
+#include <pthread.h>
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
@@ -52,8 +53,10 @@ typedef struct {
 	unsigned long long magic;
 	mc33hip_ctx *ctx;
 	_GRD *grid;          /* for MC33_HIP_REUPLOAD */
-	void *dV, *dN, *dT;  /* device staging of the last result, grown on demand */
-	unsigned long long capV, capT;
+	struct staging {     /* device staging of a result, grown on demand; two sets so that calculate_isosurfaces can */
+		void *dV, *dN, *dT; /* download one surface while the next is being extracted                           */
+		unsigned long long capV, capT;
+	} set[2];
 	int reupload;
 	int inclined;        /* G->nonortho at create time: the MC33_spnC store */
 	double grd_A[9], grd_Ai[9];
@@ -118,9 +121,11 @@ void free_MC33(MC33 *M) {
 	if (!p)
 		return;
 	if (p->ctx) {
-		if (p->dV) mc33hip_device_free(p->ctx, p->dV);
-		if (p->dN) mc33hip_device_free(p->ctx, p->dN);
-		if (p->dT) mc33hip_device_free(p->ctx, p->dT);
+		for (int k = 0; k != 2; k++) {
+			if (p->set[k].dV) mc33hip_device_free(p->ctx, p->set[k].dV);
+			if (p->set[k].dN) mc33hip_device_free(p->ctx, p->set[k].dN);
+			if (p->set[k].dT) mc33hip_device_free(p->ctx, p->set[k].dT);
+		}
 		mc33hip_destroy(p->ctx);
 	}
 	p->magic = 0;
@@ -181,70 +186,63 @@ unsigned long long size_of_isosurface(MC33 *M, MC33_real iso, unsigned int *nV, 
 	return cnt.nV * (6 * sizeof(MC33_real) + sizeof(int)) + cnt.nT * (3 * sizeof(int)) + sizeof(surface);
 }
 
-static int ensure_staging(mc33_private *p, unsigned long long nV, unsigned long long nT) {
-	if (p->capV < nV) {
-		if (p->dV) mc33hip_device_free(p->ctx, p->dV);
-		if (p->dN) mc33hip_device_free(p->ctx, p->dN);
-		p->dV = p->dN = 0; p->capV = 0;
+static int ensure_staging(mc33_private *p, struct staging *g, unsigned long long nV, unsigned long long nT) {
+	if (g->capV < nV) {
+		if (g->dV) mc33hip_device_free(p->ctx, g->dV);
+		if (g->dN) mc33hip_device_free(p->ctx, g->dN);
+		g->dV = g->dN = 0; g->capV = 0;
 		unsigned long long cap = nV + nV / 8 + 1024;
-		if (mc33hip_device_alloc(p->ctx, &p->dV, cap * 3 * sizeof(MC33_real)) != MC33HIP_OK) return -1;
-		if (mc33hip_device_alloc(p->ctx, &p->dN, cap * 12) != MC33HIP_OK) return -1;
-		p->capV = cap;
+		if (mc33hip_device_alloc(p->ctx, &g->dV, cap * 3 * sizeof(MC33_real)) != MC33HIP_OK) return -1;
+		if (mc33hip_device_alloc(p->ctx, &g->dN, cap * 12) != MC33HIP_OK) return -1;
+		g->capV = cap;
 	}
-	if (p->capT < nT) {
-		if (p->dT) mc33hip_device_free(p->ctx, p->dT);
-		p->dT = 0; p->capT = 0;
+	if (g->capT < nT) {
+		if (g->dT) mc33hip_device_free(p->ctx, g->dT);
+		g->dT = 0; g->capT = 0;
 		unsigned long long cap = nT + nT / 8 + 1024;
-		if (mc33hip_device_alloc(p->ctx, &p->dT, cap * 12) != MC33HIP_OK) return -1;
-		p->capT = cap;
+		if (mc33hip_device_alloc(p->ctx, &g->dT, cap * 12) != MC33HIP_OK) return -1;
+		g->capT = cap;
 	}
 	return 0;
 }
 
-surface *calculate_isosurface(MC33 *M, MC33_real iso) {
-	mc33_private *p = priv(M);
-	if (!p)
-		return 0;
+/* GPU part of calculate_isosurface: the surface of `iso` into staging set g (device memory), its sizes into *cnt */
+static int extract_to_staging(mc33_private *p, struct staging *g, MC33_real iso, mc33hip_counts *cnt) {
+	mc33hip_range r;
+	r.z_begin = 0; r.z_end = p->pub.nz; r.ghost_below = 0; r.id_base = 0;
+	memset(cnt, 0, sizeof *cnt);
+	int rc = refresh_grid(p);
+	if (rc != MC33HIP_OK)
+		return rc;
+	/* one pass with the staging buffers of an earlier call; if they are too small the counts come back
+	 * anyway, the buffers grow and only the emit pass is repeated */
+	rc = mc33hip_extract(p->ctx, iso, &r, g->dV, g->dN, g->dT, g->capV, g->capT, cnt);
+	if (rc == MC33HIP_ECAPACITY)
+		rc = ensure_staging(p, g, cnt->nV, cnt->nT) ? MC33HIP_ENOMEM : mc33hip_emit(p->ctx, g->dV, g->dN, g->dT, g->capV, g->capT);
+	return rc;
+}
+
+/* host part: a caller-owned `surface` (five malloc blocks, MC:84-92) filled from staging set g.
+ * concurrent: copy on the side stream, beside whatever the context is computing */
+static surface *surface_from_staging(mc33_private *p, const struct staging *g, const mc33hip_counts *cnt, MC33_real iso, int concurrent) {
 	surface *S = (surface *)malloc(sizeof(surface));
 	if (!S)
 		return 0;
-	M->nT = M->nV = 0;
-	M->memoryfault = 0;
-	M->iso = iso;
-	mc33hip_range r;
-	r.z_begin = 0; r.z_end = M->nz; r.ghost_below = 0; r.id_base = 0;
-	mc33hip_counts cnt;
-	memset(&cnt, 0, sizeof cnt);
-	int rc = refresh_grid(p);
-	if (rc == MC33HIP_OK) {
-		/* one pass with the staging buffers of the previous call; if they are too small the counts
-		 * come back anyway, the buffers grow and only the emit pass is repeated */
-		rc = mc33hip_extract(p->ctx, iso, &r, p->dV, p->dN, p->dT, p->capV, p->capT, &cnt);
-		if (rc == MC33HIP_ECAPACITY) {
-			rc = ensure_staging(p, cnt.nV, cnt.nT) ? MC33HIP_ENOMEM
-			                                       : mc33hip_emit(p->ctx, p->dV, p->dN, p->dT, p->capV, p->capT);
-		}
-	}
-	if (rc != MC33HIP_OK) {
-		M->memoryfault = 1;
-		free(S);
-		return 0;
-	}
-	if (!cnt.nV) { /* MC:1880-1883 */
+	if (!cnt->nV) { /* MC:1880-1883 */
 		memset(S, 0, sizeof(surface));
 		return S;
 	}
-	const size_t nV = (size_t)cnt.nV, nT = (size_t)cnt.nT;
+	int (*get)(mc33hip_ctx *, void *, const void *, size_t) = concurrent ? mc33hip_download_concurrent : mc33hip_download;
+	const size_t nV = (size_t)cnt->nV, nT = (size_t)cnt->nT;
 	S->V = (MC33_real(*)[3])malloc(nV * 3 * sizeof(MC33_real));
 	S->N = (float(*)[3])malloc(nV * 3 * sizeof(float));
 	S->T = (unsigned int(*)[3])malloc((nT ? nT : 1) * 3 * sizeof(int));
 	S->color = (int *)malloc(nV * sizeof(int));
 	if (!S->V || !S->N || !S->T || !S->color ||
-	    mc33hip_download(p->ctx, S->V, p->dV, nV * 3 * sizeof(MC33_real)) != MC33HIP_OK ||
-	    mc33hip_download(p->ctx, S->N, p->dN, nV * 12) != MC33HIP_OK ||
-	    mc33hip_download(p->ctx, S->T, p->dT, nT * 12) != MC33HIP_OK) {
+	    get(p->ctx, S->V, g->dV, nV * 3 * sizeof(MC33_real)) != MC33HIP_OK ||
+	    get(p->ctx, S->N, g->dN, nV * 12) != MC33HIP_OK ||
+	    get(p->ctx, S->T, g->dT, nT * 12) != MC33HIP_OK) {
 		free(S->V); free(S->N); free(S->T); free(S->color); free(S);
-		M->memoryfault = 1;
 		return 0;
 	}
 	const int col = DefaultColorMC;
@@ -253,10 +251,87 @@ surface *calculate_isosurface(MC33 *M, MC33_real iso) {
 	S->nV = (unsigned int)nV; S->nT = (unsigned int)nT;
 	S->capv = (unsigned int)nV; S->capt = (unsigned int)(nT ? nT : 1);
 	S->iso = iso;
-	/* mirror of the copy MC:1873 makes into the MC33 object's public prefix */
-	M->T = S->T; M->V = S->V; M->N = S->N; M->color = S->color;
-	M->nT = S->nT; M->capt = S->capt; M->capv = S->capv;
 	return S;
+}
+
+surface *calculate_isosurface(MC33 *M, MC33_real iso) {
+	mc33_private *p = priv(M);
+	if (!p)
+		return 0;
+	M->nT = M->nV = 0;
+	M->memoryfault = 0;
+	M->iso = iso;
+	mc33hip_counts cnt;
+	surface *S = extract_to_staging(p, &p->set[0], iso, &cnt) == MC33HIP_OK ? surface_from_staging(p, &p->set[0], &cnt, iso, 0) : 0;
+	if (!S) {
+		M->memoryfault = 1;
+		return 0;
+	}
+	if (S->nV) { /* mirror of the copy MC:1873 makes into the MC33 object's public prefix */
+		M->T = S->T; M->V = S->V; M->N = S->N; M->color = S->color;
+		M->nT = S->nT; M->capt = S->capt; M->capv = S->capv;
+	}
+	return S;
+}
+
+/* --- extension: several isovalues of the resident grid ---------------------------------------------------- */
+struct download_job {
+	mc33_private *p;
+	const struct staging *g;
+	mc33hip_counts cnt;
+	MC33_real iso;
+	surface *S;
+};
+
+static void *download_thread(void *arg) {
+	struct download_job *j = (struct download_job *)arg;
+	j->S = surface_from_staging(j->p, j->g, &j->cnt, j->iso, 1);
+	return 0;
+}
+
+unsigned int calculate_isosurfaces(MC33 *M, const MC33_real *iso, unsigned int n, surface **out) {
+	mc33_private *p = priv(M);
+	unsigned int done = 0;
+	if (!out)
+		return 0;
+	for (unsigned int k = 0; k != n; k++)
+		out[k] = 0;
+	if (!p || !iso)
+		return 0;
+	M->memoryfault = 0;
+	struct download_job job;
+	pthread_t th;
+	int running = 0;
+	unsigned int running_k = 0;
+	for (unsigned int k = 0; k != n; k++) {
+		/* surface k is computed into set k&1 while the helper thread copies surface k-1 out of the other set */
+		struct staging *g = &p->set[k & 1];
+		mc33hip_counts cnt;
+		M->iso = iso[k];
+		const int rc = extract_to_staging(p, g, iso[k], &cnt);
+		if (running) {
+			pthread_join(th, 0);
+			running = 0;
+			out[running_k] = job.S;
+		}
+		if (rc != MC33HIP_OK)
+			continue;
+		job.p = p; job.g = g; job.cnt = cnt; job.iso = iso[k]; job.S = 0;
+		if (pthread_create(&th, 0, download_thread, &job) == 0) {
+			running = 1;
+			running_k = k;
+		} else
+			out[k] = surface_from_staging(p, g, &cnt, iso[k], 0);
+	}
+	if (running) {
+		pthread_join(th, 0);
+		out[running_k] = job.S;
+	}
+	for (unsigned int k = 0; k != n; k++) {
+		if (out[k]) done++;
+		else M->memoryfault = 1;
+	}
+	return done;
 }
 
 void free_surface_memory(surface *S) { /* MC:84-92 */

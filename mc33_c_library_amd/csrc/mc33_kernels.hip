@@ -904,7 +904,8 @@ struct mc33hip_ctx {
 	uint32_t resident_blocks; // k_sweep blocks the device holds at once
 	Counters *d_ctr, *h_ctr;
 	hipEvent_t ev[4];
-	hipStream_t aux, aux2;    // the vertex pass and the slow-record pass run beside the fast triangle pass
+	hipStream_t aux, aux2;    // the triangle pass and the slow-record pass run beside the vertex pass
+	hipStream_t copy;         // mc33hip_download_concurrent
 	hipEvent_t ev_fork, ev_join, ev_join2;
 	bool emit_pending;        // an emit was enqueued after the last timing read
 	bool inclined, triangular;   // non-orthogonal grid (MC33_spnC): _GRD._A / _GRD.A_ as given
@@ -974,6 +975,7 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	for (int k = 0; k < 4; k++) CREATE_TRY(hipEventCreate(&c->ev[k]));
 	CREATE_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
 	CREATE_TRY(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
+	CREATE_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
@@ -998,6 +1000,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
 	if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+	if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
 	if (c->aux2) { (void)hipStreamSynchronize(c->aux2); (void)hipStreamDestroy(c->aux2); }
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1523,6 +1526,14 @@ extern "C" int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t) {
 	}
 	*t = c->timing;
 	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_download_concurrent(mc33hip_ctx *c, void *dst, const void *src, size_t bytes) {
+	if (!c || (bytes && (!dst || !src))) return MC33HIP_EINVAL;
+	if (!bytes) return MC33HIP_OK;
+	if (hipSetDevice(c->device) != hipSuccess) return MC33HIP_ERUNTIME;  // (may be another thread than the context's)
+	if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->copy) != hipSuccess) return MC33HIP_ERUNTIME;
+	return hipStreamSynchronize(c->copy) == hipSuccess ? MC33HIP_OK : MC33HIP_ERUNTIME;
 }
 
 extern "C" int mc33hip_download(mc33hip_ctx *c, void *dst, const void *src, size_t bytes) {

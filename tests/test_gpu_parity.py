@@ -271,3 +271,41 @@ def test_grd_orthogonal_flavour(reflibs, dtype):
         ev, en, vb, nb = assert_surface_parity(got, ref, float(max(data.shape)), "ortho " + dtype)
         assert vb and nb and got.nV > 1000
         assert (got.nV, got.nT) == (reflibs[dtype].isosurface(data, iso, r0, d).nV, ref.nT)  # and the same surface as the full-layout build
+
+
+def test_batched_isovalues_equal_single_calls(products, reflibs):
+    """calculate_isosurfaces (extension): out[k] must be exactly what calculate_isosurface(M, iso[k]) returns -
+    growing and shrinking results (both staging sets are regrown), an empty one in the middle, n = 1 and n = 0."""
+    import ctypes as C
+    from mc33_capi import SURFACE
+    lib = products["f32"]
+    L = lib.lib
+    L.calculate_isosurfaces.restype = C.c_uint
+    L.calculate_isosurfaces.argtypes = [C.POINTER(lib.MC33), C.POINTER(C.c_float), C.c_uint, C.POINTER(C.POINTER(SURFACE))]
+    data, r0, d = fx.cos_field(160)
+    G, keep = lib.make_grid(data, r0, d)
+    M = L.create_MC33(G)
+    assert M
+    isos = [2.5, 0.0, 7.0, -1.0, 1.5, 0.0, -2.9, 0.25]
+    arr = (C.c_float * len(isos))(*isos)
+    out = (C.POINTER(SURFACE) * len(isos))()
+    assert L.calculate_isosurfaces(M, arr, len(isos), out) == len(isos) and M.contents.memoryfault == 0
+    for k, iso in enumerate(isos):
+        got = lib.copy_surface(out[k])
+        S1 = L.calculate_isosurface(M, C.c_float(iso))
+        one = lib.copy_surface(S1)
+        ref = reflibs["f32"].isosurface(data, iso, r0, d)
+        assert (got.nV, got.nT) == (one.nV, one.nT) == (ref.nV, ref.nT), iso
+        assert np.array_equal(got.T, ref.T) and np.array_equal(got.V.view(np.uint32), ref.V.view(np.uint32))
+        assert np.array_equal(got.N.view(np.uint32), one.N.view(np.uint32)) and np.array_equal(got.color, one.color)
+        assert got.iso == one.iso
+        L.free_surface_memory(S1)
+        L.free_surface_memory(out[k])
+    assert isos[2] == 7.0 and lib.copy_surface is not None
+    one = (C.POINTER(SURFACE) * 1)()
+    assert L.calculate_isosurfaces(M, (C.c_float * 1)(0.5), 1, one) == 1 and one[0].contents.nV > 0
+    L.free_surface_memory(one[0])
+    assert L.calculate_isosurfaces(M, arr, 0, out) == 0
+    L.free_MC33(M)
+    L.free_memory_grd(G)
+    del keep
