@@ -263,7 +263,7 @@ def main():
                 # kernels; the three emit kernels (running side by side on 3 streams)
                 "kernel_ms": {"k_sweep": sw, "k_cells_slow_scans": avg(scan_ms), "k_emit_x3": avg(emit_ms) if emit_ms else None},
                 "whole_call": {"algorithmic_bytes": grid_bytes_alg + out_bytes,
-                               "device_ms": sw + avg(scan_ms) + avg(emit_ms),
+                               "device_ms": (sw + avg(scan_ms) + avg(emit_ms)) if sw else None,
                                "frac": ((grid_bytes_alg + out_bytes) / ((sw + avg(scan_ms) + avg(emit_ms)) * 1e-3) / 1e9 / PEAK_HBM_GBS)
                                if sw else None}}
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")

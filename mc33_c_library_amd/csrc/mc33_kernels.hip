@@ -908,6 +908,7 @@ struct mc33hip_ctx {
 	hipStream_t copy;         // mc33hip_download_concurrent
 	hipEvent_t ev_fork, ev_join, ev_join2;
 	bool emit_pending;        // an emit was enqueued after the last timing read
+	int timing_level;         // MC33_HIP_TIMING: 0 none, 1 whole call, 2 (default) per pass - an event record costs ~12 us of device time
 	bool inclined, triangular;   // non-orthogonal grid (MC33_spnC): _GRD._A / _GRD.A_ as given
 	double grd_A[9], grd_Ai[9];
 	unsigned long long *trace;  // developer tracing (MC33_HIP_TRACE_FILE)
@@ -976,6 +977,7 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	CREATE_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
 	CREATE_TRY(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
 	CREATE_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+	c->timing_level = getenv("MC33_HIP_TIMING") ? atoi(getenv("MC33_HIP_TIMING")) : 2;
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
@@ -1302,10 +1304,10 @@ static int enqueue_count(mc33hip_ctx *c) {
 	}
 	// nothing is cleared between extractions: headers carry the epoch, k_slots resets the counters and the
 	// partial sums of the next call, k_cells writes every row segment count of the range
-	HIP_TRY(hipEventRecord(c->ev[0], st));
+	if (c->timing_level > 0) HIP_TRY(hipEventRecord(c->ev[0], st));
 	hipLaunchKernelGGL(k_sweep, dim3((uint32_t)blocks), dim3(256), 0, st, a);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(c->ev[1], st));
+	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[1], st));
 	CellsArgs ca;
 	ca.P = P; ca.fast = c->d_fast;
 	ca.ze = ze; ca.nYT = a.nYT; ca.nseg_pad = a.nseg_pad;
@@ -1343,7 +1345,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, c->seg_base,
 	                   c->ghost_segs, c->d_ctr);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(c->ev[2], st));
+	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[2], st));
 	return 0;
 }
 
@@ -1385,7 +1387,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
 		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
 	}
-	HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+	if (c->timing_level > 0) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
 	c->emit_pending = true;
 	return 0;
 }
@@ -1433,14 +1435,14 @@ static void read_timing(mc33hip_ctx *c, bool with_emit, unsigned launches) {
 	mc33hip_timing &t = c->timing;
 	c->emit_pending = false;
 	t.sweep_ms = t.scan_ms = t.emit_ms = t.total_ms = 0.f;
-	(void)hipEventElapsedTime(&t.sweep_ms, c->ev[0], c->ev[1]);
-	(void)hipEventElapsedTime(&t.scan_ms, c->ev[1], c->ev[2]);
-	if (with_emit) {
-		(void)hipEventElapsedTime(&t.emit_ms, c->ev[2], c->ev[3]);
-		(void)hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[3]);
-	} else
-		(void)hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[2]);
 	t.sweep_launches = launches;
+	if (c->timing_level > 1) {
+		(void)hipEventElapsedTime(&t.sweep_ms, c->ev[0], c->ev[1]);
+		(void)hipEventElapsedTime(&t.scan_ms, c->ev[1], c->ev[2]);
+		if (with_emit) (void)hipEventElapsedTime(&t.emit_ms, c->ev[2], c->ev[3]);
+	}
+	if (c->timing_level > 0 && with_emit) (void)hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[3]);
+	else if (c->timing_level > 1) (void)hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[2]);
 }
 
 extern "C" int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *range, mc33hip_counts *out) {

@@ -5,6 +5,6 @@ for setting in "$@"; do
   out=$(env $setting MC33_BENCH_NO_CPU=1 timeout -k 10 200 python bench.py --steps 10 --warmup 3 2>/dev/null | grep '^{' | python -c '
 import json,sys
 j=json.loads(sys.stdin.read()); r=j["roofline"]
-print("ms/step %.3f  %s  frac %.3f" % (j["ms_per_step"], json.dumps(r["kernel_ms"]), r["frac"]))')
+print("ms/step %.3f  %s  frac %s" % (j["ms_per_step"], json.dumps(r["kernel_ms"]), r["frac"]))')
   echo "[$setting] $out"
 done
