@@ -22,138 +22,158 @@
 #define MC33C_VERSION_MAJOR 5
 #define MC33C_VERSION_MINOR 5
 
-#if defined(INTEGER_GRD)
-typedef float MC33_real;
-#  if GRD_TYPE_SIZE == 4
-typedef unsigned int GRD_data_type;
-#  elif GRD_TYPE_SIZE == 2
-typedef unsigned short int GRD_data_type;
-#  elif GRD_TYPE_SIZE == 1
-typedef unsigned char GRD_data_type;
-#  else
+/* ---- sample type (GRD_data_type) and arithmetic / vertex type (MC33_real) of this build ------------------- */
+#ifdef INTEGER_GRD
+#  if !defined(GRD_TYPE_SIZE) || (GRD_TYPE_SIZE != 1 && GRD_TYPE_SIZE != 2 && GRD_TYPE_SIZE != 4)
 #    error "INTEGER_GRD needs GRD_TYPE_SIZE 1, 2 or 4"
 #  endif
+#  if GRD_TYPE_SIZE == 1
+#    define MC33_SAMPLE_C_TYPE unsigned char
+#  elif GRD_TYPE_SIZE == 2
+#    define MC33_SAMPLE_C_TYPE unsigned short
+#  else
+#    define MC33_SAMPLE_C_TYPE unsigned
+#  endif
+#  define MC33_REAL_C_TYPE float
 #elif defined(GRD_TYPE_SIZE) && GRD_TYPE_SIZE == 8
-typedef double GRD_data_type;
-typedef double MC33_real;
+#  define MC33_SAMPLE_C_TYPE double
+#  define MC33_REAL_C_TYPE double
 #else
-typedef float GRD_data_type;
-typedef float MC33_real;
 #  undef GRD_TYPE_SIZE
 #  define GRD_TYPE_SIZE 4
+#  define MC33_SAMPLE_C_TYPE float
+#  define MC33_REAL_C_TYPE float
 #endif
-
+typedef MC33_SAMPLE_C_TYPE GRD_data_type;
+typedef MC33_REAL_C_TYPE MC33_real;
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-/* Regular grid of samples F[k][j][i] (k: z, j: y, i: x), N[] intervals per axis, so N[]+1 points.
- * Layout identical to the reference's _GRD (reference header :111-124), 416 bytes. */
-typedef struct {
-	GRD_data_type ***F;      /* row pointers; rows may be separate allocations                      */
-	unsigned int N[3];       /* intervals in x, y, z                                               */
-	double r0[3], d[3];      /* origin, spacing                                                    */
-	float L[3];              /* extent (unused by the isosurface path)                             */
+/* ---- _GRD: regular grid of samples F[k][j][i] (k: z, j: y, i: x); N[] intervals per axis, N[]+1 points -----
+ * Byte layout of the reference's _GRD (reference header :111-124): 416 bytes, 256 with GRD_ORTHOGONAL. */
+typedef struct mc33_grid {
+	GRD_data_type ***F;        /* plane -> row -> samples; rows may be separate allocations              */
+	unsigned N[3];             /* intervals in x, y, z                                                  */
+	double r0[3];              /* origin                                                                */
+	double d[3];               /* spacing                                                               */
+	float L[3];                /* extent (unused by the isosurface path)                                */
 #ifndef GRD_ORTHOGONAL
-	float Ang[3];
-	int nonortho;            /* inclined grid: positions / normals go through _A / A_ (MC33_spnC)  */
-	double _A[3][3], A_[3][3]; /* fractional -> cartesian cell matrix (unit edges) and its inverse  */
+	float Ang[3];              /* cell angles in degrees                                                */
+	int nonortho;              /* inclined grid: positions / normals go through _A / A_ (MC33_spnC)     */
+	double _A[3][3];           /* fractional -> cartesian cell matrix (unit edges) ...                  */
+	double A_[3][3];           /* ... and the matrix applied (transposed) to the gradients              */
 #endif
 	int periodic;
-	int internal_data;       /* 1: rows were allocated by alloc_F and are freed by free_memory_grd */
+	int internal_data;         /* 1: rows were allocated by alloc_F and are freed by free_memory_grd    */
 	char title[160];
 } _GRD;
 
-/* Result of calculate_isosurface (reference header :133-152), 64 bytes.  T, V, N, color and the
- * struct itself are five separate malloc blocks owned by the caller (free_surface_memory). */
-typedef struct {
-	unsigned int (*T)[3];    /* triangles: three vertex indices each   */
-	MC33_real (*V)[3];       /* vertex positions                        */
-	float (*N)[3];           /* unit normals                            */
-	int *color;              /* one 0xAABBGGRR colour per vertex        */
-	unsigned int nV, nT;
-	unsigned int capt, capv; /* allocated triangles / vertices          */
+/* ---- surface: result of calculate_isosurface (reference header :133-152), 64 bytes ------------------------
+ * T, V, N, color and the struct itself are five separate malloc blocks owned by the caller
+ * (free_surface_memory).  MC33 starts with the same members. */
+typedef unsigned mc33_triangle[3];
+typedef MC33_real mc33_position[3];
+typedef float mc33_normal[3];
+#define MC33_SURFACE_MEMBERS                                                                     \
+	mc33_triangle *T;  /* triangles: three vertex indices each                                */ \
+	mc33_position *V;  /* vertex positions                                                    */ \
+	mc33_normal *N;    /* unit normals                                                        */ \
+	int *color;        /* one 0xAABBGGRR colour per vertex                                    */ \
+	unsigned nV;                                                                                 \
+	unsigned nT;                                                                                 \
+	unsigned capt;     /* allocated triangles                                                 */ \
+	unsigned capv;     /* allocated vertices                                                  */ \
 	MC33_real iso;
-	union {
-		void *p;
-		long long ul;
-		int i[2];
-		short si[4];
-		char c[8];
-		float f[2];
-		double df;
-	} user;                  /* free for the caller                     */
+
+typedef union mc33_user_data { /* 8 bytes free for the caller */
+	void *p;
+	long long ul;
+	int i[2];
+	short si[4];
+	char c[8];
+	float f[2];
+	double df;
+} mc33_user_data;
+
+typedef struct mc33_surface {
+	MC33_SURFACE_MEMBERS
+	mc33_user_data user;
 } surface;
 
-/* Extraction object (reference header :154-179), 304-byte public prefix.  This library allocates a
- * larger private object whose first member is this struct; Dx..Lz are unused (NULL) and the GPU
- * context hangs behind the public part. */
-typedef struct {
-	unsigned int (*T)[3];
-	MC33_real (*V)[3];
-	float (*N)[3];
-	int *color;
-	unsigned int nV, nT;
-	unsigned int capt, capv;
-	MC33_real iso;
-	int memoryfault;         /* non-zero after a failed calculate_isosurface (out of memory, GPU error) */
+/* ---- MC33: extraction object (reference header :154-179); 304-byte public part (344 double build; 144 less
+ * with GRD_ORTHOGONAL).  This library allocates a larger private object whose first member is this struct;
+ * the five id caches of the reference's sweep are unused (NULL), the GPU context hangs behind the public part. */
+typedef struct mc33_extractor {
+	MC33_SURFACE_MEMBERS
+	int memoryfault;           /* non-zero after a failed calculate_isosurface (out of memory, GPU error) */
 	const GRD_data_type ***F;
-	MC33_real O[3], D[3], ca, cb;
-	unsigned int nx, ny, nz;
-	unsigned int (*store)(void *, MC33_real *);
+	MC33_real O[3];            /* origin, spacing as MC33_real                                           */
+	MC33_real D[3];
+	MC33_real ca;              /* d[2]/d[0], d[2]/d[1] (anisotropic spacing)                             */
+	MC33_real cb;
+	unsigned nx;
+	unsigned ny;
+	unsigned nz;
+	unsigned (*store)(void *, MC33_real *);
 #ifndef GRD_ORTHOGONAL
-	double _A[3][3], A_[3][3];
+	double _A[3][3];           /* cell matrices scaled by the spacing (inclined grids)                   */
+	double A_[3][3];
 #endif
-	unsigned int **Dx, **Dy, **Ux, **Uy, **Lz;
+	unsigned **Dx;
+	unsigned **Dy;
+	unsigned **Ux;
+	unsigned **Uy;
+	unsigned **Lz;
 } MC33;
 
-extern int DefaultColorMC;   /* colour given to every vertex, 0xAABBGGRR (reference header :181) */
+/* colour given to every vertex, 0xAABBGGRR (reference header :181) */
+extern int DefaultColorMC;
 
-/* c = A b (t == 0) or A^T b (t != 0) for a 3x3 matrix, used for inclined grids (reference header :186-191).
- * _multTSA_bf assumes an upper triangular A.  A caller may point mult_Abf at either; calculate_isosurface
- * looks at the pointer when it is called and runs the matching form on the GPU (any other function: NULL). */
-void _multTSA_bf(const double (*A)[3], MC33_real *b, MC33_real *c, int t);
-void _multA_bf(const double (*A)[3], MC33_real *b, MC33_real *c, int t);
-extern void (*mult_Abf)(const double (*)[3], MC33_real *, MC33_real *, int);
+/* ---- isosurface path (reference header :228-258) --------------------------------------------------------- */
+MC33 *create_MC33(_GRD *grid);                                   /* uploads the grid to HBM once          */
+surface *calculate_isosurface(MC33 *extractor, MC33_real isovalue); /* GPU extraction; NULL on failure      */
+unsigned long long size_of_isosurface(MC33 *extractor, MC33_real isovalue,
+                                      unsigned *vertices, unsigned *triangles);
+void free_MC33(MC33 *extractor);
+void free_surface_memory(surface *s);
+void adjustvectorlenght_s(surface *s);                           /* shrink the arrays to nV / nT          */
 
-/* --- isosurface path (reference header :228-258) ------------------------------------------------ */
-MC33 *create_MC33(_GRD *G);                                  /* uploads the grid to HBM once        */
-surface *calculate_isosurface(MC33 *M, MC33_real iso);       /* GPU extraction; NULL on failure     */
-unsigned long long size_of_isosurface(MC33 *M, MC33_real iso, unsigned int *nV, unsigned int *nT);
-void free_MC33(MC33 *M);
-void free_surface_memory(surface *S);
-void adjustvectorlenght_s(surface *S);
-
-/* --- extension (not in the reference): several isovalues of the grid that is resident in HBM ------- */
-/* out[k] = what calculate_isosurface(M, iso[k]) would return (NULL where it failed; caller frees each with
+/* extension (not in the reference): several isovalues of the grid that is resident in HBM.
+ * out[k] = what calculate_isosurface(M, iso[k]) would return (NULL where it failed; the caller frees each with
  * free_surface_memory).  The device-to-host copy of surface k runs beside the extraction of surface k+1.
  * Returns the number of surfaces produced. */
-unsigned int calculate_isosurfaces(MC33 *M, const MC33_real *iso, unsigned int n, surface **out);
+unsigned calculate_isosurfaces(MC33 *extractor, const MC33_real *isovalues, unsigned count, surface **out);
 
-/* --- surface files (reference header :193-222), host C: csrc/mc33_surface_io.c -------------------- */
-int write_bin_s(surface *S, const char *filename);   /* ".sup" binary container; 0 on success, -1 on failure */
-surface *read_bin_s(const char *filename);           /* NULL on failure; also reads ".sud" (double) files      */
-int write_txt_s(surface *S, const char *filename);
-int write_obj_s(surface *S, const char *filename);   /* Wavefront OBJ with per-vertex normals                  */
-int write_ply_s(surface *S, const char *filename, const char *author, const char *object); /* ASCII PLY       */
+/* ---- inclined grids (reference header :186-191) ---------------------------------------------------------
+ * c = A b (transposed == 0) or A^T b for a 3x3 matrix; _multTSA_bf assumes an upper triangular A.  A caller may
+ * point mult_Abf at either; calculate_isosurface looks at the pointer when it is called and runs the matching
+ * form on the GPU (any other function: NULL + memoryfault). */
+void _multA_bf(const double (*A)[3], MC33_real *b, MC33_real *c, int transposed);
+void _multTSA_bf(const double (*A)[3], MC33_real *b, MC33_real *c, int transposed);
+extern void (*mult_Abf)(const double (*A)[3], MC33_real *b, MC33_real *c, int transposed);
 
-/* --- grid container helpers (reference header :263-329), host C ---------------------------------- */
-void free_memory_grd(_GRD *Z);
-int alloc_F(_GRD *Z);
-_GRD *grid_from_data_pointer(unsigned int Nx, unsigned int Ny, unsigned int Nz, GRD_data_type *data);
-_GRD *generate_grid_from_fn(double x_initial, double y_initial, double z_initial,
-                            double x_final, double y_final, double z_final,
-                            double x_step, double y_step, double z_step,
-                            double (*fn)(double x, double y, double z));
+/* ---- surface files (reference header :193-222), host C: csrc/mc33_surface_io.c --------------------------- */
+int write_bin_s(surface *s, const char *path);     /* ".sup" / ".sud" binary container; 0 on success, -1 on failure */
+surface *read_bin_s(const char *path);             /* NULL on failure; reads both precisions                         */
+int write_txt_s(surface *s, const char *path);
+int write_obj_s(surface *s, const char *path);     /* Wavefront OBJ with per-vertex normals                          */
+int write_ply_s(surface *s, const char *path, const char *author, const char *object); /* ASCII PLY               */
 
+/* ---- grid containers (reference header :263-329), host C --------------------------------------------------- */
+int alloc_F(_GRD *grid);                            /* rows for N[] + 1 points per axis; 0 on success               */
+void free_memory_grd(_GRD *grid);
+_GRD *grid_from_data_pointer(unsigned points_x, unsigned points_y, unsigned points_z, GRD_data_type *samples);
+_GRD *generate_grid_from_fn(double x0, double y0, double z0, double x1, double y1, double z1,
+                            double step_x, double step_y, double step_z, double (*f)(double, double, double));
 
-/* --- grid file readers (reference header :263-311), host C: csrc/mc33_grid_io.c; NULL on failure --------- */
-_GRD *read_grd(const char *filename);                  /* DMol .grd text file (may describe an inclined cell)  */
-_GRD *read_grd_binary(const char *filename);           /* the library's own binary container ("_GRD")          */
-_GRD *read_scanfiles(const char *filename, unsigned int res, int order); /* numbered res x res u16 slices       */
-_GRD *read_raw_file(const char *filename, unsigned int *N, int byte, int isfloat); /* bare samples, N = points  */
-_GRD *read_dat_file(const char *filename);             /* u16 nx, ny, nz header + u16 samples                  */
+/* ---- grid files (reference header :263-311), host C: csrc/mc33_grid_io.c; NULL on failure ------------------ */
+_GRD *read_grd(const char *path);                   /* DMol .grd text file (may describe an inclined cell)         */
+_GRD *read_grd_binary(const char *path);            /* the library's own binary container ("_GRD")                 */
+_GRD *read_scanfiles(const char *first_file, unsigned resolution, int swap_bytes); /* numbered res x res u16 slices */
+_GRD *read_raw_file(const char *path, unsigned *points, int bytes_per_sample, int is_float); /* bare samples     */
+_GRD *read_dat_file(const char *path);              /* u16 nx, ny, nz header + u16 samples                         */
 
 #ifdef __cplusplus
 }

@@ -96,3 +96,42 @@ def test_orthogonal_flavour_exports_the_same_api(dtype):
     from mc33_c_library_amd import HIP_API, REFERENCE_API
     for n in HIP_API + REFERENCE_API:
         assert hasattr(lib, n), n
+
+
+CALLER = r"""
+/* a caller written against the reference header (usage snippet of reference marching_cubes_33.h:31-52) */
+#include <stdio.h>
+#include <marching_cubes_33.h>
+static double fn(double x, double y, double z) { return x * x + y * y + z * z - 1; }
+int main(void) {
+	_GRD *G = generate_grid_from_fn(-2, -2, -2, 2, 2, 2, 0.1, 0.1, 0.1, fn);
+	MC33 *M = create_MC33(G);
+	if (!M) { puts("create_MC33: NULL"); free_memory_grd(G); return 3; }
+	surface *S = calculate_isosurface(M, 0.0f);
+	if (!S) return 4;
+	unsigned int a = S->T[0][0];
+	float *v = S->V[a];
+	S->user.p = 0;
+	printf("%u %u %f %d\n", S->nV, S->nT, v[0], M->memoryfault);
+	free_surface_memory(S); free_MC33(M); free_memory_grd(G);
+	return 0;
+}
+"""
+
+
+@pytest.mark.parametrize("compiler,lang", [("gcc", "c"), ("g++", "c++")])
+def test_reference_style_caller_compiles_and_links(tmp_path, compiler, lang):
+    """Source compatibility of include/marching_cubes_33.h: a program written against the reference's header builds
+    unchanged (C and C++) and links against libMC33_f32.so; without a GPU it gets NULL from create_MC33."""
+    import subprocess
+    src = tmp_path / "caller.c"
+    src.write_text(CALLER)
+    exe = tmp_path / ("caller_" + lang.replace("+", "p"))
+    libdir = os.path.dirname(product_path("f32"))
+    subprocess.check_call([compiler, "-Wall", "-Werror", "-x", lang, "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir,
+                           "-l:libMC33_f32.so", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    if _no_gpu():
+        assert r.returncode == 3 and "NULL" in r.stdout
+    else:
+        assert r.returncode == 0 and int(r.stdout.split()[0]) > 1000
