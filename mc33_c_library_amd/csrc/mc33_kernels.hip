@@ -104,7 +104,7 @@ struct SweepArgs {
 	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz)
 	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: rows << 32 | cells of the slices of that chunk
 	uint32_t epoch;          // number of this extraction (stamped into the slice headers)
-	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only; the later passes are not launched): 2 = stream only
+	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only): 2 = stream only - no slice is handed on, every count is 0
 };
 
 
