@@ -703,33 +703,20 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, ui
 	if (threadIdx.x == 0) { bsV[blockIdx.x] = sv[0] + sv[1] + sv[2] + sv[3]; bsT[blockIdx.x] = st[0] + st[1] + st[2] + st[3]; }
 }
 
-// one block: exclusive scan of the per-chunk sums, totals into the counters
-__global__ __launch_bounds__(1024) void k_scan_spine(uint64_t *bsV, uint64_t *bsT, uint32_t nb, Counters *ctr) {
-	__shared__ uint64_t pv[1024], pt[1024];
-	const uint32_t per = (nb + 1023u) / 1024u, lo = threadIdx.x * per, hi = min(lo + per, nb);
-	uint64_t v = 0, t = 0;
-	for (uint32_t k = lo; k < hi; k++) { v += bsV[k]; t += bsT[k]; }
-	pv[threadIdx.x] = v; pt[threadIdx.x] = t;
-	__syncthreads();
-	for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan in LDS
-		uint64_t av = 0, at = 0;
-		if (threadIdx.x >= d) { av = pv[threadIdx.x - d]; at = pt[threadIdx.x - d]; }
-		__syncthreads();
-		pv[threadIdx.x] += av; pt[threadIdx.x] += at;
-		__syncthreads();
-	}
-	uint64_t ev = pv[threadIdx.x] - v, et = pt[threadIdx.x] - t;
-	for (uint32_t k = lo; k < hi; k++) {
-		const uint64_t cv = bsV[k], ct = bsT[k];
-		bsV[k] = ev; bsT[k] = et;
-		ev += cv; et += ct;
-	}
-	if (threadIdx.x == 1023) { ctr->totV = pv[1023]; ctr->totT = pt[1023]; }
-}
-
+// Second pass: every block first adds up the sums of the chunks before its own (a few thousand values, resident in
+// L2; cheaper than a separate one-block scan kernel between the two passes), then scans its chunk.  The last block
+// also knows the totals.
 __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uint64_t n, Params P, const uint64_t *bsV, const uint64_t *bsT,
                                                     SegBase *seg_base, uint64_t ghost_segs, Counters *ctr) {
 	__shared__ uint32_t sv[4], st[4];
+	__shared__ uint64_t s_bv[4], s_bt[4];
+	uint64_t bv = 0, bt = 0;  // vertices / triangles of all chunks before this one
+	for (uint32_t k = threadIdx.x; k < blockIdx.x; k += 256u) { bv += bsV[k]; bt += bsT[k]; }
+	bv = wave_sum(bv); bt = wave_sum(bt);
+	if ((threadIdx.x & 63u) == 0) { s_bv[threadIdx.x >> 6] = bv; s_bt[threadIdx.x >> 6] = bt; }
+	__syncthreads();
+	bv = s_bv[0] + s_bv[1] + s_bv[2] + s_bv[3]; bt = s_bt[0] + s_bt[1] + s_bt[2] + s_bt[3];
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { ctr->totV = bv + bsV[blockIdx.x]; ctr->totT = bt + bsT[blockIdx.x]; }
 	const uint64_t q0 = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
 	uint32_t cv[SCAN_PER_THREAD], ct[SCAN_PER_THREAD], v = 0, t = 0;
 	uint64_t st_idx[SCAN_PER_THREAD];
@@ -751,7 +738,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uin
 	}
 	if (lane == 63) { sv[wv] = iv; st[wv] = it; }
 	__syncthreads();
-	uint32_t ev = (uint32_t)bsV[blockIdx.x] + iv - v, et = (uint32_t)bsT[blockIdx.x] + it - t;
+	uint32_t ev = (uint32_t)bv + iv - v, et = (uint32_t)bt + it - t;
 	for (uint32_t k = 0; k < wv; k++) { ev += sv[k]; et += st[k]; }
 #pragma unroll
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
@@ -1341,7 +1328,6 @@ static int enqueue_count(mc33hip_ctx *c) {
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
 	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
 	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT);
-	hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, c->bsV, c->bsT, nb, c->d_ctr);
 	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, c->seg_base,
 	                   c->ghost_segs, c->d_ctr);
 	HIP_TRY(hipGetLastError());
