@@ -104,6 +104,9 @@ struct SweepArgs {
 	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz)
 	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: rows << 32 | cells of the slices of that chunk
 	uint32_t epoch;          // number of this extraction (stamped into the slice headers)
+	uint32_t z_end;          // end of the classified range: tiles that reach it have no tile above
+	uint4 *edge_bits;        // [(tile * 4 + wave) * 2 + (0 bottom | 1 top)][2][lane]: bit rows of the tile's first / last plane
+	uint4 *edge_hdr;         // ... their halo-column bits and "a sample equals the isovalue" flag
 	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only): 2 = stream only - no slice is handed on, every count is 0
 };
 
@@ -165,6 +168,34 @@ __device__ __forceinline__ void valid_masks(uint32_t xbase, uint32_t nx, uint64_
 	}
 }
 
+// A slice with cut cells is handed to k_cells: its bit rows (4 KiB), the halo-column bits, flags and counts; the
+// counts also go into the partial sum of the slot's chunk (k_slots).  prev / cur: bit rows of planes z / z+1, lane =
+// sample row; bp / bc: ballots of the halo-column bits.  Wave-uniform call.
+__device__ __forceinline__ void hand_over_slice(const SweepArgs &a, uint64_t slot, const uint64_t (&prev)[4], const uint64_t (&cur)[4],
+                                                uint64_t bp, uint64_t bc, bool has_iso, const uint64_t (&act)[4]) {
+	const uint32_t lane = threadIdx.x & 63u;
+	uint4 *bits = a.slice_bits + slot * 256u + lane;
+	if (!(a.debug & 64u)) {
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+		bits[64 * k] = uint4{(uint32_t)prev[k], (uint32_t)(prev[k] >> 32), (uint32_t)cur[k], (uint32_t)(cur[k] >> 32)};
+	}
+	// cut cells and non-empty rows of the slice: the record ranges are prefix sums of these (k_slots)
+	uint32_t ncell = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
+	const uint32_t nrow = (uint32_t)__popcll(__ballot(ncell != 0));
+#pragma unroll
+	for (int dlt = 32; dlt; dlt >>= 1) ncell += __shfl_xor(ncell, dlt);
+	if (lane == 0) {
+		SliceHeader h;
+		h.flags = a.epoch << 2 | SLICE_VALID | (has_iso ? SLICE_HAS_ISO : 0u);
+		h.prevh_lo = (uint32_t)bp; h.prevh_hi = (uint32_t)(bp >> 32);
+		h.curh_lo = (uint32_t)bc; h.curh_hi = (uint32_t)(bc >> 32);
+		h.cells = ncell; h.rows = nrow; h.pad_ = 0;
+		a.slice_hdr[slot] = h;
+		if (!(a.debug & 32u)) atomicAdd(a.slot_part + slot / SLOT_CHUNK, (unsigned long long)nrow << 32 | ncell);
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------
 // k_sweep: one wave per tile column (256 samples in x, 64 sample rows, rz+1 planes), 4 waves per block
 // side by side in x so that a block reads whole 1024-sample (4 KiB) row pieces.
@@ -177,6 +208,11 @@ __device__ __forceinline__ void valid_masks(uint32_t xbase, uint32_t nx, uint64_
 // have their bit rows written out (4 KiB) for k_cells; nothing else is stored, nothing is allocated:
 // the wave only streams.  (Doing the per-cell work here made the kernel end on a long tail of a few
 // waves whose tiles hold most of the surface.)
+//
+// Tiles of one column do not overlap: a tile reads the planes z_lo+1 .. z_hi (the lowest tile of the column also
+// z_lo) and handles the slices between them; the slice between its first plane and the last plane of the tile
+// below is put together by k_boundary from the bit rows both tiles leave behind (2 KiB each) - re-reading that
+// plane instead cost 1/depth of the traffic (6 % at depth 16).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -188,6 +224,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
 	const uint32_t nrows = min(64u, P.ny + 1 - y0);  // sample rows of this tile
 	const uint32_t z_lo = tile.z_lo, z_hi = tile.z_hi;
+	const uint32_t pl0 = z_lo == P.zs ? z_lo : z_lo + 1u;  // first plane this tile reads
+	const bool has_above = z_hi < a.z_end;
 	const real_t iso = P.iso;
 
 	// per-lane byte offsets of its four samples inside a row (clamped into the row: bits of samples
@@ -216,7 +254,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	// is turned into bit rows.  Loads go through a buffer descriptor per plane (scalar base + 32-bit
 	// offsets, hardware range check).
 	const uint32_t NB = (nrows + 3u) / 4u;
-	const uint32_t T = (z_hi - z_lo + 1u) * NB;
+	const uint32_t T = (z_hi - pl0 + 1u) * NB;
 	const uint32_t tile_bytes = nrows * rowbytes;
 #if defined(MC33_GRD_U16)
 #define MC33_LOAD(rs, vo, so) ((float)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0))
@@ -281,31 +319,24 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 			cur_z = __ballot(zmin == 0) != 0ull;  // some sample of this plane of the tile equals the isovalue
 			zmin = 1;
 		}
-		if (p > z_lo && !(a.debug & 2u)) {
-			uint64_t act[4];
-			active_cells(prev, cur, prev_h, cur_h, valid, rowvalid, act);
-			if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull)) {  // wave-uniform: hand the slice to k_cells
-				const uint64_t slot = slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad);
-				uint4 *bits = a.slice_bits + slot * 256u + lane;
-#pragma unroll
-				for (int k = 0; k < 4; k++)
-					bits[64 * k] = uint4{(uint32_t)prev[k], (uint32_t)(prev[k] >> 32), (uint32_t)cur[k], (uint32_t)(cur[k] >> 32)};
-				const uint64_t bp = __ballot(prev_h != 0), bc = __ballot(cur_h != 0);
-				// cut cells and non-empty rows of the slice: the record ranges are prefix sums of these (k_slots)
-				uint32_t ncell = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
-				const uint32_t nrow = (uint32_t)__popcll(__ballot(ncell != 0));
-#pragma unroll
-				for (int dlt = 32; dlt; dlt >>= 1) ncell += __shfl_xor(ncell, dlt);
-				if (lane == 0) {
-					SliceHeader h;
-					h.flags = a.epoch << 2 | SLICE_VALID | ((prev_z || cur_z) ? SLICE_HAS_ISO : 0u);
-					h.prevh_lo = (uint32_t)bp; h.prevh_hi = (uint32_t)(bp >> 32);
-					h.curh_lo = (uint32_t)bc; h.curh_hi = (uint32_t)(bc >> 32);
-					h.cells = ncell; h.rows = nrow; h.pad_ = 0;
-					a.slice_hdr[slot] = h;
-					atomicAdd(a.slot_part + slot / SLOT_CHUNK, (unsigned long long)nrow << 32 | ncell);
-				}
+		auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary
+			uint4 *e = a.edge_bits + ((uint64_t)(blockIdx.x * 4u + wv) * 2u + which) * 128u + lane;
+			e[0] = uint4{(uint32_t)cur[0], (uint32_t)(cur[0] >> 32), (uint32_t)cur[1], (uint32_t)(cur[1] >> 32)};
+			e[64] = uint4{(uint32_t)cur[2], (uint32_t)(cur[2] >> 32), (uint32_t)cur[3], (uint32_t)(cur[3] >> 32)};
+			const uint64_t bh = __ballot(cur_h != 0);
+			if (lane == 0) a.edge_hdr[(uint64_t)(blockIdx.x * 4u + wv) * 2u + which] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), cur_z ? 1u : 0u, 0u};
+		};
+		if (a.debug & 2u) {
+		} else {
+			if (p == pl0 && pl0 != z_lo) leave_edge(0);
+			if (p > pl0) {
+				uint64_t act[4];
+				active_cells(prev, cur, prev_h, cur_h, valid, rowvalid, act);
+				if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(a.debug & 16u))  // wave-uniform: hand the slice to k_cells
+					hand_over_slice(a, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), prev, cur, __ballot(prev_h != 0), __ballot(cur_h != 0),
+					                prev_z || cur_z, act);
 			}
+			if (p == z_hi && has_above) leave_edge(1);
 		}
 #pragma unroll
 		for (int k = 0; k < 4; k++) prev[k] = cur[k];
@@ -314,7 +345,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	};
 
 	real_t dA[16], dB[16], hA = 0, hB = 0;
-	uint32_t ip = z_lo, ib = 0, pp = z_lo, pb = 0;  // (plane, batch) of the next issue / of the next process
+	uint32_t ip = pl0, ib = 0, pp = pl0, pb = 0;  // (plane, batch) of the next issue / of the next process
 	// past the end of the tile the prefetch simply re-reads the last batch (it is never processed)
 #define MC33_ADV(p_, b_) do { if (++(b_) == NB) { (b_) = 0; ++(p_); } } while (0)
 #define MC33_ADV_ISSUE() do { if (ip != z_hi || ib + 1 != NB) MC33_ADV(ip, ib); } while (0)
@@ -332,6 +363,33 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 #undef MC33_ADV_ISSUE
 #undef MC33_ADV
 #undef MC33_LOAD
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_boundary: the slice between the last plane of a tile and the first plane of the tile above it, from the bit
+// rows the two left behind.  One block per pair of tiles (4 waves = the 4 row segments).
+// ---------------------------------------------------------------------------------------------------
+struct TileBoundary { uint32_t below, above, z, yt, xg, pad_[3]; };  // tile (block) indices of k_sweep; slice z
+
+__global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileBoundary *bounds) {
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	const TileBoundary b = bounds[blockIdx.x];
+	const Params &P = a.P;
+	const uint32_t seg = b.xg * 4u + wv;
+	if (seg >= P.nseg) return;
+	const uint64_t rp = (uint64_t)(b.below * 4u + wv) * 2u + 1u, rc = (uint64_t)(b.above * 4u + wv) * 2u;  // top of below, bottom of above
+	const uint4 p0 = a.edge_bits[rp * 128u + lane], p1 = a.edge_bits[rp * 128u + 64u + lane];
+	const uint4 c0 = a.edge_bits[rc * 128u + lane], c1 = a.edge_bits[rc * 128u + 64u + lane];
+	const uint4 hp = a.edge_hdr[rp], hc = a.edge_hdr[rc];
+	const uint64_t prev[4] = {u64(p0.x, p0.y), u64(p0.z, p0.w), u64(p1.x, p1.y), u64(p1.z, p1.w)};
+	const uint64_t cur[4] = {u64(c0.x, c0.y), u64(c0.z, c0.w), u64(c1.x, c1.y), u64(c1.z, c1.w)};
+	const uint64_t bp = u64(hp.x, hp.y), bc = u64(hc.x, hc.y);
+	uint64_t valid[4], act[4];
+	valid_masks(seg * SEG_CELLS, P.nx, valid);
+	const bool rowvalid = lane < 63u && b.yt * 63u + lane < P.ny;
+	active_cells(prev, cur, (uint32_t)((bp >> lane) & 1ull), (uint32_t)((bc >> lane) & 1ull), valid, rowvalid, act);
+	if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull))
+		hand_over_slice(a, slice_slot(b.z - P.zs, b.yt, seg, a.nYT, a.nseg_pad), prev, cur, bp, bc, (hp.z | hc.z) != 0u, act);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -886,7 +944,9 @@ struct mc33hip_ctx {
 	uint32_t epoch;           // extractions since the slice headers were last cleared
 	uint64_t slice_cap;
 	SweepTile *d_tiles;       // block plan of k_sweep for the current range
-	uint64_t tiles_cap, ntiles;
+	TileBoundary *d_bounds;   // pairs of tiles that meet in z (k_boundary)
+	uint4 *edge_bits, *edge_hdr;
+	uint64_t tiles_cap, ntiles, nbounds;
 	uint32_t tiles_zs, tiles_ze, tiles_depth;
 	uint32_t resident_blocks; // k_sweep blocks the device holds at once
 	Counters *d_ctr, *h_ctr;
@@ -984,6 +1044,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
 	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->d_tiles);
 	(void)hipFree(c->slot_base); (void)hipFree(c->slot_part);
+	(void)hipFree(c->d_bounds); (void)hipFree(c->edge_bits); (void)hipFree(c->edge_hdr);
 	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
@@ -1215,15 +1276,27 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 	for (uint64_t k = 0; k < ncol && total < B; k++)
 		if (chunks[frac[k].second] < nzc) { chunks[frac[k].second]++; total++; }
 	if (total > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
-	std::vector<SweepTile> tiles;
-	tiles.reserve(total);
+	struct Planned { SweepTile t; uint64_t col; };
+	std::vector<Planned> planned;
+	planned.reserve(total);
 	for (uint64_t i = 0; i < ncol; i++)
 		for (uint32_t k = 0; k < chunks[i]; k++) {
 			const uint32_t lo = zs + (uint32_t)((uint64_t)nzc * k / chunks[i]), hi = zs + (uint32_t)((uint64_t)nzc * (k + 1) / chunks[i]);
-			if (hi > lo) tiles.push_back(SweepTile{(uint32_t)(i % nXG), (uint32_t)(i / nXG), lo, hi});
+			if (hi > lo) planned.push_back(Planned{SweepTile{(uint32_t)(i % nXG), (uint32_t)(i / nXG), lo, hi}, i});
 		}
 	// launch order: by depth first, so that blocks running together read neighbouring memory
-	std::stable_sort(tiles.begin(), tiles.end(), [](const SweepTile &x, const SweepTile &y) { return x.z_lo < y.z_lo; });
+	std::stable_sort(planned.begin(), planned.end(), [](const Planned &x, const Planned &y) { return x.t.z_lo < y.t.z_lo; });
+	std::vector<SweepTile> tiles(planned.size());
+	std::vector<TileBoundary> bounds;
+	{
+		std::vector<uint32_t> below(ncol, 0xFFFFFFFFu);  // the tile of the column that ends where the next one begins
+		for (uint32_t b = 0; b < planned.size(); b++) {   // (ascending z_lo: a column's tiles come in order)
+			const SweepTile &t = planned[b].t;
+			tiles[b] = t;
+			if (below[planned[b].col] != 0xFFFFFFFFu) bounds.push_back(TileBoundary{below[planned[b].col], b, t.z_lo, t.yt, t.xg, {0, 0, 0}});
+			below[planned[b].col] = b;
+		}
+	}
 	if (c->tiles_cap < tiles.size()) {
 		(void)hipFree(c->d_tiles);
 		c->d_tiles = nullptr; c->tiles_cap = 0;
@@ -1232,6 +1305,15 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 	}
 	HIP_TRY(hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(SweepTile), hipMemcpyHostToDevice));
 	c->ntiles = tiles.size();
+	(void)hipFree(c->d_bounds); (void)hipFree(c->edge_bits); (void)hipFree(c->edge_hdr);
+	c->d_bounds = nullptr; c->edge_bits = nullptr; c->edge_hdr = nullptr;
+	c->nbounds = bounds.size();
+	HIP_TRY(hipMalloc(&c->edge_bits, tiles.size() * 4 * 2 * 128 * sizeof(uint4)));
+	HIP_TRY(hipMalloc(&c->edge_hdr, tiles.size() * 4 * 2 * sizeof(uint4)));
+	if (c->nbounds) {
+		HIP_TRY(hipMalloc(&c->d_bounds, bounds.size() * sizeof(TileBoundary)));
+		HIP_TRY(hipMemcpy(c->d_bounds, bounds.data(), bounds.size() * sizeof(TileBoundary), hipMemcpyHostToDevice));
+	}
 	c->tiles_zs = zs; c->tiles_ze = ze; c->tiles_depth = depth;
 	if (getenv("MC33_HIP_VERBOSE"))
 		fprintf(stderr, "[mc33hip] sweep plan: %llu tiles (%u resident), %llu columns, depth %.1f\n", (unsigned long long)c->ntiles,
@@ -1280,6 +1362,8 @@ static int enqueue_count(mc33hip_ctx *c) {
 	unsigned long long *part_now = c->slot_part + (c->epoch & 1u) * nchunks, *part_next = c->slot_part + ((c->epoch + 1u) & 1u) * nchunks;
 	a.slot_part = part_now;
 	a.epoch = c->epoch;
+	a.z_end = ze;
+	a.edge_bits = c->edge_bits; a.edge_hdr = c->edge_hdr;
 	a.trace = nullptr;
 	if (getenv("MC33_HIP_TRACE_FILE")) {
 		(void)hipFree(c->trace);
@@ -1295,6 +1379,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	hipLaunchKernelGGL(k_sweep, dim3((uint32_t)blocks), dim3(256), 0, st, a);
 	HIP_TRY(hipGetLastError());
 	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[1], st));
+	if (c->nbounds && !(a.debug & 2u)) hipLaunchKernelGGL(k_boundary, dim3((uint32_t)c->nbounds), dim3(256), 0, st, a, c->d_bounds);
 	CellsArgs ca;
 	ca.P = P; ca.fast = c->d_fast;
 	ca.ze = ze; ca.nYT = a.nYT; ca.nseg_pad = a.nseg_pad;
