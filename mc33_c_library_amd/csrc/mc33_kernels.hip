@@ -100,14 +100,18 @@ struct SweepArgs {
 	const SweepTile *tiles;  // [block]
 	uint32_t nYT, nseg_pad;  // y tiles, row segments rounded up to whole groups of 4
 	SliceHeader *slice_hdr;  // [slice_slot]
-	uint4 *slice_bits;       // [slot][k][lane]: {prev[k].lo, prev[k].hi, cur[k].lo, cur[k].hi}
+	uint4 *slice_bits;       // [slice_slot of the PLANE][half][lane]: {word 2*half lo, hi, word 2*half+1 lo, hi} of the plane's bit
+	                         // rows.  A plane is written once, by the first slice with cut cells that touches it: writes are
+	                         // what the sweep pays for (100 MB of them cost as much as 600 MB of reads), and consecutive slices
+	                         // share a plane
 	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz)
 	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: rows << 32 | cells of the slices of that chunk
 	uint32_t epoch;          // number of this extraction (stamped into the slice headers)
 	uint32_t z_end;          // end of the classified range: tiles that reach it have no tile above
 	uint4 *edge_bits;        // [(tile * 4 + wave) * 2 + (0 bottom | 1 top)][2][lane]: bit rows of the tile's first / last plane
 	uint4 *edge_hdr;         // ... their halo-column bits and "a sample equals the isovalue" flag
-	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only): 2 = stream only - no slice is handed on, every count is 0
+	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only; every count is 0): 2 = stream only, 16 = stream + the
+	                         // cut-cell test of every slice but no slice is handed on
 };
 
 
@@ -171,15 +175,20 @@ __device__ __forceinline__ void valid_masks(uint32_t xbase, uint32_t nx, uint64_
 // A slice with cut cells is handed to k_cells: its bit rows (4 KiB), the halo-column bits, flags and counts; the
 // counts also go into the partial sum of the slot's chunk (k_slots).  prev / cur: bit rows of planes z / z+1, lane =
 // sample row; bp / bc: ballots of the halo-column bits.  Wave-uniform call.
-__device__ __forceinline__ void hand_over_slice(const SweepArgs &a, uint64_t slot, const uint64_t (&prev)[4], const uint64_t (&cur)[4],
-                                                uint64_t bp, uint64_t bc, bool has_iso, const uint64_t (&act)[4]) {
+__device__ __forceinline__ void store_plane_bits(const SweepArgs &a, uint64_t plane_slot, const uint64_t (&w)[4]) {
+	uint4 *bits = a.slice_bits + plane_slot * 128u + (threadIdx.x & 63u);
+	bits[0] = uint4{(uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32)};
+	bits[64] = uint4{(uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32)};
+}
+
+// (slot: of the slice; slot_up: of the slice above = the slot of the upper plane; write_prev / write_cur: the
+// plane has not been written by this wave yet)
+__device__ __forceinline__ void hand_over_slice(const SweepArgs &a, uint64_t slot, uint64_t slot_up, const uint64_t (&prev)[4],
+                                                const uint64_t (&cur)[4], bool write_prev, bool write_cur, uint64_t bp, uint64_t bc,
+                                                bool has_iso, const uint64_t (&act)[4]) {
 	const uint32_t lane = threadIdx.x & 63u;
-	uint4 *bits = a.slice_bits + slot * 256u + lane;
-	if (!(a.debug & 64u)) {
-#pragma unroll
-	for (int k = 0; k < 4; k++)
-		bits[64 * k] = uint4{(uint32_t)prev[k], (uint32_t)(prev[k] >> 32), (uint32_t)cur[k], (uint32_t)(cur[k] >> 32)};
-	}
+	if (write_prev) store_plane_bits(a, slot, prev);
+	if (write_cur) store_plane_bits(a, slot_up, cur);
 	// cut cells and non-empty rows of the slice: the record ranges are prefix sums of these (k_slots)
 	uint32_t ncell = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
 	const uint32_t nrow = (uint32_t)__popcll(__ballot(ncell != 0));
@@ -192,7 +201,7 @@ __device__ __forceinline__ void hand_over_slice(const SweepArgs &a, uint64_t slo
 		h.curh_lo = (uint32_t)bc; h.curh_hi = (uint32_t)(bc >> 32);
 		h.cells = ncell; h.rows = nrow; h.pad_ = 0;
 		a.slice_hdr[slot] = h;
-		if (!(a.debug & 32u)) atomicAdd(a.slot_part + slot / SLOT_CHUNK, (unsigned long long)nrow << 32 | ncell);
+		atomicAdd(a.slot_part + slot / SLOT_CHUNK, (unsigned long long)nrow << 32 | ncell);
 	}
 }
 
@@ -247,6 +256,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	uint32_t c_lo[4] = {0, 0, 0, 0}, c_hi[4] = {0, 0, 0, 0};
 	uint32_t cur_h = 0, prev_h = 0;
 	bool cur_z = false, prev_z = false;
+	bool cur_written = false, prev_written = false;  // the plane's bit rows are already in slice_bits
 	real_t zmin = 1;  // min |iso - F| over the lane's samples of the plane being assembled
 
 	// The tile is consumed as a linear stream of batches of 4 sample rows (16 coalesced 256-byte loads per
@@ -332,9 +342,11 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 			if (p > pl0) {
 				uint64_t act[4];
 				active_cells(prev, cur, prev_h, cur_h, valid, rowvalid, act);
-				if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(a.debug & 16u))  // wave-uniform: hand the slice to k_cells
-					hand_over_slice(a, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), prev, cur, __ballot(prev_h != 0), __ballot(cur_h != 0),
-					                prev_z || cur_z, act);
+				if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(a.debug & 16u)) {  // wave-uniform: hand the slice to k_cells
+					hand_over_slice(a, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), prev, cur,
+					                !prev_written, true, __ballot(prev_h != 0), __ballot(cur_h != 0), prev_z || cur_z, act);
+					cur_written = true;
+				}
 			}
 			if (p == z_hi && has_above) leave_edge(1);
 		}
@@ -342,6 +354,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		for (int k = 0; k < 4; k++) prev[k] = cur[k];
 		prev_h = cur_h;
 		prev_z = cur_z;
+		prev_written = cur_written;
+		cur_written = false;
 	};
 
 	real_t dA[16], dB[16], hA = 0, hB = 0;
@@ -389,7 +403,9 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 	const bool rowvalid = lane < 63u && b.yt * 63u + lane < P.ny;
 	active_cells(prev, cur, (uint32_t)((bp >> lane) & 1ull), (uint32_t)((bc >> lane) & 1ull), valid, rowvalid, act);
 	if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull))
-		hand_over_slice(a, slice_slot(b.z - P.zs, b.yt, seg, a.nYT, a.nseg_pad), prev, cur, bp, bc, (hp.z | hc.z) != 0u, act);
+		// (the two tiles may have written these planes for slices of their own: same bytes again)
+		hand_over_slice(a, slice_slot(b.z - P.zs, b.yt, seg, a.nYT, a.nseg_pad), slice_slot(b.z + 1u - P.zs, b.yt, seg, a.nYT, a.nseg_pad), prev, cur,
+		                true, true, bp, bc, (hp.z | hc.z) != 0u, act);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -523,9 +539,10 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		// without cut cells are whatever an earlier call left there and are not looked at
 		h = a.slice_hdr[slot];
 		base = a.slot_base[slot];
-		const uint4 *bits = a.slice_bits + slot * 256u + lane;
-#pragma unroll
-		for (int k = 0; k < 4; k++) q[k] = bits[64 * k];
+		// bit rows of the two planes of the slice (the upper plane's record sits in the slot of the slice above)
+		const uint4 *lower = a.slice_bits + slot * 128u + lane;
+		const uint4 *upper = a.slice_bits + slice_slot(z + 1u - P.zs, yt, seg, a.nYT, a.nseg_pad) * 128u + lane;
+		q[0] = lower[0]; q[1] = lower[64]; q[2] = upper[0]; q[3] = upper[64];
 	}
 	__syncthreads();  // s_fast
 	const bool live = in_grid && slice_valid(h.flags, a.epoch);  // wave-uniform
@@ -536,8 +553,8 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		return;
 	}
 	uint64_t prev[4], cur[4], act[4];
-#pragma unroll
-	for (int k = 0; k < 4; k++) { prev[k] = u64(q[k].x, q[k].y); cur[k] = u64(q[k].z, q[k].w); }
+	prev[0] = u64(q[0].x, q[0].y); prev[1] = u64(q[0].z, q[0].w); prev[2] = u64(q[1].x, q[1].y); prev[3] = u64(q[1].z, q[1].w);
+	cur[0] = u64(q[2].x, q[2].y); cur[1] = u64(q[2].z, q[2].w); cur[2] = u64(q[3].x, q[3].y); cur[3] = u64(q[3].z, q[3].w);
 	const uint64_t bp = u64(h.prevh_lo, h.prevh_hi), bc = u64(h.curh_lo, h.curh_hi);  // halo-column bits of the rows
 	{
 		uint64_t valid[4];
@@ -1341,7 +1358,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 		(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits);
 		c->slice_hdr = nullptr; c->slice_bits = nullptr; c->slice_cap = 0;
 		HIP_TRY(hipMalloc(&c->slice_hdr, nslots * sizeof(SliceHeader)));
-		HIP_TRY(hipMalloc(&c->slice_bits, nslots * 4096));
+		HIP_TRY(hipMalloc(&c->slice_bits, (nslots + 4ull * a.nYT * a.nseg_pad) * 2048));  // planes: one more than slices
 		(void)hipFree(c->slot_base); (void)hipFree(c->slot_part);
 		c->slot_base = nullptr; c->slot_part = nullptr;
 		HIP_TRY(hipMalloc(&c->slot_base, nslots * sizeof(uint2)));
