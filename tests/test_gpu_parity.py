@@ -309,3 +309,18 @@ def test_batched_isovalues_equal_single_calls(products, reflibs):
     L.free_MC33(M)
     L.free_memory_grd(G)
     del keep
+
+
+def test_denormal_and_extreme_samples(products, reflibs):
+    """Samples a denormal away from the isovalue must still count as different from it (no flush to zero in the
+    sign classification, the tests or the interpolation), huge magnitudes must not break anything."""
+    rng = np.random.RandomState(77)
+    vals = np.array([1e-45, -1e-45, 3e-42, -3e-42, 1e-39, -1e-39, 1e-30, -1e-30, 0.0, 1.0, -1.0, 3e38, -3e38], np.float32)
+    data = vals[rng.randint(0, len(vals), (20, 22, 70))]
+    got = check(products, reflibs, "f32", data, 0.0, label="denormals iso 0")
+    assert got.nV > 1000
+    check(products, reflibs, "f32", data + np.float32(1.0), 1.0, (0.5, 0.5, 0.5), (0.25, 0.25, 0.25), label="near-1 values iso 1")
+    d64 = vals.astype(np.float64)[rng.randint(0, len(vals), (12, 14, 40))] * 1e-280
+    g, r = products["f64"].isosurface(d64, 0.0), reflibs["f64"].isosurface(d64, 0.0)
+    assert_surface_parity(g, r, 40.0, "f64 tiny values")
+    assert g.nV > 500
