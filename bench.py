@@ -225,10 +225,22 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         gather_alone_ms = e0.elapsed_time(e1)
+    extract_only_ms = None
+    if world > 1:  # outside the timed region as well: the extraction alone (count + exchange of counts + emit), no surface gather
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            c = grid.count(iso, rng())
+            mine = torch.tensor([c.nV, c.nT], dtype=torch.int64, device=dev)
+            all_gather_flat(counts_all, mine)
+            grid.emit_into(V[0], N[0], T[0], int(counts_all.view(world, 2)[:rank, 0].sum().item()) if rank else 0)
+        torch.cuda.synchronize()
+        extract_only_ms = (time.perf_counter() - t1) / max(3, args.steps // 2) * 1e3
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt, extract_only_ms], dtype=torch.float64, device=dev)
         all_reduce(tmax, dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, extract_only_ms = (float(x) for x in tmax.tolist())
         tot = torch.tensor([cells_rank, last.nV, last.nT], dtype=torch.int64, device=dev)
         all_reduce(tot)
         cells_all, nV_all, nT_all = (int(x) for x in tot.tolist())
@@ -284,6 +296,10 @@ def main():
         if world > 1:
             res["gather_ms"] = gather_alone_ms
             res["gather_overlapped_with_next_extraction"] = bool(overlap)
+            # informational: the step is bound by the all-gather of the surfaces (every rank receives the V, N, T of
+            # all others each step); the extraction itself scales with the slabs
+            res["extract_only_ms_per_step"] = extract_only_ms
+            res["value_without_surface_gather"] = cells_all / (extract_only_ms * 1e-3) / 1e6
         if not args.no_cpu_baseline and world == 1:
             m = min(args.cpu_sample, n)
             sub = field[:m, :m, :m].contiguous().cpu().numpy()
