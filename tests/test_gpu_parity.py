@@ -324,3 +324,29 @@ def test_denormal_and_extreme_samples(products, reflibs):
     g, r = products["f64"].isosurface(d64, 0.0), reflibs["f64"].isosurface(d64, 0.0)
     assert_surface_parity(g, r, 40.0, "f64 tiny values")
     assert g.nV > 500
+
+
+def test_random_shapes_fuzz(products, reflibs):
+    """Forty random small grids (all kinds of extents, including single-cell axes, tall and wide ones), plain and
+    quantised noise so that every table group, the slow path and the degenerate rules are hit on tile / slab / row
+    segment borders: bit-identical to the reference."""
+    rng = np.random.RandomState(2024)
+    for case in range(40):
+        kind = case % 4
+        if kind == 0:
+            shape = tuple(int(x) for x in rng.randint(2, 40, 3))
+        elif kind == 1:
+            shape = (int(rng.randint(2, 6)), int(rng.randint(2, 6)), int(rng.randint(250, 600)))  # long rows: several segments
+        elif kind == 2:
+            shape = (int(rng.randint(60, 200)), int(rng.randint(2, 5)), int(rng.randint(2, 5)))    # tall: many z tiles
+        else:
+            shape = (int(rng.randint(2, 5)), int(rng.randint(60, 140)), int(rng.randint(2, 9)))    # several y tiles
+        seed = int(rng.randint(1, 1000))
+        if case % 2:
+            data, iso = fx.noise_quant(0, seed, shape=shape), float(rng.randint(-1, 2))
+        else:
+            data, iso = fx.noise_f32(0, seed, shape=shape), 0.0
+        got = products["f32"].isosurface(data, iso)
+        ref = reflibs["f32"].isosurface(data, iso)
+        ev, en, vb, nb = assert_surface_parity(got, ref, float(max(shape)), "fuzz %d %s" % (case, shape))
+        assert vb and nb, (case, shape)
