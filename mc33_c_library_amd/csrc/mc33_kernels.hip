@@ -76,7 +76,7 @@ struct SliceHeader {
 	uint32_t cells, rows;  // cut cells of the slice / rows that hold some: what k_slots turns into record ranges
 	uint32_t pad_;
 };
-constexpr uint32_t SLOT_CHUNK = 4096;  // slice slots per partial sum (one k_slots block)
+constexpr uint32_t SLOT_CHUNK = 512;   // slice slots per partial sum (one k_slots block)
 constexpr uint32_t SLICE_VALID = 1u, SLICE_HAS_ISO = 2u;
 // The upper 30 bits of `flags` carry the number of the extraction that wrote the record (epoch >= 1): records
 // of earlier calls are simply not valid any more, and the 2 MB of headers need no clearing between calls.
