@@ -1,20 +1,29 @@
 // mc33_kernels.hip -- HIP kernels (gfx950 / CDNA4, wave64) and the device-level C ABI (include/mc33_hip.h)
 // of the MI355X Marching Cubes 33 extractor.  One shared object per grid sample type, like the
 // reference's one-type-per-compile model (reference include/marching_cubes_33.h:57-88):
-//     default            -> float samples          (libMC33_f32.so)
+//     default            -> float samples           (libMC33_f32.so)
 //     -DMC33_GRD_F64     -> double samples AND double arithmetic / vertices (libMC33_f64.so)
-//     -DMC33_GRD_U16     -> unsigned short samples  (libMC33_u16.so)
+//     -DMC33_GRD_U8 / _U16 / _U32 -> unsigned char / short / int samples (libMC33_u8 / _u16 / _u32.so)
 //
-// Passes ("MC:" = reference source/marching_cubes_33.c):
-//   k_sweep  - streams the volume once (MC:1832-1868): sign bit per sample by wave ballot, the bit
-//              rows of a 64-row x 256-sample tile are parked one row per LANE, so that the all-equal
-//              test of every cell of a tile slice is a handful of 64-bit logic ops; only cells cut
-//              by the surface are classified (MC:683-779) and planned; per row segment it leaves
-//              (#new vertices, #triangles) and one 16-byte work record per active cell.
-//   k_scan_* - exclusive prefix sums over the row segments in the reference's sweep order: this IS the
-//              reference's vertex/triangle numbering.
-//   k_emit   - one thread per active cell: interpolated vertices + normals (MC:810-1230, 485-585),
-//              vertex ids of shared edges through the owner cell's record, triangles (MC:1235-1250).
+// Passes of one extraction, in launch order ("MC:" = reference source/marching_cubes_33.c):
+//   k_sweep       - streams the volume once (MC:1832-1868) and does nothing else that costs bandwidth: sign bit
+//                   per sample by wave ballot, the bit rows of a 64-row x 256-sample tile slice parked one row
+//                   per LANE, so that "is any cell of this slice cut" is a handful of 64-bit logic ops.  For
+//                   each slice that is cut it leaves the two 2 KiB bit planes (each plane once), a 32-byte
+//                   header (active cells, active rows, halo bits) and a partial sum for k_slots.
+//   k_boundary    - the slice between two z-tiles of k_sweep, from the edge planes both left behind.
+//   k_slots       - exclusive sums of (cells, rows) over the slice slots in sweep order.
+//   k_cells       - one wave per cut slice, 64 active cells per step: case index from the bit planes, fast
+//                   cells (interior, simple case, no sample == iso) planned from a 256-entry table, the
+//                   others queued for k_slow_plan; one 16-byte work record per active cell, contiguous in
+//                   the reference's visiting order, plus (#new vertices, #triangles) per row segment.
+//   k_slow_plan   - full MC33 classification with the interior tests (MC:683-779) of the queued cells.
+//   k_seg_fix     - recount of the row segments a slow cell changed.
+//   k_scan_*      - exclusive prefix sums over the row segments in the reference's sweep order: this IS the
+//                   reference's vertex/triangle numbering.
+//   k_emit_*      - one thread per active cell: interpolated vertices + normals (MC:810-1230, 485-585),
+//                   vertex ids of shared edges through the owner cell's record, triangles (MC:1235-1250);
+//                   fast vertices, fast triangles and slow cells run concurrently on three streams.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
