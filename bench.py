@@ -90,11 +90,14 @@ def main():
     # MC33_BENCH_REHEARSAL=1: rehearse the N>1 orchestration on a ONE-GPU box - all ranks share cuda:0, the
     # collectives go through gloo on host copies (NCCL refuses two ranks on one device).  Never used by the driver.
     rehearsal = os.environ.get("MC33_BENCH_REHEARSAL", "0") == "1"
+    # MC33_BENCH_FORCE_DIST=1: run the N>1 code path (RCCL communicators, count exchange, overlapped gathers) with
+    # whatever world size was launched, 1 included - a one-GPU check of every collective call the driver's N>1 runs make.
+    multi = world > 1 or os.environ.get("MC33_BENCH_FORCE_DIST", "0") == "1"
     if rehearsal:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -136,9 +139,9 @@ def main():
     # capacity from one count pass (all ranks use the same capacity so the gather is a plain all-gather)
     cnt = grid.count(iso, rng())
     capV, capT = int(cnt.nV * 1.05) + 1024, int(cnt.nT * 1.05) + 1024
-    overlap = world > 1 and not rehearsal and os.environ.get("MC33_BENCH_NO_OVERLAP", "0") != "1"
+    overlap = multi and not rehearsal and os.environ.get("MC33_BENCH_NO_OVERLAP", "0") != "1"
     nbuf = 2 if overlap else 1
-    if world > 1:
+    if multi:
         caps = torch.tensor([capV, capT], dtype=torch.int64, device=dev)
         all_reduce(caps, dist.ReduceOp.MAX)
         capV, capT = (int(x) for x in caps.tolist())
@@ -157,7 +160,7 @@ def main():
     step_no = [0]
 
     def step(record):
-        if world == 1:
+        if not multi:
             c, ok = grid.extract_into(iso, V[0], N[0], T[0], rng())
             assert ok
             if record:
@@ -202,7 +205,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     drain()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -211,11 +214,11 @@ def main():
         last = step(True)
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
     gather_alone_ms = None
-    if world > 1:  # outside the timed region: what one un-overlapped surface all-gather costs
+    if multi:  # outside the timed region: what one un-overlapped surface all-gather costs
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
@@ -226,7 +229,7 @@ def main():
         torch.cuda.synchronize()
         gather_alone_ms = e0.elapsed_time(e1)
     extract_only_ms = None
-    if world > 1:  # outside the timed region as well: the extraction alone (count + exchange of counts + emit), no surface gather
+    if multi:  # outside the timed region as well: the extraction alone (count + exchange of counts + emit), no surface gather
         torch.cuda.synchronize()
         dist.barrier()
         t1 = time.perf_counter()
@@ -237,7 +240,7 @@ def main():
             grid.emit_into(V[0], N[0], T[0], int(counts_all.view(world, 2)[:rank, 0].sum().item()) if rank else 0)
         torch.cuda.synchronize()
         extract_only_ms = (time.perf_counter() - t1) / max(3, args.steps // 2) * 1e3
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt, extract_only_ms], dtype=torch.float64, device=dev)
         all_reduce(tmax, dist.ReduceOp.MAX)
         dt, extract_only_ms = (float(x) for x in tmax.tolist())
@@ -247,7 +250,7 @@ def main():
     else:
         cells_all, nV_all, nT_all = cells_rank, last.nV, last.nT
 
-    if world > 1 and os.environ.get("MC33_BENCH_VERIFY", "0") == "1":
+    if multi and os.environ.get("MC33_BENCH_VERIFY", "0") == "1":
         # concatenated gathered surface == whole-volume extraction by one context (small n only)
         gV, gT = gV[(step_no[0] - 1) % nbuf], gT[(step_no[0] - 1) % nbuf]
         host_counts = counts_all.view(world, 2).cpu()
@@ -263,7 +266,7 @@ def main():
         ms_step = dt / args.steps * 1e3
         avg = lambda a: (sum(a) / len(a)) if a else 0.0
         sw = avg(sweep_ms)
-        grid_bytes = (p_hi - p_lo + 1) * n * n * 4 if world > 1 else n * n * n * 4
+        grid_bytes = (p_hi - p_lo + 1) * n * n * 4 if multi else n * n * n * 4
         grid_bytes_alg = n * n * (z_end - z_begin + 1) * 4  # every sample of the rank's cells read once
         out_bytes = last.nV * 28 + last.nT * 12               # V, N, colour + T written once
         roof = {"bound": "hbm", "kernel": "k_sweep", "achieved": grid_bytes_alg / (sw * 1e-3) / 1e9 if sw else None,
@@ -279,7 +282,7 @@ def main():
                                "frac": ((grid_bytes_alg + out_bytes) / ((sw + avg(scan_ms) + avg(emit_ms)) * 1e-3) / 1e9 / PEAK_HBM_GBS)
                                if sw else None}}
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(pmc) and world == 1 and n == 1024:  # the counters were collected on this workload
+        if os.path.exists(pmc) and not multi and n == 1024:  # the counters were collected on this workload
             try:
                 roof["traffic"] = json.load(open(pmc)).get("k_sweep_bytes_per_launch")
             except Exception:
@@ -290,22 +293,22 @@ def main():
                "config": {"workload": "%dx%dx%d-point float grid cos x+cos y+cos z on h=8/%d, iso=0.0, calculate_isosurface "
                                       "(sweep+scan+emit), grid and outputs resident in HBM" % (n, n, n * world, n - 1),
                           "cells": cells_all, "vertices": nV_all, "triangles": nT_all,
-                          "parallelism": "z-slab x%d" % world if world > 1 else "single GPU"},
+                          "parallelism": "z-slab x%d" % world if multi else "single GPU"},
                "mtris_per_s": nT_all / (dt / args.steps) / 1e6,
                "roofline": roof}
-        if world > 1:
+        if multi:
             res["gather_ms"] = gather_alone_ms
             res["gather_overlapped_with_next_extraction"] = bool(overlap)
             # informational: the step is bound by the all-gather of the surfaces (every rank receives the V, N, T of
             # all others each step); the extraction itself scales with the slabs
             res["extract_only_ms_per_step"] = extract_only_ms
             res["value_without_surface_gather"] = cells_all / (extract_only_ms * 1e-3) / 1e6
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not multi:
             m = min(args.cpu_sample, n)
             sub = field[:m, :m, :m].contiguous().cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(sub, (lo, lo, lo), (h, h, h), iso)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
