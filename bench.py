@@ -298,6 +298,13 @@ def main():
                "roofline": roof}
         if multi:
             res["gather_ms"] = gather_alone_ms
+            # what the all-gather moves INTO each GPU per step (the padded V, N, T of the other ranks), against the
+            # xGMI links it arrives on: one link per peer, ~153 GB/s per link both ways = ~76.8 GB/s inbound each
+            recv = (world - 1) * (capV * 24 + capT * 12)
+            res["gather"] = {"bytes_received_per_rank": recv,
+                             "achieved_GBps": recv / (gather_alone_ms * 1e-3) / 1e9 if gather_alone_ms and world > 1 else None,
+                             "xgmi_inbound_peak_GBps": 76.8 * (world - 1),
+                             "note": "surface arrays of all ranks on every rank (north_star); the step is bound by this, not by the extraction"}
             res["gather_overlapped_with_next_extraction"] = bool(overlap)
             # informational: the step is bound by the all-gather of the surfaces (every rank receives the V, N, T of
             # all others each step); the extraction itself scales with the slabs
