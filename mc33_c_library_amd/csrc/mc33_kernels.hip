@@ -1380,6 +1380,11 @@ static int enqueue_count(mc33hip_ctx *c) {
 	}
 	a.slice_hdr = c->slice_hdr; a.slice_bits = c->slice_bits;
 	a.debug = env_u32("MC33_HIP_DEBUG", 0);
+	if (a.debug) {  // never silent: with this set the call measures the sweep's read stream and finds no surface
+		static bool warned = false;
+		if (!warned) fprintf(stderr, "[mc33hip] MC33_HIP_DEBUG=%u: timing experiment, every extraction returns an EMPTY surface\n", a.debug);
+		warned = true;
+	}
 	const uint64_t nchunks = (c->slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;  // (capacity: the halves keep their place)
 	if (++c->epoch >= (1u << 30)) {  // stamps wrap: start over with clean headers
 		HIP_TRY(hipMemsetAsync(c->slice_hdr, 0, c->slice_cap * sizeof(SliceHeader), st));
