@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -1004,6 +1005,42 @@ static int use_device(mc33hip_ctx *c) {
 	return 0;
 }
 
+// Side streams are taken from a process-wide pool and handed back, never destroyed: hipStreamDestroy of a stream
+// that events were recorded on leaves the HIP runtime (ROCm 7.x) with a dangling reference - its reference count
+// is decremented after the stream object has been freed, which corrupts whatever the heap put there next
+// (found with tools/uaf_trap.c under tools/soak.py: thousands of create_MC33 / free_MC33 pairs in one process).
+namespace {
+struct StreamPool {
+	std::mutex m;
+	std::vector<std::pair<int, hipStream_t>> idle;
+};
+StreamPool &stream_pool() {
+	static StreamPool *p = new StreamPool;  // never destructed: no ordering problem with the runtime's own teardown
+	return *p;
+}
+hipError_t pool_take(int device, hipStream_t *out) {
+	StreamPool &sp = stream_pool();
+	{
+		std::lock_guard<std::mutex> g(sp.m);
+		for (size_t k = 0; k < sp.idle.size(); k++)
+			if (sp.idle[k].first == device) {
+				*out = sp.idle[k].second;
+				sp.idle[k] = sp.idle.back();
+				sp.idle.pop_back();
+				return hipSuccess;
+			}
+	}
+	return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void pool_give(int device, hipStream_t s) {
+	if (!s) return;
+	(void)hipStreamSynchronize(s);
+	StreamPool &sp = stream_pool();
+	std::lock_guard<std::mutex> g(sp.m);
+	sp.idle.emplace_back(device, s);
+}
+}  // namespace
+
 extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	if (!out || !d) return MC33HIP_EINVAL;
 	*out = nullptr;
@@ -1047,9 +1084,9 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	CREATE_TRY(hipMalloc(&c->d_ctr, sizeof(Counters)));
 	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
 	for (int k = 0; k < 4; k++) CREATE_TRY(hipEventCreate(&c->ev[k]));
-	CREATE_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-	CREATE_TRY(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
-	CREATE_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+	CREATE_TRY(pool_take(c->device, &c->aux));
+	CREATE_TRY(pool_take(c->device, &c->aux2));
+	CREATE_TRY(pool_take(c->device, &c->copy));
 	c->timing_level = getenv("MC33_HIP_TIMING") ? atoi(getenv("MC33_HIP_TIMING")) : 2;
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -1074,13 +1111,14 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+	if (c->aux) (void)hipStreamSynchronize(c->aux);
+	if (c->aux2) (void)hipStreamSynchronize(c->aux2);
+	if (c->copy) (void)hipStreamSynchronize(c->copy);
 	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
-	if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
-	if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
-	if (c->aux2) { (void)hipStreamSynchronize(c->aux2); (void)hipStreamDestroy(c->aux2); }
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+	pool_give(c->device, c->aux); pool_give(c->device, c->aux2); pool_give(c->device, c->copy);  // after the events
 	free(c);
 }
 

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""tools/soak.py -- long random comparison of the product libraries with the reference build (oracle/_ref),
+through the C API both expose.  Developer tool: the test-suite's fuzz case runs 40 grids, this runs for a time
+budget over all five sample types, random extents (single-cell axes, many row segments / y tiles / z tiles),
+smooth and quantised noise (quantised noise makes samples equal to the isovalue common, which is where the
+degenerate-vertex rules and the slow path live), random spacings and origins.
+
+    python tools/soak.py [--seconds 300] [--seed 1] [--max-cells 600000]
+
+Prints one line per 25 cases and a summary; exits non-zero at the first difference (the case is printed so that it
+can be replayed with --seed / --only).
+"""
+import argparse
+import faulthandler
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+
+from mc33_capi import MC33Lib, product_path, ref_path  # noqa: E402
+from parity import assert_surface_parity  # noqa: E402
+
+DTYPES = ("f32", "u16", "u8", "u32", "f64")
+
+
+def random_shape(rng, max_cells):
+    kind = rng.randint(0, 6)
+    if kind == 0:
+        s = rng.randint(2, 70, 3)
+    elif kind == 1:
+        s = (rng.randint(2, 8), rng.randint(2, 8), rng.randint(250, 1200))   # long rows: several segments / x groups
+    elif kind == 2:
+        s = (rng.randint(60, 400), rng.randint(2, 6), rng.randint(2, 6))     # many planes: several z tiles
+    elif kind == 3:
+        s = (rng.randint(2, 6), rng.randint(60, 300), rng.randint(2, 12))    # several y tiles
+    elif kind == 4:
+        s = (rng.randint(2, 40), rng.randint(60, 140), rng.randint(250, 600))
+    else:
+        s = (rng.randint(20, 120), rng.randint(20, 120), rng.randint(20, 120))
+    s = [int(x) for x in s]
+    while s[0] * s[1] * s[2] > max_cells:
+        s[int(np.argmax(s))] = max(2, s[int(np.argmax(s))] // 2)
+    return tuple(s)  # (nz, ny, nx) points
+
+
+def random_field(rng, dtype, shape):
+    """(samples, isovalue): smooth noise, white noise, or a small alphabet with the isovalue in it."""
+    kind = rng.randint(0, 3)
+    if dtype in ("f32", "f64"):
+        np_t = np.float32 if dtype == "f32" else np.float64
+        if kind == 0:
+            return rng.standard_normal(shape).astype(np_t), float(rng.choice([0.0, 0.25, -0.5]))
+        if kind == 1:  # smooth: sum of a few waves
+            z, y, x = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
+            f = sum(np.cos(rng.uniform(0.05, 0.6) * x + rng.uniform(0.05, 0.6) * y + rng.uniform(0.05, 0.6) * z + rng.uniform(0, 6))
+                    for _ in range(3))
+            return f.astype(np_t), float(rng.choice([0.0, 0.5, -1.0]))
+        levels = int(rng.randint(2, 7))
+        return rng.randint(-levels, levels + 1, shape).astype(np_t), float(rng.randint(-1, 2))
+    np_t, top = {"u8": (np.uint8, 255), "u16": (np.uint16, 65535), "u32": (np.uint32, 2 ** 32 - 1)}[dtype]
+    if kind == 0:
+        return rng.randint(0, min(top, 2 ** 31 - 1), shape).astype(np_t), float(min(top, 2 ** 31 - 1) // 2)
+    if kind == 1:
+        z, y, x = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
+        f = np.cos(0.21 * x + rng.uniform(0, 3)) + np.cos(0.17 * y) + np.cos(0.13 * z + rng.uniform(0, 3))
+        amp = min(top, 40000) / 7.0
+        return (f * amp + 3.5 * amp).astype(np_t), float(int(3.5 * amp))
+    levels = int(rng.randint(2, 9))
+    return rng.randint(0, levels, shape).astype(np_t), float(rng.randint(0, levels))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-cells", type=int, default=600000)
+    ap.add_argument("--only", type=int, default=-1, help="run just this case number")
+    ap.add_argument("--start", type=int, default=0, help="first case number")
+    ap.add_argument("--verbose", action="store_true", help="print every case before it runs")
+    args = ap.parse_args()
+    faulthandler.enable()
+    prod = {d: MC33Lib(product_path(d), d) for d in DTYPES}
+    ref = {d: MC33Lib(ref_path(d), d) for d in DTYPES if os.path.exists(ref_path(d))}
+    t0 = time.time()
+    case, exact_v, exact_n, verts = args.start, 0, 0, 0
+    per_type = dict.fromkeys(DTYPES, 0)
+    while time.time() - t0 < args.seconds:
+        rng = np.random.RandomState(args.seed * 1000003 + case)
+        dtype = DTYPES[rng.randint(0, len(DTYPES))]
+        shape = random_shape(rng, args.max_cells)
+        data, iso = random_field(rng, dtype, shape)
+        d = tuple(float(x) for x in rng.choice([0.25, 0.5, 1.0, 1.5, 3.0], 3))
+        r0 = tuple(float(x) for x in rng.choice([0.0, -2.0, 10.5], 3))
+        if args.only >= 0 and case != args.only:
+            case += 1
+            continue
+        if dtype not in ref:
+            case += 1
+            continue
+        label = "case %d seed %d %s %s iso %g r0 %s d %s" % (case, args.seed, dtype, shape, iso, r0, d)
+        if args.verbose:
+            print(label, flush=True)
+        try:
+            got = prod[dtype].isosurface(data, iso, r0, d)
+            want = ref[dtype].isosurface(data, iso, r0, d)
+            extent = max(abs(r0[k]) + d[k] * shape[2 - k] for k in range(3))
+            _, _, vb, nb = assert_surface_parity(got, want, extent, label)
+        except AssertionError as e:
+            print("DIFFERENCE:", label, "\n ", e, flush=True)
+            sys.exit(1)
+        exact_v += bool(vb); exact_n += bool(nb); verts += got.nV
+        per_type[dtype] += 1
+        case += 1
+        if args.only >= 0:
+            break
+        if case % 25 == 0:
+            print("[%6.1f s] %d cases, %d vertices compared, V bit-identical in %d, N in %d" % (time.time() - t0, case, verts, exact_v, exact_n),
+                  flush=True)
+    print("soak done: %d cases %s, %d vertices, no difference; V bit-identical in %d cases, N in %d" %
+          (sum(per_type.values()), per_type, verts, exact_v, exact_n), flush=True)
+
+
+if __name__ == "__main__":
+    main()
