@@ -5,7 +5,7 @@ budget over all five sample types, random extents (single-cell axes, many row se
 smooth and quantised noise (quantised noise makes samples equal to the isovalue common, which is where the
 degenerate-vertex rules and the slow path live), random spacings and origins.
 
-    python tools/soak.py [--seconds 300] [--seed 1] [--max-cells 600000]
+    python tools/soak.py [--seconds 300] [--seed 1] [--max-cells 600000] [--modes single,reuse,slabs]
 
 Prints one line per 25 cases and a summary; exits non-zero at the first difference (the case is printed so that it
 can be replayed with --seed / --only).
@@ -29,8 +29,10 @@ DTYPES = ("f32", "u16", "u8", "u32", "f64")
 
 
 def random_shape(rng, max_cells):
-    kind = rng.randint(0, 6)
-    if kind == 0:
+    kind = rng.randint(0, 7 if max_cells >= 8000000 else 6)
+    if kind == 6:
+        s = (rng.randint(64, 420), rng.randint(64, 420), rng.randint(64, 1100))  # many tiles in every direction
+    elif kind == 0:
         s = rng.randint(2, 70, 3)
     elif kind == 1:
         s = (rng.randint(2, 8), rng.randint(2, 8), rng.randint(250, 1200))   # long rows: several segments / x groups
@@ -74,6 +76,56 @@ def random_field(rng, dtype, shape):
     return rng.randint(0, levels, shape).astype(np_t), float(rng.randint(0, levels))
 
 
+def other_isovalues(rng, dtype, iso, count):
+    """More isovalues for the same grid: near the first one, far outside the data (empty surface), the first again."""
+    if dtype in ("f32", "f64"):
+        pool = [iso + 0.125, iso - 0.25, iso + 1.0, 1e9, iso, iso - 1.0]
+    else:
+        pool = [iso + 1, max(iso - 1, 0), iso + 3, 4e9 if dtype == "u32" else 70000.0, iso, max(iso - 2, 0)]
+    return [float(pool[k]) for k in rng.randint(0, len(pool), count)]
+
+
+def reuse_case(P, R, data, isos, r0, d, extent, label):
+    """One create_MC33 per library, several calculate_isosurface calls on it (the product clears nothing in between)."""
+    Gp, kp = P.make_grid(data, r0, d)
+    Gr, kr = R.make_grid(data, r0, d)
+    Mp, Mr = P.lib.create_MC33(Gp), R.lib.create_MC33(Gr)
+    nv = 0
+    try:
+        for iso in isos:
+            Sp, Sr = P.lib.calculate_isosurface(Mp, P.real(iso)), R.lib.calculate_isosurface(Mr, R.real(iso))
+            assert bool(Sp) and bool(Sr), "%s: NULL surface at iso %g" % (label, iso)
+            got, want = P.copy_surface(Sp), R.copy_surface(Sr)
+            P.lib.free_surface_memory(Sp)
+            R.lib.free_surface_memory(Sr)
+            _, _, vb, nb = assert_surface_parity(got, want, extent, "%s, reused context, iso %g of %s" % (label, iso, isos))
+            assert vb and nb, "%s: not bit-identical at iso %g" % (label, iso)
+            nv += got.nV
+    finally:
+        P.lib.free_MC33(Mp); R.lib.free_MC33(Mr)
+        P.lib.free_memory_grd(Gp); R.lib.free_memory_grd(Gr)
+        del kp, kr
+    return nv
+
+
+def slab_case(rng, R, dtype, data, iso, r0, d, label):
+    """The device ABI with the volume cut into z-slabs (own context per slab, ghost slice, id base): the concatenated
+    arrays must be the reference's."""
+    from test_gpu_device_api import beq, slabbed
+    nz = data.shape[0] - 1
+    if nz < 2:
+        return 0
+    cuts = sorted(set(int(c) for c in rng.randint(1, nz, int(rng.randint(1, 4)))))
+    dev = data.view(np.int16) if dtype == "u16" else data.view(np.int32) if dtype == "u32" else data
+    V, N, T, counts = slabbed(dev, iso, cuts, r0, d)
+    want = R.isosurface(data, iso, r0, d)
+    assert sum(c.nV for c in counts) == want.nV and sum(c.nT for c in counts) == want.nT, "%s: slab counts (cuts %s)" % (label, cuts)
+    if want.nV:
+        assert np.array_equal(T[:want.nT], want.T) and beq(V[:want.nV], want.V) and beq(N[:want.nV], want.N), \
+            "%s: slabs cut at %s differ from the reference" % (label, cuts)
+    return want.nV
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
@@ -82,6 +134,7 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="run just this case number")
     ap.add_argument("--start", type=int, default=0, help="first case number")
     ap.add_argument("--verbose", action="store_true", help="print every case before it runs")
+    ap.add_argument("--modes", default="single", help="comma list of single,reuse,slabs: what a case may do")
     args = ap.parse_args()
     faulthandler.enable()
     prod = {d: MC33Lib(product_path(d), d) for d in DTYPES}
@@ -105,15 +158,26 @@ def main():
         label = "case %d seed %d %s %s iso %g r0 %s d %s" % (case, args.seed, dtype, shape, iso, r0, d)
         if args.verbose:
             print(label, flush=True)
+        modes = args.modes.split(",")
+        mode = modes[rng.randint(0, len(modes))]
+        if mode == "slabs" and dtype == "f64":
+            mode = "single"
+        extent = max(abs(r0[k]) + d[k] * shape[2 - k] for k in range(3))
         try:
-            got = prod[dtype].isosurface(data, iso, r0, d)
-            want = ref[dtype].isosurface(data, iso, r0, d)
-            extent = max(abs(r0[k]) + d[k] * shape[2 - k] for k in range(3))
-            _, _, vb, nb = assert_surface_parity(got, want, extent, label)
+            if mode == "reuse":
+                isos = [iso] + other_isovalues(rng, dtype, iso, int(rng.randint(2, 6)))
+                nv, vb, nb = reuse_case(prod[dtype], ref[dtype], data, isos, r0, d, extent, label), True, True
+            elif mode == "slabs":
+                nv, vb, nb = slab_case(rng, ref[dtype], dtype, data, iso, r0, d, label), True, True
+            else:
+                got = prod[dtype].isosurface(data, iso, r0, d)
+                want = ref[dtype].isosurface(data, iso, r0, d)
+                _, _, vb, nb = assert_surface_parity(got, want, extent, label)
+                nv = got.nV
         except AssertionError as e:
-            print("DIFFERENCE:", label, "\n ", e, flush=True)
+            print("DIFFERENCE:", label, "mode", mode, "\n ", e, flush=True)
             sys.exit(1)
-        exact_v += bool(vb); exact_n += bool(nb); verts += got.nV
+        exact_v += bool(vb); exact_n += bool(nb); verts += nv
         per_type[dtype] += 1
         case += 1
         if args.only >= 0:
