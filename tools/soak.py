@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="run just this case number")
     ap.add_argument("--start", type=int, default=0, help="first case number")
     ap.add_argument("--verbose", action="store_true", help="print every case before it runs")
-    ap.add_argument("--modes", default="single", help="comma list of single,reuse,slabs: what a case may do")
+    ap.add_argument("--modes", default="single", help="comma list of single,reuse,slabs,inclined,sizes: what a case may do")
     args = ap.parse_args()
     faulthandler.enable()
     prod = {d: MC33Lib(product_path(d), d) for d in DTYPES}
@@ -169,6 +169,17 @@ def main():
                 nv, vb, nb = reuse_case(prod[dtype], ref[dtype], data, isos, r0, d, extent, label), True, True
             elif mode == "slabs":
                 nv, vb, nb = slab_case(rng, ref[dtype], dtype, data, iso, r0, d, label), True, True
+            elif mode == "inclined":  # MC33_spnC with a full cell matrix (the _multA_bf form); tolerance, not bits
+                A = np.eye(3) + 0.3 * rng.uniform(-1, 1, (3, 3))
+                mats = (A, np.linalg.inv(A))
+                got = prod[dtype].isosurface(data, iso, r0, d, inclined=mats)
+                want = ref[dtype].isosurface(data, iso, r0, d, inclined=mats)
+                _, _, vb, nb = assert_surface_parity(got, want, 2.0 * extent, label)
+                nv = got.nV
+            elif mode == "sizes":     # size_of_isosurface: counts and byte size
+                a, b = prod[dtype].sizes(data, iso, r0, d), ref[dtype].sizes(data, iso, r0, d)
+                assert a == b, "%s: size_of_isosurface %s vs reference %s" % (label, a, b)
+                nv, vb, nb = a[0], True, True
             else:
                 got = prod[dtype].isosurface(data, iso, r0, d)
                 want = ref[dtype].isosurface(data, iso, r0, d)
