@@ -350,3 +350,21 @@ def test_random_shapes_fuzz(products, reflibs):
         ref = reflibs["f32"].isosurface(data, iso)
         ev, en, vb, nb = assert_surface_parity(got, ref, float(max(shape)), "fuzz %d %s" % (case, shape))
         assert vb and nb, (case, shape)
+
+
+def test_many_contexts_in_one_process(products, reflibs):
+    """Several hundred create_MC33 ... free_MC33 pairs, product and reference taking turns on the heap.  (The
+    context's side streams come from a pool: destroying a stream per context left the HIP runtime writing into freed
+    memory, which showed as a crash in whichever library reused the block - tools/soak.py, tools/uaf_trap.c.)"""
+    rng = np.random.RandomState(99)
+    for case in range(300):
+        dtype = ("f32", "u16", "u8", "u32", "f64")[case % 5]
+        shape = (int(rng.randint(2, 12)), int(rng.randint(2, 120)), int(rng.randint(2, 40)))
+        if dtype in ("f32", "f64"):
+            data, iso = rng.randint(-2, 3, shape).astype(products[dtype].np_dtype), float(rng.randint(-1, 2))
+        else:
+            data, iso = rng.randint(0, 5, shape).astype(products[dtype].np_dtype), float(rng.randint(0, 5))
+        got = products[dtype].isosurface(data, iso)
+        ref = reflibs[dtype].isosurface(data, iso)
+        _, _, vb, nb = assert_surface_parity(got, ref, float(max(shape)), "cycle %d %s %s" % (case, dtype, shape))
+        assert vb and nb
