@@ -104,6 +104,11 @@ int mc33hip_extract(mc33hip_ctx *c, double iso, const mc33hip_range *range, void
 
 int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t);  /* waits for a pending mc33hip_emit */
 
+/* Waits until everything enqueued on the context's stream (mc33hip_emit in particular) has finished.  Needed before
+ * the output buffers are read by anything that is not ordered after that stream - mc33hip_download_concurrent, another
+ * stream, another process. */
+int mc33hip_synchronize(mc33hip_ctx *c);
+
 /* Device-to-host copy helper for callers without a HIP runtime of their own (blocking). */
 int mc33hip_download(mc33hip_ctx *c, void *host_dst, const void *device_src, size_t bytes);
 /* The same on a stream of the context's own that neither waits for nor delays the work queued by the other entry

@@ -217,8 +217,13 @@ static int extract_to_staging(mc33_private *p, struct staging *g, MC33_real iso,
 	/* one pass with the staging buffers of an earlier call; if they are too small the counts come back
 	 * anyway, the buffers grow and only the emit pass is repeated */
 	rc = mc33hip_extract(p->ctx, iso, &r, g->dV, g->dN, g->dT, g->capV, g->capT, cnt);
-	if (rc == MC33HIP_ECAPACITY)
+	if (rc == MC33HIP_ECAPACITY) {
 		rc = ensure_staging(p, g, cnt->nV, cnt->nT) ? MC33HIP_ENOMEM : mc33hip_emit(p->ctx, g->dV, g->dN, g->dT, g->capV, g->capT);
+		/* mc33hip_emit only enqueues: the set must be complete before anybody reads it - the helper thread of
+		 * calculate_isosurfaces copies on a stream of its own, which is not ordered after this one */
+		if (rc == MC33HIP_OK)
+			rc = mc33hip_synchronize(p->ctx);
+	}
 	return rc;
 }
 

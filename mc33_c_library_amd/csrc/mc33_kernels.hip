@@ -1670,6 +1670,14 @@ extern "C" int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t) {
 	return MC33HIP_OK;
 }
 
+extern "C" int mc33hip_synchronize(mc33hip_ctx *c) {
+	if (!c) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return MC33HIP_OK;
+}
+
 extern "C" int mc33hip_download_concurrent(mc33hip_ctx *c, void *dst, const void *src, size_t bytes) {
 	if (!c || (bytes && (!dst || !src))) return MC33HIP_EINVAL;
 	if (!bytes) return MC33HIP_OK;

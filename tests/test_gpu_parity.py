@@ -368,3 +368,33 @@ def test_many_contexts_in_one_process(products, reflibs):
         ref = reflibs[dtype].isosurface(data, iso)
         _, _, vb, nb = assert_surface_parity(got, ref, float(max(shape)), "cycle %d %s %s" % (case, dtype, shape))
         assert vb and nb
+
+
+def test_batched_isovalues_with_fresh_staging_sets(products, reflibs):
+    """calculate_isosurfaces right after create_MC33, small grid: both staging sets are allocated inside the call
+    (count -> grow -> emit), and the helper thread's copy stream is not ordered after the emit - the set has to be
+    complete before it is handed over.  Contexts are created again and again so that the recycled device memory
+    holds other surfaces (found by tools/soak.py --modes batched)."""
+    import ctypes as C
+    rng = np.random.RandomState(5)
+    for dtype, shape, isos in (("u16", (68, 41, 12), [4.0, 4.0, 2.0, 5.0]), ("f32", (30, 50, 70), [0.0, 1.0, 0.0, -1.0, 2.0])):
+        lib, ref = products[dtype], reflibs[dtype]
+        data = rng.randint(0, 8, shape).astype(lib.np_dtype) if dtype == "u16" else rng.randint(-3, 4, shape).astype(lib.np_dtype)
+        want = [ref.isosurface(data, iso) for iso in isos]
+        L = lib.lib
+        L.calculate_isosurfaces.restype = C.c_uint
+        L.calculate_isosurfaces.argtypes = [C.POINTER(lib.MC33), C.POINTER(lib.real), C.c_uint, C.POINTER(C.POINTER(lib.SURFACE))]
+        for rep in range(6):
+            G, keep = lib.make_grid(data)
+            M = L.create_MC33(G)
+            arr = (lib.real * len(isos))(*isos)
+            out = (C.POINTER(lib.SURFACE) * len(isos))()
+            assert L.calculate_isosurfaces(M, arr, len(isos), out) == len(isos)
+            for k in range(len(isos)):
+                got = lib.copy_surface(out[k])
+                L.free_surface_memory(out[k])
+                _, _, vb, nb = assert_surface_parity(got, want[k], float(max(shape)), "%s rep %d surface %d" % (dtype, rep, k))
+                assert vb and nb
+            L.free_MC33(M)
+            L.free_memory_grd(G)
+            del keep

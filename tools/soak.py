@@ -5,7 +5,7 @@ budget over all five sample types, random extents (single-cell axes, many row se
 smooth and quantised noise (quantised noise makes samples equal to the isovalue common, which is where the
 degenerate-vertex rules and the slow path live), random spacings and origins.
 
-    python tools/soak.py [--seconds 300] [--seed 1] [--max-cells 600000] [--modes single,reuse,slabs]
+    python tools/soak.py [--seconds 300] [--seed 1] [--max-cells 600000] [--modes single,reuse,batched,slabs,inclined,sizes]
 
 Prints one line per 25 cases and a summary; exits non-zero at the first difference (the case is printed so that it
 can be replayed with --seed / --only).
@@ -108,6 +108,34 @@ def reuse_case(P, R, data, isos, r0, d, extent, label):
     return nv
 
 
+def batched_case(P, R, data, isos, r0, d, extent, label):
+    """calculate_isosurfaces (extension; a helper thread downloads surface k while k+1 is extracted) against single
+    calls of the reference."""
+    import ctypes as C
+    L = P.lib
+    L.calculate_isosurfaces.restype = C.c_uint
+    L.calculate_isosurfaces.argtypes = [C.POINTER(P.MC33), C.POINTER(P.real), C.c_uint, C.POINTER(C.POINTER(P.SURFACE))]
+    G, keep = P.make_grid(data, r0, d)
+    M = L.create_MC33(G)
+    nv = 0
+    try:
+        arr = (P.real * len(isos))(*isos)
+        out = (C.POINTER(P.SURFACE) * len(isos))()
+        assert L.calculate_isosurfaces(M, arr, len(isos), out) == len(isos), "%s: calculate_isosurfaces failed" % label
+        for k, iso in enumerate(isos):
+            got = P.copy_surface(out[k])
+            L.free_surface_memory(out[k])
+            want = R.isosurface(data, iso, r0, d)
+            _, _, vb, nb = assert_surface_parity(got, want, extent, "%s, batched, iso %g of %s" % (label, iso, isos))
+            assert vb and nb, "%s: batched result not bit-identical at iso %g" % (label, iso)
+            nv += got.nV
+    finally:
+        L.free_MC33(M)
+        L.free_memory_grd(G)
+        del keep
+    return nv
+
+
 def slab_case(rng, R, dtype, data, iso, r0, d, label):
     """The device ABI with the volume cut into z-slabs (own context per slab, ghost slice, id base): the concatenated
     arrays must be the reference's."""
@@ -134,7 +162,7 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="run just this case number")
     ap.add_argument("--start", type=int, default=0, help="first case number")
     ap.add_argument("--verbose", action="store_true", help="print every case before it runs")
-    ap.add_argument("--modes", default="single", help="comma list of single,reuse,slabs,inclined,sizes: what a case may do")
+    ap.add_argument("--modes", default="single", help="comma list of single,reuse,batched,slabs,inclined,sizes: what a case may do")
     args = ap.parse_args()
     faulthandler.enable()
     prod = {d: MC33Lib(product_path(d), d) for d in DTYPES}
@@ -167,6 +195,9 @@ def main():
             if mode == "reuse":
                 isos = [iso] + other_isovalues(rng, dtype, iso, int(rng.randint(2, 6)))
                 nv, vb, nb = reuse_case(prod[dtype], ref[dtype], data, isos, r0, d, extent, label), True, True
+            elif mode == "batched":
+                isos = [iso] + other_isovalues(rng, dtype, iso, int(rng.randint(1, 6)))
+                nv, vb, nb = batched_case(prod[dtype], ref[dtype], data, isos, r0, d, extent, label), True, True
             elif mode == "slabs":
                 nv, vb, nb = slab_case(rng, ref[dtype], dtype, data, iso, r0, d, label), True, True
             elif mode == "inclined":  # MC33_spnC with a full cell matrix (the _multA_bf form); tolerance, not bits
