@@ -162,16 +162,35 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="run just this case number")
     ap.add_argument("--start", type=int, default=0, help="first case number")
     ap.add_argument("--verbose", action="store_true", help="print every case before it runs")
+    ap.add_argument("--threads", type=int, default=1, help="caller threads, each running its own sequence of cases")
     ap.add_argument("--modes", default="single", help="comma list of single,reuse,batched,slabs,inclined,sizes: what a case may do")
     args = ap.parse_args()
     faulthandler.enable()
     prod = {d: MC33Lib(product_path(d), d) for d in DTYPES}
     ref = {d: MC33Lib(ref_path(d), d) for d in DTYPES if os.path.exists(ref_path(d))}
+    if args.threads <= 1:
+        sys.exit(0 if worker(args, prod, ref, 0) else 1)
+    # several caller threads, each with its own contexts (ctypes releases the GIL inside the libraries)
+    import threading
+    ok = [False] * args.threads
+    def run(t):
+        ok[t] = worker(args, prod, ref, t)
+    ts = [threading.Thread(target=run, args=(t,)) for t in range(args.threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    sys.exit(0 if all(ok) else 1)
+
+
+def worker(args, prod, ref, tid):
+    tag = "[t%d] " % tid if args.threads > 1 else ""
+    seed = args.seed + 7919 * tid
     t0 = time.time()
     case, exact_v, exact_n, verts = args.start, 0, 0, 0
     per_type = dict.fromkeys(DTYPES, 0)
     while time.time() - t0 < args.seconds:
-        rng = np.random.RandomState(args.seed * 1000003 + case)
+        rng = np.random.RandomState((seed * 1000003 + case) % (2 ** 32))
         dtype = DTYPES[rng.randint(0, len(DTYPES))]
         shape = random_shape(rng, args.max_cells)
         data, iso = random_field(rng, dtype, shape)
@@ -183,7 +202,7 @@ def main():
         if dtype not in ref:
             case += 1
             continue
-        label = "case %d seed %d %s %s iso %g r0 %s d %s" % (case, args.seed, dtype, shape, iso, r0, d)
+        label = "%scase %d seed %d %s %s iso %g r0 %s d %s" % (tag, case, seed, dtype, shape, iso, r0, d)
         if args.verbose:
             print(label, flush=True)
         modes = args.modes.split(",")
@@ -216,19 +235,20 @@ def main():
                 want = ref[dtype].isosurface(data, iso, r0, d)
                 _, _, vb, nb = assert_surface_parity(got, want, extent, label)
                 nv = got.nV
-        except AssertionError as e:
-            print("DIFFERENCE:", label, "mode", mode, "\n ", e, flush=True)
-            sys.exit(1)
+        except (AssertionError, MemoryError) as e:
+            print("DIFFERENCE:", label, "mode", mode, "\n ", repr(e), flush=True)
+            return False
         exact_v += bool(vb); exact_n += bool(nb); verts += nv
         per_type[dtype] += 1
         case += 1
         if args.only >= 0:
             break
         if case % 25 == 0:
-            print("[%6.1f s] %d cases, %d vertices compared, V bit-identical in %d, N in %d" % (time.time() - t0, case, verts, exact_v, exact_n),
+            print("%s[%6.1f s] %d cases, %d vertices compared, V bit-identical in %d, N in %d" % (tag, time.time() - t0, case, verts, exact_v, exact_n),
                   flush=True)
-    print("soak done: %d cases %s, %d vertices, no difference; V bit-identical in %d cases, N in %d" %
-          (sum(per_type.values()), per_type, verts, exact_v, exact_n), flush=True)
+    print("%ssoak done: %d cases %s, %d vertices, no difference; V bit-identical in %d cases, N in %d" %
+          (tag, sum(per_type.values()), per_type, verts, exact_v, exact_n), flush=True)
+    return True
 
 
 if __name__ == "__main__":
