@@ -206,3 +206,41 @@ def test_read_dat_file(prods, reflibs, tmp_path, dtype):
     assert np.array_equal(got.astype(np.uint16), data[::-1])  # the file starts with the top slice
     free_both(prods[dtype], Gp, reflibs[dtype], Gr)
     assert not P.read_dat_file(str(tmp_path / "missing.dat").encode())
+
+
+def test_truncated_files_never_crash_or_hang(prods, tmp_path):
+    """Every reader on files cut short at many lengths (inside the magic, the header, the matrices, the samples):
+    NULL or a grid, never a fault or an endless loop.  Each call runs in a forked child with an alarm.  (The
+    reference itself hangs in read_dat_file on a header cut short and returns grids with unread header fields from
+    read_grd_binary; the product returns NULL there.)"""
+    import os
+    import signal
+    import fixtures as fx
+    lib = prods["f32"]
+    P = declare(lib)
+    rng = np.random.RandomState(1)
+    data = rng.normal(size=(5, 4, 7)).astype(np.float32)
+    files = []
+    p = str(tmp_path / "b.grb"); write_grd_binary(p, np.float32, (6, 3, 4), (3.0, 1.5, 2.0), (1.0, -2.0, 0.5), (0.5, 0.5, 0.5), data); files.append(("read_grd_binary", p))
+    p = str(tmp_path / "bi.grb"); write_grd_binary(p, np.float32, (6, 3, 4), (3.0, 1.5, 2.0), (0, 0, 0), (0.5, 0.5, 0.5), data, fx.general_matrices()); files.append(("read_grd_binary", p))
+    p = str(tmp_path / "t.grd"); write_grd_text(p, (6, 3, 4), (3.0, 1.5, 2.0), (80.0, 95.0, 70.0), (0, 0, 0), 3, rng.normal(size=7 * 4 * 5)); files.append(("read_grd", p))
+    p = str(tmp_path / "v.dat"); open(p, "wb").write(struct.pack("<3H", 7, 5, 4) + rng.randint(0, 4096, (4, 5, 7)).astype(np.uint16).tobytes()); files.append(("read_dat_file", p))
+    outcomes = set()
+    for fn, path in files:
+        blob = open(path, "rb").read()
+        cuts = sorted(set(list(range(0, min(len(blob), 40), 3)) + list(range(40, len(blob), max(1, len(blob) // 12))) + [len(blob) - 1, len(blob)]))
+        for n in cuts:
+            q = str(tmp_path / "cut")
+            open(q, "wb").write(blob[:n])
+            pid = os.fork()
+            if pid == 0:
+                signal.alarm(5)
+                G = getattr(P, fn)(q.encode())
+                os._exit(10 if G else 11)
+            _, st = os.waitpid(pid, 0)
+            assert not os.WIFSIGNALED(st), "%s on %d of %d bytes: signal %d" % (fn, n, len(blob), os.WTERMSIG(st))
+            assert os.WEXITSTATUS(st) in (10, 11)
+            outcomes.add((fn, os.WEXITSTATUS(st), n == len(blob)))
+            if n == len(blob):
+                assert os.WEXITSTATUS(st) == 10, fn  # the whole file reads
+    assert ("read_grd_binary", 11, False) in outcomes and ("read_dat_file", 11, False) in outcomes

@@ -30,6 +30,14 @@ DTYPES = ("f32", "u16", "u8", "u32", "f64")
 
 def random_shape(rng, max_cells):
     kind = rng.randint(0, 7 if max_cells >= 8000000 else 6)
+    if rng.randint(0, 5) == 0:  # extents on the tiling's edges: 256-sample row segments, 1024-sample groups, 63-row y tiles, 4-slice groups
+        xs = (2, 3, 64, 65, 255, 256, 257, 258, 511, 512, 513, 1023, 1024, 1025, 1026, 1281)
+        ys = (2, 3, 62, 63, 64, 65, 66, 125, 126, 127, 128, 190)
+        zs = (2, 3, 4, 5, 6, 8, 9, 16, 17, 18, 33, 34)
+        for _ in range(50):
+            s = (int(rng.choice(zs)), int(rng.choice(ys)), int(rng.choice(xs)))
+            if s[0] * s[1] * s[2] <= max_cells:
+                return s
     if kind == 6:
         s = (rng.randint(64, 420), rng.randint(64, 420), rng.randint(64, 1100))  # many tiles in every direction
     elif kind == 0:
