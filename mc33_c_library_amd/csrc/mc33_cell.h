@@ -94,6 +94,13 @@ MC33_HD float sample_diff(uint8_t a, uint8_t b) { return (float)((int)a - (int)b
 // unsigned int does not promote: the difference wraps modulo 2^32 before it becomes a float
 MC33_HD float sample_diff(uint32_t a, uint32_t b) { return (float)(uint32_t)(a - b); }
 
+// v = iso - F as the reference's CPU code gets it (MC:1840-1855).  Only a NaN sample needs care: x86 (and ARM) hand
+// back that NaN with ITS sign, so signbf(v) is the sign bit of the sample, while the GPU's subtract negates the second
+// operand first and returns the NaN with the sign flipped.  The reference's sign classification of a NaN sample is
+// therefore "the NaN's own sign bit" and that is what every pass here reproduces (tools/nan_check.py).
+MC33_HD float iso_diff(float iso, float f) { return f != f ? f : iso - f; }
+MC33_HD double iso_diff(double iso, double f) { return f != f ? f : iso - f; }
+
 MC33_HD uint32_t sign_of(float f) { return __builtin_bit_cast(uint32_t, f) >> 31; }  // MC:406-408
 MC33_HD uint32_t sign_of(double f) { return (uint32_t)(__builtin_bit_cast(uint64_t, f) >> 63); }  // MC:402-404
 
@@ -152,7 +159,7 @@ MC33_HD uint32_t load_cell(const GridView<T> &G, real_t iso, uint32_t x, uint32_
 	uint32_t i = 0;
 	for (uint32_t k = 0; k < 8; k++) {
 		const uint32_t c = corner_code(k);
-		const real_t d = iso - (real_t)G.at(x + (c & 1), y + ((c >> 1) & 1), z + (c >> 2));
+		const real_t d = iso_diff(iso, (real_t)G.at(x + (c & 1), y + ((c >> 1) & 1), z + (c >> 2)));
 		v[k] = d;
 		i |= sign_of(d) << (7 - k);
 	}
@@ -350,7 +357,7 @@ MC33_HD void plan_visit(CellPlan &p, const Tables &tab, const Params &P, const G
 			uint32_t pass;
 			if (w & (1u << 13)) {
 				const int fx = (int)((w >> 14) & 3) - 1, fy = (int)((w >> 16) & 3) - 1, fz = (int)((w >> 18) & 3) - 1;
-				pass = sign_of(P.iso - (real_t)G.at((uint32_t)((int)x + fx), (uint32_t)((int)y + fy), (uint32_t)((int)z + fz)));
+				pass = sign_of(iso_diff(P.iso, (real_t)G.at((uint32_t)((int)x + fx), (uint32_t)((int)y + fy), (uint32_t)((int)z + fz))));
 			} else
 				pass = sign_of(v[(int)arg]);
 			if (!pass) continue;

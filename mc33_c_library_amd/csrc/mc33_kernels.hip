@@ -39,6 +39,9 @@
 #ifdef MC33_GRD_F64
 #define MC33_REAL_DOUBLE  // MC33_real is double in the double build (reference marching_cubes_33.h:80-82)
 #endif
+#if !defined(MC33_GRD_U8) && !defined(MC33_GRD_U16) && !defined(MC33_GRD_U32)
+#define MC33_NAN_SAMPLES 1  // float / double grids may hold NaN samples
+#endif
 #include "mc33_cell.h"
 #include "mc33_lut_data.h"
 #include "mc33_rules_data.h"
@@ -312,7 +315,10 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
 				const real_t d = iso - dd[rr * 4 + k];                   // MC:1852-1855
-				const uint64_t bb = __ballot(sign_of(d) != 0);            // MC:1856-1859 (sign bit)
+				uint64_t bb = __ballot(sign_of(d) != 0);                  // MC:1856-1859 (sign bit)
+#ifdef MC33_NAN_SAMPLES
+				bb ^= __ballot(d != d);  // NaN sample: the sign the reference sees is the NaN's own (see iso_diff)
+#endif
 				m[2 * k] = (uint32_t)bb; m[2 * k + 1] = (uint32_t)(bb >> 32);
 				zmin = real_min(zmin, real_abs(d));
 			}
@@ -335,6 +341,9 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		{
 			const real_t dh = iso - halo;
 			cur_h = sign_of(dh);
+#ifdef MC33_NAN_SAMPLES
+			cur_h ^= (uint32_t)(dh != dh);
+#endif
 			if (lane < nrows) zmin = real_min(zmin, real_abs(dh));  // lanes past the tile never loaded a halo sample
 			cur_z = __ballot(zmin == 0) != 0ull;  // some sample of this plane of the tile equals the isovalue
 			zmin = 1;

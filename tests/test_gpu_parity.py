@@ -398,3 +398,32 @@ def test_batched_isovalues_with_fresh_staging_sets(products, reflibs):
             L.free_MC33(M)
             L.free_memory_grd(G)
             del keep
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_nan_and_infinite_samples(products, reflibs, dtype):
+    """NaN samples of both signs and infinities.  The reference classifies a sample by the sign bit of iso - F; for a
+    NaN sample that is the NaN's own sign on the CPU, while the GPU's subtract returns the NaN with the sign flipped
+    (mc33_cell.h iso_diff): topology, the pattern of NaN coordinates and every finite number must still be the
+    reference's."""
+    ft, ut, sb = (np.float32, np.uint32, 0x80000000) if dtype == "f32" else (np.float64, np.uint64, 0x8000000000000000)
+    negnan = np.array(np.nan, ft).view(ut) | ut(sb)
+    for seed, kind in enumerate(("nan+", "nan-", "inf", "all")):
+        rng = np.random.RandomState(seed)
+        data = rng.standard_normal((20, 30, 70)).astype(ft)
+        u = rng.uniform(size=data.shape)
+        if kind in ("nan+", "all"):
+            data[u < 0.01] = np.nan
+        if kind in ("nan-", "all"):
+            data.view(ut)[(u >= 0.01) & (u < 0.02)] = negnan
+        if kind in ("inf", "all"):
+            data[(u >= 0.02) & (u < 0.03)] = np.inf
+            data[(u >= 0.03) & (u < 0.04)] = -np.inf
+        for iso in (0.0, 0.5):
+            got, want = products[dtype].isosurface(data, iso), reflibs[dtype].isosurface(data, iso)
+            label = "%s %s iso %g" % (dtype, kind, iso)
+            assert (got.nV, got.nT) == (want.nV, want.nT), label
+            assert np.array_equal(got.T, want.T), label
+            for a, b, w in ((got.V, want.V, ut), (got.N, want.N, np.uint32)):
+                assert np.array_equal(np.isnan(a), np.isnan(b)), label
+                assert np.array_equal(a[~np.isnan(a)].view(w), b[~np.isnan(b)].view(w)), label
