@@ -85,11 +85,14 @@ def random_field(rng, dtype, shape):
 
 
 def other_isovalues(rng, dtype, iso, count):
-    """More isovalues for the same grid: near the first one, far outside the data (empty surface), the first again."""
+    """More isovalues for the same grid: near the first one, far outside the data (empty surface), the first again,
+    infinite and NaN ones.  Not -0.0: with samples equal to zero the reference then takes the sign of a zero for "this
+    edge was cut" and reads vertex ids that earlier slices left in its layer arrays - its output depends on stale
+    memory there (our oracle, which has no such arrays, differs from it too)."""
     if dtype in ("f32", "f64"):
-        pool = [iso + 0.125, iso - 0.25, iso + 1.0, 1e9, iso, iso - 1.0]
+        pool = [iso + 0.125, iso - 0.25, iso + 1.0, 1e9, iso, iso - 1.0, float("inf"), float("-inf"), float("nan")]
     else:
-        pool = [iso + 1, max(iso - 1, 0), iso + 3, 4e9 if dtype == "u32" else 70000.0, iso, max(iso - 2, 0)]
+        pool = [iso + 1, max(iso - 1, 0), iso + 3, 4e9 if dtype == "u32" else 70000.0, iso, max(iso - 2, 0), iso + 0.5, iso - 0.25, -3.0]
     return [float(pool[k]) for k in rng.randint(0, len(pool), count)]
 
 
