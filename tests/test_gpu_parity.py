@@ -427,3 +427,40 @@ def test_nan_and_infinite_samples(products, reflibs, dtype):
             for a, b, w in ((got.V, want.V, ut), (got.N, want.N, np.uint32)):
                 assert np.array_equal(np.isnan(a), np.isnan(b)), label
                 assert np.array_equal(a[~np.isnan(a)].view(w), b[~np.isnan(b)].view(w)), label
+
+
+def test_surface_blocks_are_recycled_safely(products, reflibs):
+    """free_surface_memory keeps the large arrays for the next surface (mc33_capi.c surface_block): surfaces that
+    grow, shrink and repeat must each be the reference's, with capacities that cover their counts, also when two
+    surfaces are alive at once and with the cache switched off."""
+    import ctypes as C
+    import os
+    lib, ref = products["f32"], reflibs["f32"]
+    data, r0, d = fx.cos_field(320)
+    want = {iso: ref.isosurface(data, iso, r0, d) for iso in (0.0, 0.5, 2.5)}
+    G, keep = lib.make_grid(data, r0, d)
+    M = lib.lib.create_MC33(G)
+    try:
+        for cache in ("1024", "0", "64"):
+            os.environ["MC33_HOST_CACHE_MB"] = cache
+            held = []
+            for step, iso in enumerate((0.0, 0.5, 0.0, 2.5, 0.0, 0.5, 2.5, 0.0)):
+                S = lib.lib.calculate_isosurface(M, C.c_float(iso))
+                assert S
+                got = lib.copy_surface(S)
+                assert got.capv >= got.nV and got.capt >= got.nT
+                _, _, vb, nb = assert_surface_parity(got, want[iso], 8.0, "cache %s step %d iso %g" % (cache, step, iso))
+                assert vb and nb and np.all(got.color == got.color[0])
+                held.append((S, iso))
+                if len(held) == 2:  # the older of two live surfaces is still intact, then goes back
+                    S0, iso0 = held.pop(0)
+                    again = lib.copy_surface(S0)
+                    assert np.array_equal(again.T, want[iso0].T) and np.array_equal(again.V.view(np.uint32), want[iso0].V.view(np.uint32))
+                    lib.lib.free_surface_memory(S0)
+            for S, _ in held:
+                lib.lib.free_surface_memory(S)
+    finally:
+        os.environ.pop("MC33_HOST_CACHE_MB", None)
+        lib.lib.free_MC33(M)
+        lib.lib.free_memory_grd(G)
+        del keep
