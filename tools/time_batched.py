@@ -26,7 +26,7 @@ t0 = time.perf_counter()
 M = L.create_MC33(G)
 print("create_MC33 (upload %.2f GB): %.3f s" % (data.nbytes / 1e9, time.perf_counter() - t0))
 isos = [-1.75 + 0.5 * k for k in range(8)]
-for rep in range(2):
+for rep in range(4):
     t0 = time.perf_counter()
     tris = 0
     for iso in isos:
