@@ -155,6 +155,13 @@ def main():
     N = [torch.empty_like(V[0]) for _ in range(nbuf)]
     T = [torch.empty((capT, 3), dtype=torch.int32, device=dev) for _ in range(nbuf)]
 
+    rows = [capV, capT]  # rows per rank in the gathered arrays of the last step
+
+    def gathered(b):
+        """[world, rows, 3] views on the front of the gather buffers of set b"""
+        return (gV[b].view(-1)[:world * rows[0] * 3].view(world, rows[0], 3), gN[b].view(-1)[:world * rows[0] * 3].view(world, rows[0], 3),
+                gT[b].view(-1)[:world * rows[1] * 3].view(world, rows[1], 3))
+
     sweep_ms, scan_ms, emit_ms, gather_ms = [], [], [], []
     pending = [[] for _ in range(nbuf)]
     step_no = [0]
@@ -182,16 +189,20 @@ def main():
             dist.all_gather_into_tensor(counts_all, mine, group=small_group)
         else:
             all_gather_flat(counts_all, mine)
-        id_base = int(counts_all.view(world, 2)[:rank, 0].sum().item()) if rank else 0
+        host_counts = counts_all.view(world, 2).tolist()
+        id_base = sum(c[0] for c in host_counts[:rank])
         grid.emit_into(V[b], N[b], T[b], id_base)
+        # gather only as many rows as the largest rank has (all ranks know all counts), not the padded capacity
+        rows[0], rows[1] = max(c[0] for c in host_counts), max(c[1] for c in host_counts)
+        gv, gn, gt = gathered(b)
         if overlap:
-            pending[b] = [dist.all_gather_into_tensor(gV[b].view(-1), V[b].view(-1), async_op=True),
-                          dist.all_gather_into_tensor(gN[b].view(-1), N[b].view(-1), async_op=True),
-                          dist.all_gather_into_tensor(gT[b].view(-1), T[b].view(-1), async_op=True)]
+            pending[b] = [dist.all_gather_into_tensor(gv.view(-1), V[b][:rows[0]].reshape(-1), async_op=True),
+                          dist.all_gather_into_tensor(gn.view(-1), N[b][:rows[0]].reshape(-1), async_op=True),
+                          dist.all_gather_into_tensor(gt.view(-1), T[b][:rows[1]].reshape(-1), async_op=True)]
         else:
-            all_gather_flat(gV[b].view(-1), V[b].view(-1))
-            all_gather_flat(gN[b].view(-1), N[b].view(-1))
-            all_gather_flat(gT[b].view(-1), T[b].view(-1))
+            all_gather_flat(gv.view(-1), V[b][:rows[0]].reshape(-1))
+            all_gather_flat(gn.view(-1), N[b][:rows[0]].reshape(-1))
+            all_gather_flat(gt.view(-1), T[b][:rows[1]].reshape(-1))
         if record:
             sweep_ms.append(t.sweep_ms); scan_ms.append(t.scan_ms)
         return c
@@ -222,9 +233,10 @@ def main():
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        all_gather_flat(gV[0].view(-1), V[0].view(-1))
-        all_gather_flat(gN[0].view(-1), N[0].view(-1))
-        all_gather_flat(gT[0].view(-1), T[0].view(-1))
+        gv, gn, gt = gathered(0)
+        all_gather_flat(gv.view(-1), V[0][:rows[0]].reshape(-1))
+        all_gather_flat(gn.view(-1), N[0][:rows[0]].reshape(-1))
+        all_gather_flat(gt.view(-1), T[0][:rows[1]].reshape(-1))
         e1.record()
         torch.cuda.synchronize()
         gather_alone_ms = e0.elapsed_time(e1)
@@ -252,7 +264,7 @@ def main():
 
     if multi and os.environ.get("MC33_BENCH_VERIFY", "0") == "1":
         # concatenated gathered surface == whole-volume extraction by one context (small n only)
-        gV, gT = gV[(step_no[0] - 1) % nbuf], gT[(step_no[0] - 1) % nbuf]
+        gV, _, gT = gathered((step_no[0] - 1) % nbuf)
         host_counts = counts_all.view(world, 2).cpu()
         whole_field = cos_field_slab(n, nz_total + 1, h, lo, dev, z_first=0)
         wg = DeviceGrid(whole_field, r0=(lo, lo, lo), d=(h, h, h))
@@ -300,7 +312,7 @@ def main():
             res["gather_ms"] = gather_alone_ms
             # what the all-gather moves INTO each GPU per step (the padded V, N, T of the other ranks), against the
             # xGMI links it arrives on: one link per peer, ~153 GB/s per link both ways = ~76.8 GB/s inbound each
-            recv = (world - 1) * (capV * 24 + capT * 12)
+            recv = (world - 1) * (rows[0] * 24 + rows[1] * 12)
             res["gather"] = {"bytes_received_per_rank": recv,
                              "achieved_GBps": recv / (gather_alone_ms * 1e-3) / 1e9 if gather_alone_ms and world > 1 else None,
                              "xgmi_inbound_peak_GBps": 76.8 * (world - 1),
