@@ -99,7 +99,7 @@ __host__ __device__ inline bool slice_valid(uint32_t flags, uint32_t epoch) { re
 // The host cuts every (xg, yt) column into chunks of equal WORK (rows x planes), as many in total as the
 // GPU holds blocks at once: waves of one SIMD are served oldest first, so a CU that got one block more
 // than the others ends that much later, and short tiles (the last y tile) get deeper chunks.
-struct SweepTile { uint32_t xg, yt, z_lo, z_hi; };
+struct SweepTile { uint32_t seg, yt, z_lo, z_hi; };  // the piece of the volume ONE WAVE of k_sweep streams: row segment, y tile, planes
 
 // slice record of (cell slice z, y tile, row segment): groups of 4 consecutive slices of one tile column are
 // adjacent (one k_cells block; the emit kernels find neighbouring cells in neighbouring records)
@@ -110,7 +110,8 @@ __host__ __device__ inline uint64_t slice_slot(uint32_t dz, uint32_t yt, uint32_
 struct SweepArgs {
 	GridView<sample_t> G;
 	Params P;
-	const SweepTile *tiles;  // [block]
+	const SweepTile *tiles;  // [wave]: the waves of a block are independent, a block is any four consecutive tiles
+	uint32_t ntiles;
 	uint32_t nYT, nseg_pad;  // y tiles, row segments rounded up to whole groups of 4
 	SliceHeader *slice_hdr;  // [slice_slot]
 	uint4 *slice_bits;       // [slice_slot of the PLANE][half][lane]: {word 2*half lo, hi, word 2*half+1 lo, hi} of the plane's bit
@@ -121,7 +122,7 @@ struct SweepArgs {
 	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: rows << 32 | cells of the slices of that chunk
 	uint32_t epoch;          // number of this extraction (stamped into the slice headers)
 	uint32_t z_end;          // end of the classified range: tiles that reach it have no tile above
-	uint4 *edge_bits;        // [(tile * 4 + wave) * 2 + (0 bottom | 1 top)][2][lane]: bit rows of the tile's first / last plane
+	uint4 *edge_bits;        // [tile * 2 + (0 bottom | 1 top)][2][lane]: bit rows of the tile's first / last plane
 	uint4 *edge_hdr;         // ... their halo-column bits and "a sample equals the isovalue" flag
 	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only; every count is 0): 2 = stream only, 16 = stream + the
 	                         // cut-cell test of every slice but no slice is handed on
@@ -219,8 +220,10 @@ __device__ __forceinline__ void hand_over_slice(const SweepArgs &a, uint64_t slo
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_sweep: one wave per tile column (256 samples in x, 64 sample rows, rz+1 planes), 4 waves per block
-// side by side in x so that a block reads whole 1024-sample (4 KiB) row pieces.
+// k_sweep: one wave per tile (256 samples in x, 64 sample rows, a run of planes).  The waves are independent; the
+// plan puts the tiles of neighbouring row segments next to each other, so that the 4 waves of a block normally read
+// whole 1024-sample (4 KiB) row pieces, and fills blocks with whatever tiles come next where a grid is not a multiple
+// of 1024 samples wide (plan_sweep).
 //
 // Every lane loads 4 samples of a row (x = xbase + 64k + lane: fully coalesced 256-byte requests),
 // v = iso - F, the sign bits of the 64 lanes are collected by ballot into one 64-bit word per k, and the
@@ -237,11 +240,12 @@ __device__ __forceinline__ void hand_over_slice(const SweepArgs &a, uint64_t slo
 // plane instead cost 1/depth of the traffic (6 % at depth 16).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
-	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-	const SweepTile tile = a.tiles[blockIdx.x];
-	const uint32_t yt = tile.yt, seg = tile.xg * 4 + wv;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wtile = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, in an SGPR
+	if (wtile >= a.ntiles) return;
+	const SweepTile tile = a.tiles[wtile];
+	const uint32_t yt = tile.yt, seg = tile.seg;
 	const Params &P = a.P;
-	if (seg >= P.nseg) return;
 	const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
 	const uint32_t nrows = min(64u, P.ny + 1 - y0);  // sample rows of this tile
@@ -349,11 +353,11 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 			zmin = 1;
 		}
 		auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary
-			uint4 *e = a.edge_bits + ((uint64_t)(blockIdx.x * 4u + wv) * 2u + which) * 128u + lane;
+			uint4 *e = a.edge_bits + ((uint64_t)wtile * 2u + which) * 128u + lane;
 			e[0] = uint4{(uint32_t)cur[0], (uint32_t)(cur[0] >> 32), (uint32_t)cur[1], (uint32_t)(cur[1] >> 32)};
 			e[64] = uint4{(uint32_t)cur[2], (uint32_t)(cur[2] >> 32), (uint32_t)cur[3], (uint32_t)(cur[3] >> 32)};
 			const uint64_t bh = __ballot(cur_h != 0);
-			if (lane == 0) a.edge_hdr[(uint64_t)(blockIdx.x * 4u + wv) * 2u + which] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), cur_z ? 1u : 0u, 0u};
+			if (lane == 0) a.edge_hdr[(uint64_t)wtile * 2u + which] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), cur_z ? 1u : 0u, 0u};
 		};
 		if (a.debug & 2u) {
 		} else {
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		if (t + 1 < T) { process(dB, hB, pp, pb); MC33_ADV(pp, pb); }
 	}
 	if (a.trace && lane == 0) {
-		unsigned long long *tr = a.trace + 2ull * (blockIdx.x * 4ull + wv);
+		unsigned long long *tr = a.trace + 2ull * wtile;
 		tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
 	}
 #undef MC33_ADV_ISSUE
@@ -400,17 +404,18 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // k_boundary: the slice between the last plane of a tile and the first plane of the tile above it, from the bit
-// rows the two left behind.  One block per pair of tiles (4 waves = the 4 row segments).
+// rows the two left behind.  One wave per pair of tiles.
 // ---------------------------------------------------------------------------------------------------
-struct TileBoundary { uint32_t below, above, z, yt, xg, pad_[3]; };  // tile (block) indices of k_sweep; slice z
+struct TileBoundary { uint32_t below, above, z, yt, seg, pad_[3]; };  // tile (wave) indices of k_sweep; slice z
 
-__global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileBoundary *bounds) {
-	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-	const TileBoundary b = bounds[blockIdx.x];
+__global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileBoundary *bounds, uint32_t nbounds) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t bi = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	if (bi >= nbounds) return;
+	const TileBoundary b = bounds[bi];
 	const Params &P = a.P;
-	const uint32_t seg = b.xg * 4u + wv;
-	if (seg >= P.nseg) return;
-	const uint64_t rp = (uint64_t)(b.below * 4u + wv) * 2u + 1u, rc = (uint64_t)(b.above * 4u + wv) * 2u;  // top of below, bottom of above
+	const uint32_t seg = b.seg;
+	const uint64_t rp = (uint64_t)b.below * 2u + 1u, rc = (uint64_t)b.above * 2u;  // top of below, bottom of above
 	const uint4 p0 = a.edge_bits[rp * 128u + lane], p1 = a.edge_bits[rp * 128u + 64u + lane];
 	const uint4 c0 = a.edge_bits[rc * 128u + lane], c1 = a.edge_bits[rc * 128u + 64u + lane];
 	const uint4 hp = a.edge_hdr[rp], hc = a.edge_hdr[rc];
@@ -1339,51 +1344,62 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 		const uint32_t want = env_u32("MC33_HIP_SWEEP_BLOCKS_PER_CU", 4);
 		c->resident_blocks = (uint32_t)std::max(1, cus) * (uint32_t)std::max(1, std::min(per_cu, (int)want));
 	}
+	// A tile is what ONE wave streams: a row segment (256 samples in x) x a y tile (64 sample rows) x a run of planes.
+	// Planning is done per group of up to 4 neighbouring segments (they read the same 4 KiB rows and are launched
+	// side by side), but every wave gets a tile of its own, so a group with fewer than 4 segments (grids that are
+	// not a multiple of 1024 samples wide, narrow grids) does not leave the waves of a block idle.
 	const uint32_t nXG = (P.nseg + 3) / 4, nYT = (P.ny + 62) / 63, nzc = ze - zs;
-	const uint64_t ncol = (uint64_t)nXG * nYT;
-	std::vector<double> w(ncol);
-	double W = 0;
+	const uint64_t ncol = (uint64_t)nXG * nYT;  // groups
+	std::vector<double> w(ncol);       // work of one WAVE of the group per slice: its sample rows
+	std::vector<uint32_t> waves(ncol);
+	double W = 0;                      // ... summed over all waves
 	for (uint32_t yt = 0; yt < nYT; yt++)
 		for (uint32_t xg = 0; xg < nXG; xg++) {
-			const uint32_t rows = std::min(64u, P.ny + 1 - yt * 63u), waves = std::min(4u, P.nseg - xg * 4);
-			W += w[(uint64_t)yt * nXG + xg] = (double)rows * waves;
+			const uint64_t i = (uint64_t)yt * nXG + xg;
+			waves[i] = std::min(4u, P.nseg - xg * 4);
+			w[i] = (double)std::min(64u, P.ny + 1 - yt * 63u);
+			W += w[i] * waves[i];
 		}
-	// chunks wanted: W * nzc / (256 * depth), rounded to whole rounds of the resident set
-	const double pref = W * nzc / (256.0 * depth);
-	uint64_t B = c->resident_blocks;
+	// wave tiles wanted: W * nzc / (64 * depth), rounded to whole rounds of the resident set
+	const double pref = W * nzc / (64.0 * depth);
+	uint64_t B = (uint64_t)c->resident_blocks * 4;
 	if (pref >= (double)B) B *= (uint64_t)(pref / (double)B + 0.5);
-	else B = std::max<uint64_t>(1, std::min<uint64_t>(B, (uint64_t)(W * nzc / (256.0 * 4.0))));  // small grid: at least 4 slices deep
-	std::vector<uint32_t> chunks(ncol);
+	else B = std::max<uint64_t>(1, std::min<uint64_t>(B, (uint64_t)(W * nzc / (64.0 * 4.0))));  // small grid: at least 4 slices deep
+	std::vector<uint32_t> chunks(ncol);  // z pieces of the group (each is one tile per wave of the group)
 	std::vector<std::pair<double, uint64_t>> frac(ncol);
 	uint64_t total = 0;
 	for (uint64_t i = 0; i < ncol; i++) {
 		const double share = (double)B * w[i] / W;
 		const uint32_t n = (uint32_t)std::min<double>(std::max(1.0, std::floor(share)), (double)nzc);
-		chunks[i] = n; total += n;
+		chunks[i] = n; total += (uint64_t)n * waves[i];
 		frac[i] = {share - std::floor(share), i};
 	}
 	std::sort(frac.begin(), frac.end(), [](const std::pair<double, uint64_t> &x, const std::pair<double, uint64_t> &y) { return x.first > y.first; });
 	for (uint64_t k = 0; k < ncol && total < B; k++)
-		if (chunks[frac[k].second] < nzc) { chunks[frac[k].second]++; total++; }
+		if (chunks[frac[k].second] < nzc) { chunks[frac[k].second]++; total += waves[frac[k].second]; }
 	if (total > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
-	struct Planned { SweepTile t; uint64_t col; };
+	struct Planned { SweepTile t; uint64_t col; };  // col: the wave's column (yt, seg)
 	std::vector<Planned> planned;
 	planned.reserve(total);
 	for (uint64_t i = 0; i < ncol; i++)
 		for (uint32_t k = 0; k < chunks[i]; k++) {
 			const uint32_t lo = zs + (uint32_t)((uint64_t)nzc * k / chunks[i]), hi = zs + (uint32_t)((uint64_t)nzc * (k + 1) / chunks[i]);
-			if (hi > lo) planned.push_back(Planned{SweepTile{(uint32_t)(i % nXG), (uint32_t)(i / nXG), lo, hi}, i});
+			if (hi <= lo) continue;
+			const uint32_t yt = (uint32_t)(i / nXG), xg = (uint32_t)(i % nXG);
+			for (uint32_t sgm = xg * 4; sgm < xg * 4 + waves[i]; sgm++)
+				planned.push_back(Planned{SweepTile{sgm, yt, lo, hi}, (uint64_t)yt * P.nseg + sgm});
 		}
-	// launch order: by depth first, so that blocks running together read neighbouring memory
+	// launch order: by depth first, so that waves running together read neighbouring memory (the segments of a group
+	// stay next to each other: the sort is stable)
 	std::stable_sort(planned.begin(), planned.end(), [](const Planned &x, const Planned &y) { return x.t.z_lo < y.t.z_lo; });
 	std::vector<SweepTile> tiles(planned.size());
 	std::vector<TileBoundary> bounds;
 	{
-		std::vector<uint32_t> below(ncol, 0xFFFFFFFFu);  // the tile of the column that ends where the next one begins
+		std::vector<uint32_t> below((uint64_t)nYT * P.nseg, 0xFFFFFFFFu);  // the tile of the column that ends where the next one begins
 		for (uint32_t b = 0; b < planned.size(); b++) {   // (ascending z_lo: a column's tiles come in order)
 			const SweepTile &t = planned[b].t;
 			tiles[b] = t;
-			if (below[planned[b].col] != 0xFFFFFFFFu) bounds.push_back(TileBoundary{below[planned[b].col], b, t.z_lo, t.yt, t.xg, {0, 0, 0}});
+			if (below[planned[b].col] != 0xFFFFFFFFu) bounds.push_back(TileBoundary{below[planned[b].col], b, t.z_lo, t.yt, t.seg, {0, 0, 0}});
 			below[planned[b].col] = b;
 		}
 	}
@@ -1398,16 +1414,16 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 	(void)hipFree(c->d_bounds); (void)hipFree(c->edge_bits); (void)hipFree(c->edge_hdr);
 	c->d_bounds = nullptr; c->edge_bits = nullptr; c->edge_hdr = nullptr;
 	c->nbounds = bounds.size();
-	HIP_TRY(hipMalloc(&c->edge_bits, tiles.size() * 4 * 2 * 128 * sizeof(uint4)));
-	HIP_TRY(hipMalloc(&c->edge_hdr, tiles.size() * 4 * 2 * sizeof(uint4)));
+	HIP_TRY(hipMalloc(&c->edge_bits, tiles.size() * 2 * 128 * sizeof(uint4)));
+	HIP_TRY(hipMalloc(&c->edge_hdr, tiles.size() * 2 * sizeof(uint4)));
 	if (c->nbounds) {
 		HIP_TRY(hipMalloc(&c->d_bounds, bounds.size() * sizeof(TileBoundary)));
 		HIP_TRY(hipMemcpy(c->d_bounds, bounds.data(), bounds.size() * sizeof(TileBoundary), hipMemcpyHostToDevice));
 	}
 	c->tiles_zs = zs; c->tiles_ze = ze; c->tiles_depth = depth;
 	if (getenv("MC33_HIP_VERBOSE"))
-		fprintf(stderr, "[mc33hip] sweep plan: %llu tiles (%u resident), %llu columns, depth %.1f\n", (unsigned long long)c->ntiles,
-		        c->resident_blocks, (unsigned long long)ncol, (double)nzc * ncol / (double)c->ntiles);
+		fprintf(stderr, "[mc33hip] sweep plan: %llu wave tiles (%u resident), %llu columns, depth %.1f\n", (unsigned long long)c->ntiles,
+		        c->resident_blocks * 4, (unsigned long long)nYT * P.nseg, (double)nzc * nYT * P.nseg / (double)c->ntiles);
 	return 0;
 }
 
@@ -1423,7 +1439,8 @@ static int enqueue_count(mc33hip_ctx *c) {
 	a.nseg_pad = (P.nseg + 3) / 4 * 4;
 	if (int rc = plan_sweep(c, P.zs, ze)) return rc;
 	a.tiles = c->d_tiles;
-	const uint64_t blocks = c->ntiles;
+	const uint64_t blocks = (c->ntiles + 3) / 4;
+	a.ntiles = (uint32_t)c->ntiles;
 	const uint64_t cell_blocks = (uint64_t)((ze - P.zs + 3) / 4) * a.nYT * a.nseg_pad;
 	if (cell_blocks > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
 	const uint64_t nslots = cell_blocks * 4;
@@ -1474,7 +1491,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	hipLaunchKernelGGL(k_sweep, dim3((uint32_t)blocks), dim3(256), 0, st, a);
 	HIP_TRY(hipGetLastError());
 	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[1], st));
-	if (c->nbounds && !(a.debug & 2u)) hipLaunchKernelGGL(k_boundary, dim3((uint32_t)c->nbounds), dim3(256), 0, st, a, c->d_bounds);
+	if (c->nbounds && !(a.debug & 2u)) hipLaunchKernelGGL(k_boundary, dim3((uint32_t)((c->nbounds + 3) / 4)), dim3(256), 0, st, a, c->d_bounds, (uint32_t)c->nbounds);
 	CellsArgs ca;
 	ca.P = P; ca.fast = c->d_fast;
 	ca.ze = ze; ca.nYT = a.nYT; ca.nseg_pad = a.nseg_pad;
