@@ -112,7 +112,7 @@ struct SweepArgs {
 	Params P;
 	const SweepTile *tiles;  // [wave]: the waves of a block are independent, a block is any four consecutive tiles
 	uint32_t ntiles;
-	uint32_t nYT, nseg_pad;  // y tiles, row segments rounded up to whole groups of 4
+	uint32_t nYT, nseg_pad;  // y tiles, row segments per slot row (= P.nseg)
 	SliceHeader *slice_hdr;  // [slice_slot]
 	uint4 *slice_bits;       // [slice_slot of the PLANE][half][lane]: {word 2*half lo, hi, word 2*half+1 lo, hi} of the plane's bit
 	                         // rows.  A plane is written once, by the first slice with cut cells that touches it: writes are
@@ -1436,7 +1436,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	a.P = P;
 	const uint32_t ze = c->range.z_end;
 	a.nYT = (P.ny + 62) / 63;
-	a.nseg_pad = (P.nseg + 3) / 4 * 4;
+	a.nseg_pad = P.nseg;  // (no padding needed any more: the slots of a slice group are its real row segments)
 	if (int rc = plan_sweep(c, P.zs, ze)) return rc;
 	a.tiles = c->d_tiles;
 	const uint64_t blocks = (c->ntiles + 3) / 4;
