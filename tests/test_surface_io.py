@@ -172,3 +172,33 @@ def test_double_build_files(reflibs, tmp_path):
         assert (s.nV, s.nT, s.iso) == (33, 12, 0.75) and s.V.dtype == np.float64
         assert np.array_equal(s.V, keep[1].astype(np.float64)) and np.array_equal(s.T, keep[0])
         lib.lib.free_surface_memory(Sp)
+
+
+def test_read_bin_on_damaged_files_never_crashes(prod, tmp_path):
+    """read_bin_s on a file cut short at many lengths and on headers announcing absurd sizes: NULL or a surface, never
+    a fault or a hang (each call in a forked child with an alarm)."""
+    import os
+    import signal
+    import struct
+    P = declare(prod)
+    S, keep = make_surface(40, 25, seed=4)
+    path = str(tmp_path / "ok.sup")
+    assert P.write_bin_s(C.byref(S), path.encode()) == 0
+    blob = open(path, "rb").read()
+    variants = [blob[:n] for n in list(range(0, 24)) + list(range(24, len(blob), 37)) + [len(blob) - 1]]
+    for nV, nT in ((0xFFFFFFFF, 1), (1, 0xFFFFFFFF), (0x7FFFFFFF, 0x7FFFFFFF), (0, 0), (0, 5), (41, 25)):
+        variants.append(blob[:8] + struct.pack("<II", nV, nT) + blob[16:])
+    for k, data in enumerate(variants):
+        q = str(tmp_path / "damaged.sup")
+        open(q, "wb").write(data)
+        pid = os.fork()
+        if pid == 0:
+            signal.alarm(10)
+            Sp = P.read_bin_s(q.encode())
+            if Sp:
+                prod.lib.free_surface_memory(Sp)
+            os._exit(10 if Sp else 11)
+        _, st = os.waitpid(pid, 0)
+        assert not os.WIFSIGNALED(st), "variant %d (%d bytes): signal %d" % (k, len(data), os.WTERMSIG(st))
+        assert os.WEXITSTATUS(st) in (10, 11)
+    del keep
