@@ -1364,7 +1364,7 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 	const double pref = W * nzc / (64.0 * depth);
 	uint64_t B = (uint64_t)c->resident_blocks * 4;
 	if (pref >= (double)B) B *= (uint64_t)(pref / (double)B + 0.5);
-	else B = std::max<uint64_t>(1, std::min<uint64_t>(B, (uint64_t)(W * nzc / (64.0 * 4.0))));  // small grid: at least 4 slices deep
+	else B = std::max<uint64_t>(1, std::min<uint64_t>(B, (uint64_t)(W * nzc / (64.0 * std::max(1u, env_u32("MC33_HIP_MIN_DEPTH", 1))))));  // small grid: fill the GPU, tiles down to one plane deep (k_boundary then does the slices)
 	std::vector<uint32_t> chunks(ncol);  // z pieces of the group (each is one tile per wave of the group)
 	std::vector<std::pair<double, uint64_t>> frac(ncol);
 	uint64_t total = 0;
