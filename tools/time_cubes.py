@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from mc33_c_library_amd import api, fields  # noqa: E402
 
 dev = torch.device("cuda:0")
-for n in (32, 64, 128, 256, 384, 512, 640, 768, 1024):
+for n in [int(x) for x in os.environ.get("CUBES", "32,64,128,256,384,512,640,768,1024").split(",")]:
     f, r0, d = fields.cos_field_cube(n, dev)
     g = api.DeviceGrid(f, r0=r0, d=d)
     V, N, T, cnt = g.extract(0.0)
