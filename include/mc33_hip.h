@@ -102,7 +102,9 @@ int mc33hip_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long lon
 int mc33hip_extract(mc33hip_ctx *c, double iso, const mc33hip_range *range, void *dV, void *dN, void *dT,
                     unsigned long long capV, unsigned long long capT, mc33hip_counts *out);
 
-int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t);  /* waits for a pending mc33hip_emit */
+/* hipEvent times of the last extraction; all zero unless the context was created with MC33_HIP_TIMING=1 (whole call)
+ * or 2 (per pass) in the environment - the event records cost about 20 us per call.  Waits for a pending mc33hip_emit. */
+int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t);
 
 /* Waits until everything enqueued on the context's stream (mc33hip_emit in particular) has finished.  Needed before
  * the output buffers are read by anything that is not ordered after that stream - mc33hip_download_concurrent, another

@@ -123,6 +123,7 @@ class DeviceGrid:
         desc = GridDesc(npx, npy, npz, plane0, (nz_total if nz_total is not None else npz - 1),
                         (C.c_double * 3)(*r0), (C.c_double * 3)(*d), sb, tensor.device.index)
         self.desc = desc
+        os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvent timing for timing(); off by default in the library
         self.ctx = C.c_void_p()
         _check(self.lib, self.lib.mc33hip_create(C.byref(self.ctx), C.byref(desc)))
         _check(self.lib, self.lib.mc33hip_adopt_device(self.ctx, C.c_void_p(tensor.data_ptr()), pitch, tensor.stride(0)))

@@ -996,7 +996,7 @@ struct mc33hip_ctx {
 	hipStream_t copy;         // mc33hip_download_concurrent
 	hipEvent_t ev_fork, ev_join, ev_join2;
 	bool emit_pending;        // an emit was enqueued after the last timing read
-	int timing_level;         // MC33_HIP_TIMING: 0 none, 1 whole call, 2 (default) per pass - an event record costs ~12 us of device time
+	int timing_level;         // MC33_HIP_TIMING: 0 none (default), 1 whole call, 2 per pass - the event records cost ~20 us per call
 	bool inclined, triangular;   // non-orthogonal grid (MC33_spnC): _GRD._A / _GRD.A_ as given
 	double grd_A[9], grd_Ai[9];
 	unsigned long long *trace;  // developer tracing (MC33_HIP_TRACE_FILE)
@@ -1101,7 +1101,7 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	CREATE_TRY(pool_take(c->device, &c->aux));
 	CREATE_TRY(pool_take(c->device, &c->aux2));
 	CREATE_TRY(pool_take(c->device, &c->copy));
-	c->timing_level = getenv("MC33_HIP_TIMING") ? atoi(getenv("MC33_HIP_TIMING")) : 2;
+	c->timing_level = getenv("MC33_HIP_TIMING") ? atoi(getenv("MC33_HIP_TIMING")) : 0;
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
