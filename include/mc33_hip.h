@@ -117,6 +117,10 @@ int mc33hip_download(mc33hip_ctx *c, void *host_dst, const void *device_src, siz
  * points: the download of one result can run while the next extraction is computed (calculate_isosurfaces does
  * that from a helper thread).  The source must not be written meanwhile.  Blocking; callable from any thread. */
 int mc33hip_download_concurrent(mc33hip_ctx *c, void *host_dst, const void *device_src, size_t bytes);
+/* Several copies, one wait at the end (a surface is three arrays): concurrent = 0 orders them after the context's
+ * stream like mc33hip_download, != 0 uses the side stream like mc33hip_download_concurrent. */
+int mc33hip_download_many(mc33hip_ctx *c, int n, void *const *host_dst, const void *const *device_src, const size_t *bytes,
+                          int concurrent);
 /* Plain device allocations on the context's device (for language bindings). */
 int mc33hip_device_alloc(mc33hip_ctx *c, void **dptr, size_t bytes);
 int mc33hip_device_free(mc33hip_ctx *c, void *dptr);

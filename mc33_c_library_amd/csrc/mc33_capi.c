@@ -316,17 +316,16 @@ static surface *surface_from_staging(mc33_private *p, const struct staging *g, c
 		memset(S, 0, sizeof(surface));
 		return S;
 	}
-	int (*get)(mc33hip_ctx *, void *, const void *, size_t) = concurrent ? mc33hip_download_concurrent : mc33hip_download;
 	const size_t nV = (size_t)cnt->nV, nT = (size_t)cnt->nT;
 	size_t capV = 0, capN = 0, capT = 0, capC = 0;
 	S->V = (MC33_real(*)[3])surface_block(nV * 3 * sizeof(MC33_real), &capV);
 	S->N = (float(*)[3])surface_block(nV * 3 * sizeof(float), &capN);
 	S->T = (unsigned int(*)[3])surface_block((nT ? nT : 1) * 3 * sizeof(int), &capT);
 	S->color = (int *)surface_block(nV * sizeof(int), &capC);
-	if (!S->V || !S->N || !S->T || !S->color ||
-	    get(p->ctx, S->V, g->dV, nV * 3 * sizeof(MC33_real)) != MC33HIP_OK ||
-	    get(p->ctx, S->N, g->dN, nV * 12) != MC33HIP_OK ||
-	    get(p->ctx, S->T, g->dT, nT * 12) != MC33HIP_OK) {
+	void *const dst[3] = {S->V, S->N, S->T};
+	const void *const src[3] = {g->dV, g->dN, g->dT};
+	const size_t bytes[3] = {nV * 3 * sizeof(MC33_real), nV * 12, nT * 12};
+	if (!S->V || !S->N || !S->T || !S->color || mc33hip_download_many(p->ctx, 3, dst, src, bytes, concurrent) != MC33HIP_OK) {
 		free(S->V); free(S->N); free(S->T); free(S->color); free(S);
 		return 0;
 	}

@@ -1726,6 +1726,18 @@ extern "C" int mc33hip_synchronize(mc33hip_ctx *c) {
 	return MC33HIP_OK;
 }
 
+extern "C" int mc33hip_download_many(mc33hip_ctx *c, int n, void *const *dst, const void *const *src, const size_t *bytes, int concurrent) {
+	if (!c || n < 0 || (n && (!dst || !src || !bytes))) return MC33HIP_EINVAL;
+	if (hipSetDevice(c->device) != hipSuccess) return MC33HIP_ERUNTIME;  // (the concurrent form may come from another thread)
+	hipStream_t st = concurrent ? c->copy : c->stream;
+	for (int k = 0; k < n; k++) {
+		if (!bytes[k]) continue;
+		if (!dst[k] || !src[k]) return MC33HIP_EINVAL;
+		if (hipMemcpyAsync(dst[k], src[k], bytes[k], hipMemcpyDeviceToHost, st) != hipSuccess) { (void)hipStreamSynchronize(st); return MC33HIP_ERUNTIME; }
+	}
+	return hipStreamSynchronize(st) == hipSuccess ? MC33HIP_OK : MC33HIP_ERUNTIME;
+}
+
 extern "C" int mc33hip_download_concurrent(mc33hip_ctx *c, void *dst, const void *src, size_t bytes) {
 	if (!c || (bytes && (!dst || !src))) return MC33HIP_EINVAL;
 	if (!bytes) return MC33HIP_OK;
