@@ -230,8 +230,6 @@ static int extract_to_staging(mc33_private *p, struct staging *g, MC33_real iso,
 	return rc;
 }
 
-/* host part: a caller-owned `surface` (five malloc blocks, MC:84-92) filled from staging set g.
- * concurrent: copy on the side stream, beside whatever the context is computing */
 /* One array of a caller-owned surface: plain free() releases it (MC:84-92).  Large ones start on a 2 MiB boundary and
  * ask for transparent huge pages: a 1024^3 surface is 200 MB, and touching it for the first time in 4 KiB pages (the
  * copy from the GPU, the colour fill, the munmap in free) cost more than the extraction itself.
@@ -308,6 +306,8 @@ static void surface_block_release(void *p) {
 	free(p);
 }
 
+/* host part: a caller-owned `surface` (five malloc blocks, MC:84-92) filled from staging set g.
+ * concurrent: copy on the side stream, beside whatever the context is computing */
 static surface *surface_from_staging(mc33_private *p, const struct staging *g, const mc33hip_counts *cnt, MC33_real iso, int concurrent) {
 	surface *S = (surface *)malloc(sizeof(surface));
 	if (!S)
