@@ -8,7 +8,7 @@ from mc33_capi import MC33Lib, product_path
 import fixtures as fx
 
 lib = MC33Lib(product_path("f32"), "f32")
-for n in (64, 256):
+for n in [int(x) for x in os.environ.get("CUBES", "64,256").split(",")]:
     data, r0, d = fx.cos_field(n)
     G, keep = lib.make_grid(data, r0, d)
     for rep in range(6):
