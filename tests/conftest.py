@@ -10,8 +10,31 @@ for p in (HERE, ROOT):
         sys.path.insert(0, p)
 
 
+_launcher = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Tests that start rank processes do it through a helper started NOW, before anything in this process can have
+    # initialised the GPU (tests/launcher.py): a GPU-initialised process must not start other programs on this pool.
+    global _launcher
+    if os.path.exists("/dev/kfd") and _launcher is None:
+        from launcher import Launcher
+        _launcher = Launcher()
+
+
+def pytest_unconfigure(config):
+    global _launcher
+    if _launcher is not None:
+        _launcher.close()
+        _launcher = None
+
+
+@pytest.fixture(scope="session")
+def launcher():
+    if _launcher is None:
+        pytest.skip("no GPU device node: the rank launcher was not started")
+    return _launcher
 
 
 DTYPES = ("f32", "u16", "u8", "u32", "f64")  # one library per GRD_data_type, like the reference's compile-time variants

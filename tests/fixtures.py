@@ -144,3 +144,73 @@ def cos_field_int(n, dtype, amp, mid):
     """cos x + cos y + cos z on [-4, 4]^3 quantised to an unsigned integer type: mid + amp * f."""
     f, _, _ = cos_field(n, dtype=np.float64)
     return np.rint(mid + amp * f).astype(dtype)
+
+
+# The ten default grids of the reference's GLUT example (GLUT_example/TestMC33_glut.c:837-923 the functions,
+# :948-979 the domains and steps), restated with numpy: name -> (lo[3], hi[3], step, isovalues worth testing).
+# Coordinates advance by repeated addition like generate_grid_from_fn (MC33_util_grd.c:660-672).
+REFERENCE_FIELDS = {
+    "f1": ((-3.0,) * 3, (3.0,) * 3, 0.04, (0.05, -0.1)),
+    "barth": ((-2.0,) * 3, (2.0,) * 3, 0.02, (0.0,)),
+    "gauss4": ((-4.0,) * 3, (4.0,) * 3, 0.04, (0.3, 0.6)),
+    "cube": ((-3.0,) * 3, (3.0,) * 3, 0.04, (0.5, 0.0)),
+    "cylinder": ((-3.0,) * 3, (3.0,) * 3, 0.04, (0.2, -0.3)),
+    "genus2": ((-1.875, -2.2, -1.875), (1.875, 1.55, 1.875), 0.025, (0.0,)),
+    "tanglecube": ((-3.0,) * 3, (3.0,) * 3, 0.03, (0.0,)),
+    "threetori": ((-1.5,) * 3, (1.5,) * 3, 0.015, (0.0,)),
+    "decocube_ref": ((-1.5,) * 3, (1.5,) * 3, 0.015, (0.0,)),
+    "leocube": ((-1.2,) * 3, (1.2,) * 3, 0.006, (0.0,)),
+}
+
+
+def reference_field(name, coarsen=1):
+    """(data [Nz, Ny, Nx] float32, r0, d) of one of the reference example's default grids; coarsen = k takes a
+    k times larger step (the leocube grid has 401^3 points)."""
+    lo, hi, step, _ = REFERENCE_FIELDS[name]
+    step *= coarsen
+    n = [int((hi[k] - lo[k]) / step + 0.5) + 1 for k in range(3)]
+    ax = [axis_accum(lo[k], step, n[k]) for k in range(3)]
+    x, y, z = ax[0][None, None, :], ax[1][None, :, None], ax[2][:, None, None]
+    if name == "f1":
+        f = (np.sin(x * y) + np.sin(y * z) + np.sin(x * z)) / (1.0 + x * x + y * y + z * z)
+    elif name == "barth":
+        phi = (np.sqrt(5.0) + 1) / 2
+        phi2 = phi * phi
+        X, Y, Z = x * x, y * y, z * z
+        t = (X + Y + Z - 1.0) * 1.0
+        f = 4 * (phi2 * X - Y) * (phi2 * Y - Z) * (phi2 * Z - X) - (1 + 2 * phi) * t * t
+    elif name == "gauss4":
+        ga = lambda cx, cy, cz: np.exp(-0.5 * ((x - cx) * (x - cx) + (y - cy) * (y - cy) + (z - cz) * (z - cz)))
+        f = ga(-1.5, -1.5, -1.5) + ga(1.5, 1.5, -1.5) + ga(1.5, -1.5, 1.5) + ga(-1.5, 1.5, 1.5)
+    elif name == "cube":
+        f = 1.0 - (1.0 / 3.0) * np.maximum(np.maximum(np.abs(x), np.abs(y)), np.abs(z))
+    elif name == "cylinder":
+        f = 1.0 - (1.0 / 3.0) * np.maximum(np.sqrt(x * x + z * z), np.sqrt(2.0) * np.abs(y))
+    elif name == "genus2":
+        t = y * y
+        X, Z = x * x, z * z - 1.0
+        Y = (2.0 * y * (t - 3.0 * X) - 9.0 * Z - 8.0) * Z
+        X = X + t
+        f = Y - X * X
+    elif name == "tanglecube":
+        X, Y, Z = x * x, y * y, z * z
+        f = X * (5 - X) + Y * (5 - Y) + Z * (5 - Z) - 11.8
+    elif name == "threetori":
+        X, Y, Z = x * x, y * y, z * z
+        t = X + Y + Z + 1.0 - 0.2 * 0.2
+        t = t * t
+        f = 0.01 - (t - 4 * (X + Y)) * (t - 4 * (X + Z)) * (t - 4 * (Y + Z))
+    elif name == "decocube_ref":
+        c2 = 2.0 - 1.3 * 1.3
+        X, Y, Z = x * x - 1.0, y * y - 1.0, z * z - 1.0
+        t1, t2, t3 = X + Y + c2, Y + Z + c2, Z + X + c2
+        f = 0.02 - (t1 * t1 + Z * Z) * (t2 * t2 + X * X) * (t3 * t3 + Y * Y)
+    elif name == "leocube":
+        X, Y, Z = x * x, y * y, z * z
+        t1 = (2.92 * (X - 1) * X + 1.7 * Y) * (Y - 0.88)
+        t2 = (2.92 * (Y - 1) * Y + 1.7 * Z) * (Z - 0.88)
+        t3 = (2.92 * (Z - 1) * Z + 1.7 * X) * (X - 0.88)
+        f = 0.04 - t1 * t1 - t2 * t2 - t3 * t3
+    else:
+        raise KeyError(name)
+    return np.broadcast_to(f, (n[2], n[1], n[0])).astype(np.float32), tuple(lo), (step, step, step)

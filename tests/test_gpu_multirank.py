@@ -1,0 +1,93 @@
+"""Multi-PROCESS GPU tests of the z-slab path: rank processes sharing cuda:0 of the one-GPU box,
+collectives over gloo.  The processes are started by the helper of tests/launcher.py (started before this pytest
+process touched the GPU)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PORT = [29600]
+
+
+def torchrun(launcher, world, script, env=None, timeout=900):
+    PORT[0] += 1
+    e = {"MASTER_ADDR": "127.0.0.1", "OMP_NUM_THREADS": "2", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    e.update(env or {})
+    return launcher.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                         "--master-port", str(PORT[0]), script], env=e, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_processes_on_one_gpu_equal_reference(launcher, world):
+    """Degenerate-rich float and ushort grids, noise that reaches every table group, a cos field; all three
+    exchange modes; concatenation compared bit for bit with oracle/_ref inside rank 0."""
+    out = torchrun(launcher, world, os.path.join(HERE, "gpu_slab_worker.py"))
+    assert out["rc"] == 0, out["stdout"][-3000:] + out["stderr"][-5000:]
+    assert "GPU_SLABS_OK 15" in out["stdout"], out["stdout"][-2000:]
+
+
+def bench(launcher, args, env, timeout=900):
+    e = {"MC33_BENCH_REHEARSAL": "1", "MC33_BENCH_VERIFY": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    e.update(env)
+    out = launcher.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, unset=["WORLD_SIZE", "RANK", "LOCAL_RANK"], timeout=timeout)
+    assert out["rc"] == 0, out["stdout"][-3000:] + out["stderr"][-5000:]
+    line = [l for l in out["stdout"].splitlines() if l.startswith("{")]
+    assert len(line) == 1, out["stdout"][-2000:]
+    return json.loads(line[0]), out
+
+
+@pytest.mark.parametrize("gather", ["allgather", "pairs", "root"])
+def test_bench_self_launch_c3_rehearsal(launcher, reflibs, tmp_path, gather):
+    """`python bench.py --gpus 2` exactly as the driver starts it (no WORLD_SIZE): the parent spawns the ranks; the
+    ranks share cuda:0 (rehearsal), verify the concatenation against a whole-volume extraction (MC33_BENCH_VERIFY) and
+    dump it; here it is compared with oracle/_ref on the same field."""
+    dump = str(tmp_path / "surf.npz")
+    n = 80
+    res, out = bench(launcher, ["--gpus", "2", "--steps", "3", "--warmup", "1", "--points", str(n), "--gather", gather], {"MC33_BENCH_DUMP": dump})
+    assert res["n_gpus"] == 2 and res["config"]["name"] == "c3" and res["gather"]["mode"] == gather and res["scaling"] == "weak"
+    assert set(res["gather"]["alone"]) == {"allgather", "pairs", "root"} and res["value"] > 0 and res["step_ms_min"] <= res["step_ms_max"]
+    assert "equals whole-volume result: True" in out["stderr"]
+    h = 8.0 / (n - 1)
+    x = np.cos(fx.axis_accum(-4.0, h, n))
+    z = np.cos(fx.axis_accum(-4.0, h, 2 * n))
+    data = ((x[None, None, :] + x[None, :, None]) + z[:, None, None]).astype(np.float32)
+    ref = reflibs["f32"].isosurface(data, 0.0, (-4.0, -4.0, -4.0), (h, h, h))
+    got = np.load(dump)
+    assert res["config"]["vertices"] == ref.nV and res["config"]["triangles"] == ref.nT
+    assert np.array_equal(got["T"], ref.T) and np.array_equal(got["V"].view(np.uint32), ref.V.view(np.uint32))
+    assert np.array_equal(got["N"].view(np.uint32), ref.N.view(np.uint32))
+
+
+def test_bench_self_launch_c5_rehearsal(launcher, reflibs, tmp_path):
+    """The ushort / 8-isovalue config on 3 rank processes (strong scaling: one grid cut into z-slabs)."""
+    dump = str(tmp_path / "surf.npz")
+    res, out = bench(launcher, ["--gpus", "3", "--steps", "2", "--warmup", "1", "--config", "c5", "--points", "40", "--gather", "pairs"], {"MC33_BENCH_DUMP": dump})
+    assert res["n_gpus"] == 3 and res["dtype"] == "u16" and res["config"]["isovalues_per_step"] == 8 and res["scaling"] == "strong"
+    data = fx.cos_field_u16(80, 80, 40)
+    total_v = total_t = 0
+    for k in range(8):
+        nV, nT, _ = reflibs["u16"].sizes(data, 15268.5 + 5000.0 * k)
+        total_v += nV; total_t += nT
+    assert res["config"]["vertices"] == total_v and res["config"]["triangles"] == total_t
+    ref = reflibs["u16"].isosurface(data, 15268.5 + 5000.0 * 7)
+    got = np.load(dump)
+    assert np.array_equal(got["T"], ref.T) and np.array_equal(got["V"].view(np.uint32), ref.V.view(np.uint32))
+
+
+def test_bench_single_gpu_lines(launcher):
+    """The default line and the C5 line at reduced size: contract keys, roofline and cpu_baseline objects."""
+    for args, name in ((["--points", "128"], "c3"), (["--config", "c5", "--points", "64"], "c5")):
+        res, _ = bench(launcher, ["--steps", "3", "--warmup", "1"] + args, {"MC33_BENCH_REHEARSAL": "0", "MC33_BENCH_VERIFY": "0"})
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                    "data", "config", "roofline", "cpu_baseline", "step_ms_min", "step_ms_median", "step_ms_max"):
+            assert key in res, key
+        assert res["config"]["name"] == name and res["n_gpus"] == 1 and res["vs_baseline"] is None
+        assert res["roofline"]["bound"] == "hbm" and res["roofline"]["frac"] > 0 and res["roofline"]["traffic"] is None
+        assert res["cpu_baseline"]["kind"] == "reference" and res["cpu_baseline"]["cores"] == 1 and res["cpu_baseline"]["value"] > 0

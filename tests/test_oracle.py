@@ -120,3 +120,13 @@ def test_oracle_bit_exact_vs_reference_double(oracles, reflibs, seed):
     mats = fx.general_matrices()
     data = fx.cos_field(24, dtype=np.float64)[0]
     assert _same(O.isosurface(data, 0.1, (0, 0, 0), (0.2, 0.3, 0.45), inclined=mats), R.isosurface(data, 0.1, (0, 0, 0), (0.2, 0.3, 0.45), inclined=mats))
+
+
+@pytest.mark.parametrize("name", sorted(fx.REFERENCE_FIELDS))
+def test_oracle_bit_exact_vs_reference_example_grids(oracles, reflibs, name):
+    """The ten default grids of the reference's GLUT example (GLUT_example/TestMC33_glut.c:837-979), at a coarser step
+    here; `cube` at iso 0 holds ~16 000 samples equal to the isovalue."""
+    data, r0, d = fx.reference_field(name, 4 if name == "leocube" else 2)
+    for iso in fx.REFERENCE_FIELDS[name][3]:
+        a, b = oracles["f32"].isosurface(data, iso, r0, d), reflibs["f32"].isosurface(data, iso, r0, d)
+        assert a.nV > 1000 and _same(a, b), (name, iso)
