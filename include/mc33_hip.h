@@ -79,6 +79,11 @@ int mc33hip_adopt_device(mc33hip_ctx *c, const void *device_samples, size_t pitc
  * _multTSA_bf (MC33_util_grd.c:86-97).  NULL matrices switch back to the orthogonal stores. */
 int mc33hip_set_inclined(mc33hip_ctx *c, const double *grd_A, const double *grd_Ai, int triangular);
 
+/* Orientation: on != 0 negates the normals and exchanges the first two indices of every triangle - what the reference
+ * does when it is compiled with MC33_NORMAL_NEG 1 (reference source/libMC33.c:20-22, marching_cubes_33.c:509-513,
+ * 1246-1250).  The libMC33_<type>_nneg.so flavour of the host layer switches it on in create_MC33. */
+int mc33hip_set_normal_neg(mc33hip_ctx *c, int on);
+
 /* Stream all work is enqueued on (a hipStream_t passed as void*; NULL = the default stream). */
 int mc33hip_set_stream(mc33hip_ctx *c, void *hip_stream);
 

@@ -35,7 +35,7 @@ class Timing(C.Structure):
 HIP_API = ["mc33hip_set_id_base", "mc33hip_create", "mc33hip_destroy", "mc33hip_last_error", "mc33hip_upload_rows",
            "mc33hip_upload_contiguous", "mc33hip_adopt_device", "mc33hip_set_stream", "mc33hip_count",
            "mc33hip_emit", "mc33hip_extract", "mc33hip_last_timing", "mc33hip_download",
-           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many"]
+           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many", "mc33hip_set_normal_neg"]
 REFERENCE_API = ["create_MC33", "calculate_isosurface", "size_of_isosurface", "free_MC33", "free_surface_memory",
                  "adjustvectorlenght_s", "DefaultColorMC", "free_memory_grd", "alloc_F", "grid_from_data_pointer",
                  "generate_grid_from_fn", "_multTSA_bf", "_multA_bf", "mult_Abf",
@@ -87,6 +87,7 @@ def load_library(dtype="f32"):
     lib.mc33hip_device_alloc.argtypes = [V, P(V), C.c_size_t]
     lib.mc33hip_device_free.argtypes = [V, V]
     lib.mc33hip_set_inclined.argtypes = [V, V, V, C.c_int]
+    lib.mc33hip_set_normal_neg.argtypes = [V, C.c_int]
     _libs[dtype] = lib
     return lib
 

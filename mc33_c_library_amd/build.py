@@ -1,10 +1,13 @@
-"""Build the two product libraries in-tree with hipcc (gfx950) + gcc.
+"""Build the product libraries in-tree with hipcc (gfx950) + gcc.
 
-    mc33_c_library_amd/libMC33_f32.so   GRD_data_type = float
-    mc33_c_library_amd/libMC33_u16.so   GRD_data_type = unsigned short (-DINTEGER_GRD -DGRD_TYPE_SIZE=2)
+    mc33_c_library_amd/libMC33_<type>.so        <type> = f32 (float), f64 (double, -DGRD_TYPE_SIZE=8), u8 / u16 / u32
+                                                (-DINTEGER_GRD -DGRD_TYPE_SIZE=1 / 2 / 4)
+    mc33_c_library_amd/libMC33_<type>_ortho.so  the same kernels, host layer compiled with -DGRD_ORTHOGONAL
+    mc33_c_library_amd/libMC33_<type>_nneg.so   ... with -DMC33_NORMAL_NEG=1 (front and back exchanged; f32 and u16)
 
-One library per grid sample type, like the reference's one-type-per-compile model
-(reference include/marching_cubes_33.h:57-88).  hipcc cross-compiles without a GPU.
+One library per grid sample type and per compile-time switch of the reference's header, like the reference's
+one-type-per-compile model (reference include/marching_cubes_33.h:57-88, source/libMC33.c:17-28).  hipcc cross-compiles
+without a GPU.  MC33_DEV=1 in the environment adds -DMC33_DEV (developer switches such as MC33_HIP_DEBUG; never shipped).
 """
 import os
 import shutil
@@ -22,6 +25,8 @@ GCC = os.environ.get("CC") or "gcc"
 # -ffp-contract=off: the reference's face / interior tests compare rounded products (MC:349-364, 436-445);
 # fusing a*b+c changes which sub-case is chosen.  Division and sqrt stay IEEE-correct (hipcc default).
 HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
+if os.environ.get("MC33_DEV", "0") == "1":
+    HIP_FLAGS.append("-DMC33_DEV")
 C_FLAGS = ["-O2", "-ffp-contract=off", "-std=c11", "-fPIC", "-Wall", "-Wextra"]
 
 VARIANTS = {
@@ -33,9 +38,12 @@ VARIANTS = {
 }
 
 
-def lib_path(dtype, ortho=False):
-    """ortho: the GRD_ORTHOGONAL flavour of the C API (structs without the inclined-grid members)."""
-    return os.path.join(PKG, "libMC33_%s%s.so" % (dtype, "_ortho" if ortho else ""))
+def lib_path(dtype, ortho=False, nneg=False):
+    """ortho: the GRD_ORTHOGONAL flavour of the C API (structs without the inclined-grid members); nneg: MC33_NORMAL_NEG."""
+    return os.path.join(PKG, "libMC33_%s%s%s.so" % (dtype, "_ortho" if ortho else "", "_nneg" if nneg else ""))
+
+
+NNEG_TYPES = ("f32", "u16")
 
 
 def _newer(target, deps):
@@ -88,6 +96,17 @@ def build(dtype, force=False, verbose_resources=False):
     oout = lib_path(dtype, ortho=True)
     if relink or _newer(oout, oobjs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + oobjs + ["-o", oout])
+    if dtype in NNEG_TYPES:  # MC33_NORMAL_NEG flavour: only mc33_capi.c looks at the switch
+        nobjs, relink = list(objs), force
+        src = os.path.join(CSRC, "mc33_capi.c")
+        obj = os.path.join(BUILD, "mc33_capi_%s_nneg.o" % dtype)
+        if force or _newer(obj, [src] + incs):
+            _run([GCC] + C_FLAGS + var["c"] + ["-DMC33_NORMAL_NEG=1", "-c", src, "-o", obj])
+            relink = True
+        nobjs[1 + C_SOURCES.index("mc33_capi.c")] = obj
+        nout = lib_path(dtype, nneg=True)
+        if relink or _newer(nout, nobjs):
+            _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + nobjs + ["-o", nout])
     return out
 
 

@@ -12,7 +12,7 @@
  * rewrites G->F between calls sets MC33_HIP_REUPLOAD=1 (re-upload before every extraction).
  */
 #define _DEFAULT_SOURCE /* madvise */
-#include <malloc.h> /* malloc_usable_size */
+#include <malloc.h> /* malloc_usable_size: asked only about blocks this library allocated itself */
 #include <pthread.h>
 #include <stddef.h>
 #include <stdlib.h>
@@ -47,6 +47,9 @@ _Static_assert(sizeof(MC33) == 160 + MC33_MATS && offsetof(MC33, memoryfault) ==
 
 #ifndef DEFAULT_SURFACE_COLOR
 #define DEFAULT_SURFACE_COLOR 0xff5c5c5c /* grey, 0xAABBGGRR (MC:76-78) */
+#endif
+#ifndef MC33_NORMAL_NEG
+#define MC33_NORMAL_NEG 0 /* 1: front and back exchanged, reference source/libMC33.c:20-22 (the _nneg flavour of the library) */
 #endif
 int DefaultColorMC = (int)DEFAULT_SURFACE_COLOR;
 
@@ -112,6 +115,7 @@ MC33 *create_MC33(_GRD *G) {
 	p->reupload = e && *e && *e != '0';
 	p->grid = G;
 	if (G->N[0] < 1 || G->N[1] < 1 || G->N[2] < 1 || mc33hip_create(&p->ctx, &d) != MC33HIP_OK ||
+	    mc33hip_set_normal_neg(p->ctx, MC33_NORMAL_NEG) != MC33HIP_OK ||
 	    mc33hip_upload_rows(p->ctx, (const void *const *const *)G->F) != MC33HIP_OK) {
 		free_MC33(M);
 		return 0;
@@ -234,24 +238,42 @@ static int extract_to_staging(mc33_private *p, struct staging *g, MC33_real iso,
  * ask for transparent huge pages: a 1024^3 surface is 200 MB, and touching it for the first time in 4 KiB pages (the
  * copy from the GPU, the colour fill, the munmap in free) cost more than the extraction itself.
  *
- * free_surface_memory keeps the large blocks of the surfaces it is given in a small cache instead of releasing them,
- * and the next surface takes its arrays from there: pages that are already mapped (and already known to the GPU
- * driver) make calculate_isosurface + free_surface_memory at 1024^3 about three times faster than with fresh memory.
- * The blocks are ordinary malloc blocks at all times - a caller that frees the arrays itself simply bypasses the
- * cache.  MC33_HOST_CACHE_MB (default 1024, 0 = off) bounds what is kept. */
+ * free_surface_memory may keep large blocks for the next surface instead of releasing them (pages that are already
+ * mapped and already known to the GPU driver make calculate_isosurface + free_surface_memory at 1024^3 about three
+ * times faster than fresh memory).  What it keeps is bounded by MC33_HOST_CACHE_MB: default 64 (one array of a
+ * 512^3-class surface; a drop-in library should not sit on a gigabyte after `free`), 0 = keep nothing; callers that
+ * extract large surfaces in a loop set it to a few times the surface size.
+ *
+ * Only blocks this library allocated are ever looked at: every large block handed out is entered in a small table
+ * (address, size); free_surface_memory looks the pointer up there, and an address it does not know is simply passed to
+ * free().  A table hit is double-checked with the allocator (a caller may have freed our block and got the same
+ * address back for a smaller one of its own): it counts as ours only if the allocator still holds at least the
+ * recorded size there.  The blocks are ordinary malloc blocks at all times. */
 #define HUGE_PAGE ((size_t)2 << 20)
 #define CACHE_MIN_BLOCK (2 * HUGE_PAGE)
 #define CACHE_SLOTS 16
+#define LIVE_SLOTS 256
 static struct {
 	void *p;
 	size_t cap;
-} g_cache[CACHE_SLOTS];
+} g_cache[CACHE_SLOTS], g_live[LIVE_SLOTS]; /* kept for reuse / handed out and still with the caller */
 static size_t g_cache_bytes;
 static pthread_mutex_t g_cache_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static size_t cache_limit(void) {
 	const char *e = getenv("MC33_HOST_CACHE_MB");
-	return (size_t)(e ? strtoull(e, 0, 10) : 1024ull) << 20;
+	return (size_t)(e ? strtoull(e, 0, 10) : 64ull) << 20;
+}
+
+/* (lock held) remember a large block that goes to the caller; when the table is full the block is simply not known
+ * later and will be freed like a foreign one */
+static void live_add(void *p, size_t cap) {
+	for (int k = 0; k != LIVE_SLOTS; k++)
+		if (!g_live[k].p || g_live[k].p == p) {
+			g_live[k].p = p;
+			g_live[k].cap = cap;
+			return;
+		}
 }
 
 /* a block of at least `bytes` bytes; *cap = what it can really hold */
@@ -268,6 +290,7 @@ static void *surface_block(size_t bytes, size_t *cap) {
 			*cap = g_cache[best].cap;
 			g_cache[best].p = 0;
 			g_cache_bytes -= *cap;
+			live_add(p, *cap);
 		}
 		pthread_mutex_unlock(&g_cache_lock);
 		if (p)
@@ -276,6 +299,9 @@ static void *surface_block(size_t bytes, size_t *cap) {
 		if (posix_memalign(&p, HUGE_PAGE, rounded) == 0) {
 			(void)madvise(p, rounded, MADV_HUGEPAGE);
 			*cap = rounded;
+			pthread_mutex_lock(&g_cache_lock);
+			live_add(p, rounded);
+			pthread_mutex_unlock(&g_cache_lock);
 			return p;
 		}
 	}
@@ -284,25 +310,28 @@ static void *surface_block(size_t bytes, size_t *cap) {
 	return p;
 }
 
-/* the counterpart used by free_surface_memory: keep a large block for the next surface, or free it */
+/* the counterpart used by free_surface_memory: keep a large block of ours for the next surface, or free it */
 static void surface_block_release(void *p) {
 	if (!p)
 		return;
-	const size_t cap = malloc_usable_size(p);
-	if (cap >= CACHE_MIN_BLOCK) {
-		const size_t limit = cache_limit();
-		pthread_mutex_lock(&g_cache_lock);
-		if (g_cache_bytes + cap <= limit)
-			for (int k = 0; k != CACHE_SLOTS; k++)
-				if (!g_cache[k].p) {
-					g_cache[k].p = p;
-					g_cache[k].cap = cap;
-					g_cache_bytes += cap;
-					p = 0;
-					break;
-				}
-		pthread_mutex_unlock(&g_cache_lock);
-	}
+	size_t cap = 0;
+	pthread_mutex_lock(&g_cache_lock);
+	for (int k = 0; k != LIVE_SLOTS; k++)
+		if (g_live[k].p == p) {
+			cap = g_live[k].cap;
+			g_live[k].p = 0;
+			break;
+		}
+	if (cap && malloc_usable_size(p) >= cap && g_cache_bytes + cap <= cache_limit())
+		for (int k = 0; k != CACHE_SLOTS; k++)
+			if (!g_cache[k].p) {
+				g_cache[k].p = p;
+				g_cache[k].cap = cap;
+				g_cache_bytes += cap;
+				p = 0;
+				break;
+			}
+	pthread_mutex_unlock(&g_cache_lock);
 	free(p);
 }
 
@@ -326,7 +355,8 @@ static surface *surface_from_staging(mc33_private *p, const struct staging *g, c
 	const void *const src[3] = {g->dV, g->dN, g->dT};
 	const size_t bytes[3] = {nV * 3 * sizeof(MC33_real), nV * 12, nT * 12};
 	if (!S->V || !S->N || !S->T || !S->color || mc33hip_download_many(p->ctx, 3, dst, src, bytes, concurrent) != MC33HIP_OK) {
-		free(S->V); free(S->N); free(S->T); free(S->color); free(S);
+		surface_block_release(S->V); surface_block_release(S->N); surface_block_release(S->T); surface_block_release(S->color);
+		free(S);
 		return 0;
 	}
 	const int col = DefaultColorMC;
@@ -440,7 +470,7 @@ void adjustvectorlenght_s(surface *S) { /* MC:94-127: shrink the four arrays to 
 		memcpy(c, S->color, sizeof(int) * (size_t)S->nV);
 		memcpy(n, S->N, 3 * sizeof(float) * (size_t)S->nV);
 		memcpy(v, S->V, 3 * sizeof(MC33_real) * (size_t)S->nV);
-		free(S->color); free(S->N); free(S->V);
+		surface_block_release(S->color); surface_block_release(S->N); surface_block_release(S->V);
 		S->color = (int *)c; S->N = (float(*)[3])n; S->V = (MC33_real(*)[3])v;
 		S->capv = S->nV;
 	}
@@ -448,7 +478,7 @@ void adjustvectorlenght_s(surface *S) { /* MC:94-127: shrink the four arrays to 
 		void *t = malloc(3 * sizeof(int) * (size_t)S->nT);
 		if (!t) return;
 		memcpy(t, S->T, 3 * sizeof(int) * (size_t)S->nT);
-		free(S->T);
+		surface_block_release(S->T);
 		S->T = (unsigned int(*)[3])t;
 		S->capt = S->nT;
 	}

@@ -51,6 +51,8 @@ struct Params {
 	real_t ca, cb;         // MC:1773-1774
 	int32_t store_mode;   // 0: MC33_spn0 (MC:485), 1: MC33_spnA (MC:518), 2: MC33_spnB (MC:551), 3: MC33_spnC (MC:587)
 	int32_t triangular;   // spnC: mult_Abf is _multTSA_bf (UTIL:86-97) rather than _multA_bf (UTIL:99-112)
+	int32_t normal_neg;   // the reference's MC33_NORMAL_NEG (libMC33.c:20-22): normals negated (MC:509-513), first two
+	                      // indices of every triangle exchanged (MC:1246-1250)
 	double A[9], Ai[9];   // spnC: M->_A, M->A_ (row major; MC:1763-1770)
 };
 
@@ -584,7 +586,8 @@ MC33_HD void store_vertex(const Params &P, real_t *r, real_t *V, float *N, uint3
 		if (P.store_mode == 2) { r[3] *= P.ca; r[4] *= P.cb; }
 	}
 	// MC:510-515: the squared length is MC33_real, the inverse root and the normal are float
-	const float s = inv_sqrt_exact((float)(r[3] * r[3] + r[4] * r[4] + r[5] * r[5]));
+	float s = inv_sqrt_exact((float)(r[3] * r[3] + r[4] * r[4] + r[5] * r[5]));
+	if (P.normal_neg) s = -s;  // MC:509-513
 	float *n = N + 3 * (uint64_t)id;
 	n[0] = s * (float)r[3]; n[1] = s * (float)r[4]; n[2] = s * (float)r[5];
 }
@@ -798,7 +801,8 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 		ti[0] = ids[(int)((word >> 8) & 15u)];
 		if (ti[0] != ti[1] && ti[0] != ti[2] && ti[1] != ti[2]) {
 			uint32_t *t = c.Tri + 3 * (uint64_t)tpos++;
-			t[0] = (p.n ? ti[1] : ti[0]) + c.id_delta; t[1] = (p.m ? ti[1] : ti[0]) + c.id_delta; t[2] = ti[2] + c.id_delta;
+			const bool swap = (p.n != 0) != (c.P.normal_neg != 0);  // MC:1246-1250
+			t[0] = (swap ? ti[1] : ti[0]) + c.id_delta; t[1] = (swap ? ti[0] : ti[1]) + c.id_delta; t[2] = ti[2] + c.id_delta;
 		}
 	} while (word >> 12);
 }
@@ -988,7 +992,7 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 	uint32_t tpos = sb.tbase + (en.w1 >> 16) - c.t_skip;
 	ids[5] = vbase + ((en.w2 >> 20) & 15u); ids[6] = vbase + ((en.w2 >> 24) & 15u); ids[10] = vbase + ((en.w3 >> 8) & 15u);
 	// winding (MC:683-691): n = 1 swaps the first two indices
-	const uint32_t n = ((c.tab.lut[(i & 0x80) ? (i ^ 0xFF) : i] >> 11) ^ (i >> 7) ^ 1u) & 1u;
+	const uint32_t n = ((c.tab.lut[(i & 0x80) ? (i ^ 0xFF) : i] >> 11) ^ (i >> 7) ^ 1u ^ (uint32_t)c.P.normal_neg) & 1u;
 	uint32_t pos = (en.w0 >> 16) & 0xFFFu, word;
 	do {  // MC:780-784, 1245-1250 (all three ids differ: regular vertices on three different edges)
 		word = c.tab.lut[++pos];

@@ -124,9 +124,14 @@ struct SweepArgs {
 	uint32_t z_end;          // end of the classified range: tiles that reach it have no tile above
 	uint4 *edge_bits;        // [tile * 2 + (0 bottom | 1 top)][2][lane]: bit rows of the tile's first / last plane
 	uint4 *edge_hdr;         // ... their halo-column bits and "a sample equals the isovalue" flag
-	uint32_t debug;          // MC33_HIP_DEBUG (timing experiments only; every count is 0): 2 = stream only, 16 = stream + the
-	                         // cut-cell test of every slice but no slice is handed on
+	uint32_t debug;          // MC33_HIP_DEBUG, developer builds (-DMC33_DEV) only - timing experiments, every count is 0: 2 = stream
+	                         // only, 16 = stream + the cut-cell test of every slice but no slice is handed on
 };
+#ifdef MC33_DEV
+#define MC33_DEBUG_BITS(a) ((a).debug)
+#else
+#define MC33_DEBUG_BITS(a) 0u  // the shipped library has no switch that changes results
+#endif
 
 
 // fast[i] of mc33_cell.h unpacked into the record words written for a FAST cell:
@@ -359,13 +364,13 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 			const uint64_t bh = __ballot(cur_h != 0);
 			if (lane == 0) a.edge_hdr[(uint64_t)wtile * 2u + which] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), cur_z ? 1u : 0u, 0u};
 		};
-		if (a.debug & 2u) {
+		if (MC33_DEBUG_BITS(a) & 2u) {
 		} else {
 			if (p == pl0 && pl0 != z_lo) leave_edge(0);
 			if (p > pl0) {
 				uint64_t act[4];
 				active_cells(prev, cur, prev_h, cur_h, valid, rowvalid, act);
-				if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(a.debug & 16u)) {  // wave-uniform: hand the slice to k_cells
+				if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(MC33_DEBUG_BITS(a) & 16u)) {  // wave-uniform: hand the slice to k_cells
 					hand_over_slice(a, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), prev, cur,
 					                !prev_written, true, __ballot(prev_h != 0), __ballot(cur_h != 0), prev_z || cur_z, act);
 					cur_written = true;
@@ -983,6 +988,7 @@ struct mc33hip_ctx {
 	uint2 *slot_base;
 	unsigned long long *slot_part;
 	uint32_t epoch;           // extractions since the slice headers were last cleared
+	uint32_t epoch_wrap;      // the stamps start over at this count (2^30; MC33_HIP_EPOCH_WRAP for the test that crosses it)
 	uint64_t slice_cap;
 	SweepTile *d_tiles;       // block plan of k_sweep for the current range
 	TileBoundary *d_bounds;   // pairs of tiles that meet in z (k_boundary)
@@ -998,6 +1004,7 @@ struct mc33hip_ctx {
 	bool emit_pending;        // an emit was enqueued after the last timing read
 	int timing_level;         // MC33_HIP_TIMING: 0 none (default), 1 whole call, 2 per pass - the event records cost ~20 us per call
 	bool inclined, triangular;   // non-orthogonal grid (MC33_spnC): _GRD._A / _GRD.A_ as given
+	bool normal_neg;             // front and back exchanged (the reference's MC33_NORMAL_NEG compile-time switch)
 	double grd_A[9], grd_Ai[9];
 	unsigned long long *trace;  // developer tracing (MC33_HIP_TRACE_FILE)
 	uint64_t trace_waves;
@@ -1013,6 +1020,7 @@ struct mc33hip_ctx {
 };
 
 extern "C" const char *mc33hip_last_error(void) { return g_err; }
+static uint32_t env_u32(const char *name, uint32_t dflt);
 
 static int use_device(mc33hip_ctx *c) {
 	HIP_TRY(hipSetDevice(c->device));
@@ -1102,6 +1110,7 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	CREATE_TRY(pool_take(c->device, &c->aux2));
 	CREATE_TRY(pool_take(c->device, &c->copy));
 	c->timing_level = getenv("MC33_HIP_TIMING") ? atoi(getenv("MC33_HIP_TIMING")) : 0;
+	c->epoch_wrap = std::min(1u << 30, std::max(3u, env_u32("MC33_HIP_EPOCH_WRAP", 1u << 30)));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
@@ -1256,6 +1265,7 @@ static void fill_params(mc33hip_ctx *c, double iso, const mc33hip_range *r) {
 	if (d.d[0] != d.d[1] || d.d[1] != d.d[2]) { P.store_mode = 2; P.ca = (real_t)(d.d[2] / d.d[0]); P.cb = (real_t)(d.d[2] / d.d[1]); }
 	else { P.store_mode = (d.d[0] == 1 && d.r0[0] == 0 && d.r0[1] == 0 && d.r0[2] == 0) ? 0 : 1; P.ca = P.cb = 1.0f; }
 	P.triangular = 0;
+	P.normal_neg = c->normal_neg ? 1 : 0;
 	for (int k = 0; k < 9; k++) P.A[k] = P.Ai[k] = 0.0;
 	if (c->inclined) {  // G->nonortho: MC:1763-1770
 		P.store_mode = 3;
@@ -1460,15 +1470,20 @@ static int enqueue_count(mc33hip_ctx *c) {
 		c->slice_cap = nslots;
 	}
 	a.slice_hdr = c->slice_hdr; a.slice_bits = c->slice_bits;
+	a.debug = 0;
+#ifdef MC33_DEV
 	a.debug = env_u32("MC33_HIP_DEBUG", 0);
 	if (a.debug) {  // never silent: with this set the call measures the sweep's read stream and finds no surface
 		static bool warned = false;
 		if (!warned) fprintf(stderr, "[mc33hip] MC33_HIP_DEBUG=%u: timing experiment, every extraction returns an EMPTY surface\n", a.debug);
 		warned = true;
 	}
+#endif
 	const uint64_t nchunks = (c->slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;  // (capacity: the halves keep their place)
-	if (++c->epoch >= (1u << 30)) {  // stamps wrap: start over with clean headers
+	if (++c->epoch >= c->epoch_wrap) {  // stamps wrap: start over with clean headers AND clean partial sums - the call before
+		// accumulated into the half an odd epoch selects and cleared only the other one, and epoch 1 is odd again
 		HIP_TRY(hipMemsetAsync(c->slice_hdr, 0, c->slice_cap * sizeof(SliceHeader), st));
+		HIP_TRY(hipMemsetAsync(c->slot_part, 0, 2 * nchunks * 8, st));
 		c->epoch = 1;
 	}
 	unsigned long long *part_now = c->slot_part + (c->epoch & 1u) * nchunks, *part_next = c->slot_part + ((c->epoch + 1u) & 1u) * nchunks;
@@ -1491,7 +1506,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	hipLaunchKernelGGL(k_sweep, dim3((uint32_t)blocks), dim3(256), 0, st, a);
 	HIP_TRY(hipGetLastError());
 	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[1], st));
-	if (c->nbounds && !(a.debug & 2u)) hipLaunchKernelGGL(k_boundary, dim3((uint32_t)((c->nbounds + 3) / 4)), dim3(256), 0, st, a, c->d_bounds, (uint32_t)c->nbounds);
+	if (c->nbounds && !(MC33_DEBUG_BITS(a) & 2u)) hipLaunchKernelGGL(k_boundary, dim3((uint32_t)((c->nbounds + 3) / 4)), dim3(256), 0, st, a, c->d_bounds, (uint32_t)c->nbounds);
 	CellsArgs ca;
 	ca.P = P; ca.fast = c->d_fast;
 	ca.ze = ze; ca.nYT = a.nYT; ca.nseg_pad = a.nseg_pad;
@@ -1660,6 +1675,13 @@ extern "C" int mc33hip_set_inclined(mc33hip_ctx *c, const double *grd_A, const d
 	c->inclined = grd_A && grd_Ai;
 	c->triangular = triangular != 0;
 	if (c->inclined) { memcpy(c->grd_A, grd_A, sizeof c->grd_A); memcpy(c->grd_Ai, grd_Ai, sizeof c->grd_Ai); }
+	c->counted = false;
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_set_normal_neg(mc33hip_ctx *c, int on) {
+	if (!c) return MC33HIP_EINVAL;
+	c->normal_neg = on != 0;
 	c->counted = false;
 	return MC33HIP_OK;
 }

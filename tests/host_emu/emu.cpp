@@ -33,7 +33,7 @@ template <typename T>
 static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const double *r0, const double *d, float iso,
                emu_surface *out, const emu_slab *slab = nullptr) {
 	memset(out, 0, sizeof *out);
-	Params P;
+	Params P{};
 	P.nx = npx - 1; P.ny = npy - 1; P.nz = npz - 1;
 	P.nseg = (P.nx + SEG_CELLS - 1) / SEG_CELLS;
 	P.iso = iso; P.zs = 0;

@@ -274,12 +274,12 @@ class MC33Lib:
             del keep
 
 
-def ref_path(dtype="f32", fast=False, ortho=False):
-    return os.path.join(ROOT, "oracle", "_ref", "libMC33ref_%s%s%s.so" % (dtype, "_ortho" if ortho else "", "_fast" if fast else ""))
+def ref_path(dtype="f32", fast=False, ortho=False, nneg=False):
+    return os.path.join(ROOT, "oracle", "_ref", "libMC33ref_%s%s%s%s.so" % (dtype, "_ortho" if ortho else "", "_nneg" if nneg else "", "_fast" if fast else ""))
 
 
-def product_path(dtype="f32", ortho=False):
-    return os.path.join(ROOT, "mc33_c_library_amd", "libMC33_%s%s.so" % (dtype, "_ortho" if ortho else ""))
+def product_path(dtype="f32", ortho=False, nneg=False):
+    return os.path.join(ROOT, "mc33_c_library_amd", "libMC33_%s%s%s.so" % (dtype, "_ortho" if ortho else "", "_nneg" if nneg else ""))
 
 
 def fnv1a64(a):

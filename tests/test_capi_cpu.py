@@ -135,3 +135,33 @@ def test_reference_style_caller_compiles_and_links(tmp_path, compiler, lang):
         assert r.returncode == 3 and "NULL" in r.stdout
     else:
         assert r.returncode == 0 and int(r.stdout.split()[0]) > 1000
+
+
+REF_INC = "/root/reference/include"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INC), reason="the reference header exists only in the build container")
+def test_callers_compiled_against_the_reference_header(tmp_path):
+    """tests/callers/caller.c compiled against the REFERENCE's own marching_cubes_33.h, for all five sample types with
+    and without GRD_ORTHOGONAL, linked with the product libraries: it builds warning-free, runs (create_MC33 -> NULL on a
+    box without GPU), and the struct layout it prints equals that of the same program compiled against THIS repo's
+    header - header drift cannot hide behind hand-maintained offsets."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "callers"))
+    import build_callers as bc
+    built = bc.build_all()
+    assert len(built) >= 10 + 5
+    for name, flags, plib, rlib in bc.VARIANTS:
+        ours = str(tmp_path / ("ourhdr_" + name))
+        bc.compile_caller(os.path.join(ROOT, "include"), flags, os.path.join(ROOT, "mc33_c_library_amd"), plib, ours, os.path.join(ROOT, "mc33_c_library_amd"))
+        a = subprocess.run([os.path.join(bc.OUT, "refhdr_" + name)], capture_output=True, text=True)
+        b = subprocess.run([ours], capture_output=True, text=True)
+        la = [l for l in a.stdout.splitlines() if l.startswith("layout")]
+        lb = [l for l in b.stdout.splitlines() if l.startswith("layout")]
+        assert len(la) >= 4 and la == lb, (name, la, lb)
+        if _no_gpu():
+            assert a.returncode == 3 and b.returncode == 3 and "create_MC33: NULL" in a.stdout, (name, a.returncode, a.stdout, a.stderr)
+        if rlib:  # the reference library run by the same program: layout lines again, and a surface
+            r = subprocess.run([os.path.join(bc.OUT, "reflib_" + name)], capture_output=True, text=True)
+            assert r.returncode == 0 and [l for l in r.stdout.splitlines() if l.startswith("layout")] == la and "digest T" in r.stdout, (name, r.stdout, r.stderr)

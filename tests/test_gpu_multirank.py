@@ -91,3 +91,30 @@ def test_bench_single_gpu_lines(launcher):
         assert res["config"]["name"] == name and res["n_gpus"] == 1 and res["vs_baseline"] is None
         assert res["roofline"]["bound"] == "hbm" and res["roofline"]["frac"] > 0 and res["roofline"]["traffic"] is None
         assert res["cpu_baseline"]["kind"] == "reference" and res["cpu_baseline"]["cores"] == 1 and res["cpu_baseline"]["value"] > 0
+
+
+def test_programs_built_against_the_reference_header(launcher):
+    """Drop-in at the binary level: tests/callers/caller.c was compiled in the build container against the REFERENCE's
+    marching_cubes_33.h (oracle/_ref/callers/, built by __graft_entry__.build()), once linked with the product library
+    and once with the reference library.  Run as child processes here: same struct layout, same counts, same digests of
+    T, V and N - for every sample type, with and without GRD_ORTHOGONAL."""
+    d = os.path.join(ROOT, "oracle", "_ref", "callers")
+    if not os.path.isdir(d):
+        pytest.skip("oracle/_ref/callers not built (needs the reference header in the build container)")
+    names = sorted(n[len("refhdr_"):] for n in os.listdir(d) if n.startswith("refhdr_"))
+    assert len(names) == 10
+    compared = 0
+    for n in names:
+        got = launcher.run([os.path.join(d, "refhdr_" + n)], timeout=300)
+        assert got["rc"] == 0 and "digest T" in got["stdout"], (n, got)
+        nv = int(got["stdout"].split("surface nV ")[1].split()[0])
+        assert nv > 5000, got["stdout"]
+        want_path = os.path.join(d, "reflib_" + n)
+        if os.path.exists(want_path):
+            want = launcher.run([want_path], timeout=300)
+            assert want["rc"] == 0
+            # (capacities after the reference's doubling growth differ from exact-fit ones before adjustvectorlenght_s; the
+            # lines compared are layout, surface counts, digests and the state after the adjust)
+            assert got["stdout"] == want["stdout"], (n, got["stdout"], want["stdout"])
+            compared += 1
+    assert compared >= 7

@@ -312,6 +312,53 @@ def test_grd_orthogonal_flavour(reflibs, dtype):
         assert (got.nV, got.nT) == (reflibs[dtype].isosurface(data, iso, r0, d).nV, ref.nT)  # and the same surface as the full-layout build
 
 
+@pytest.mark.parametrize("dtype", ["f32", "u16"])
+def test_normal_neg_flavour(reflibs, dtype):
+    """libMC33_<type>_nneg.so = the reference compiled with MC33_NORMAL_NEG 1 (source/libMC33.c:20-22): normals negated
+    (marching_cubes_33.c:509-513), first two indices of every triangle exchanged (:1246-1250) - fast cells, slow cells
+    (all table groups, degenerate corners), every store."""
+    from mc33_capi import MC33Lib, product_path, ref_path
+    P, R = MC33Lib(product_path(dtype, nneg=True), dtype), MC33Lib(ref_path(dtype, nneg=True), dtype)
+    if dtype == "f32":
+        cases = [(fx.cos_field(70)[0], 0.0, (-4.0, -4.0, -4.0), (8 / 69,) * 3, None), (fx.noise_f32(32, 2), 0.0, None, None, None),
+                 (fx.noise_quant(24, 2), 1.0, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0), None),
+                 (fx.cos_field(40)[0], 0.1, (0.0, 0.0, 0.0), (0.2, 0.3, 0.45), fx.general_matrices())]
+    else:
+        cases = [(fx.noise_u16(24, 3, 7), 3.0, None, None, None), (fx.cos_field_u16(60, 50, 40), 25268.5, None, (0.5, 0.5, 0.5), None)]
+    for data, iso, r0, d, inc in cases:
+        got, ref = P.isosurface(data, iso, r0, d, inclined=inc), R.isosurface(data, iso, r0, d, inclined=inc)
+        assert_surface_parity(got, ref, float(max(data.shape)), "nneg " + dtype, bit_exact=True)
+        plain = reflibs[dtype].isosurface(data, iso, r0, d, inclined=inc)   # ... and really the mirror image of the default build
+        assert got.nV > 1000 and np.array_equal(got.T[:, [1, 0, 2]], plain.T)
+        fin = np.isfinite(plain.N)
+        assert np.array_equal(got.N[fin], -plain.N[fin])
+
+
+def test_epoch_stamps_wrap_around(reflibs):
+    """Slice headers carry the number of the extraction instead of being cleared; when the stamps wrap, the headers and
+    BOTH halves of the slot partial sums start over.  MC33_HIP_EPOCH_WRAP moves the wrap from 2^30 down to 4 calls, so
+    that one context crosses it several times, with odd and even epochs before the wrap."""
+    import os
+    import torch
+    from mc33_c_library_amd import DeviceGrid
+    data, r0, d = fx.cos_field(140)
+    t = torch.from_numpy(data).cuda()
+    refs = {iso: reflibs["f32"].isosurface(data, iso, r0, d) for iso in (0.0, 1.1, -0.7)}
+    for wrap in ("4", "5"):
+        os.environ["MC33_HIP_EPOCH_WRAP"] = wrap
+        try:
+            g = DeviceGrid(t, r0=r0, d=d)
+        finally:
+            os.environ.pop("MC33_HIP_EPOCH_WRAP")
+        for step in range(14):
+            iso = (0.0, 1.1, -0.7)[step % 3]
+            V, N, T, cnt = g.extract(iso)
+            ref = refs[iso]
+            assert (cnt.nV, cnt.nT) == (ref.nV, ref.nT), (wrap, step)
+            assert np.array_equal(T.cpu().numpy().view(np.uint32), ref.T) and np.array_equal(V.cpu().numpy().view(np.uint32), ref.V.view(np.uint32)), (wrap, step)
+        g.close()
+
+
 def test_batched_isovalues_equal_single_calls(products, reflibs):
     """calculate_isosurfaces (extension): out[k] must be exactly what calculate_isosurface(M, iso[k]) returns -
     growing and shrinking results (both staging sets are regrown), an empty one in the middle, n = 1 and n = 0."""
