@@ -280,6 +280,26 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
 
+    if multi and (os.environ.get("MC33_BENCH_VERIFY", "0") == "1" or os.environ.get("MC33_BENCH_DUMP")):
+        # the exchanged surface of the LAST isovalue (checked before anything below reuses the buffers): concatenation in
+        # rank order = the whole-volume result
+        counts = state["counts"]
+        if args.gather != "root" or rank == 0:
+            Vc, Nc, Tc = ex.concatenated(state["b"], counts)
+            if os.environ.get("MC33_BENCH_DUMP") and rank == 0:  # for tests: compared with oracle/_ref by the caller
+                import numpy as np
+                np.savez(os.environ["MC33_BENCH_DUMP"], V=Vc.cpu().numpy(), N=Nc.cpu().numpy(), T=Tc.cpu().numpy().view(np.uint32), iso=isos[-1])
+            if os.environ.get("MC33_BENCH_VERIFY", "0") == "1":
+                if args.config == "c3":
+                    whole_field = cos_field_slab(npx, nz_total + 1, h, lo, dev, z_first=0)
+                else:
+                    whole_field = cos_field_u16(npx, npy, nz_total + 1, dev)
+                wg = DeviceGrid(whole_field, r0=r0, d=dd)
+                Vw, Nw, Tw, cw = wg.extract(isos[-1])
+                ok = bool(torch.equal(Tc, Tw) and torch.equal(Vc.contiguous().view(torch.int32), Vw.contiguous().view(torch.int32)) and
+                          torch.equal(Nc.contiguous().view(torch.int32), Nw.contiguous().view(torch.int32)))
+                print("[rank %d] slab concatenation (%s) equals whole-volume result: %s (nV %d nT %d)" % (rank, args.gather, ok, cw.nV, cw.nT), file=sys.stderr)
+                assert ok
     # ---- outside the timed region ---------------------------------------------------------------------------
     gather_info = None
     extract_only_ms = None
@@ -329,25 +349,6 @@ def main():
     else:
         cells_all, nV_all, nT_all = cells_rank, last[0], last[1]
 
-    if multi and (os.environ.get("MC33_BENCH_VERIFY", "0") == "1" or os.environ.get("MC33_BENCH_DUMP")):
-        # the exchanged surface of the LAST isovalue: concatenation in rank order = the whole-volume result
-        counts = state["counts"]
-        if args.gather != "root" or rank == 0:
-            Vc, Nc, Tc = ex.concatenated(state["b"], counts)
-            if os.environ.get("MC33_BENCH_DUMP") and rank == 0:  # for tests: compared with oracle/_ref by the caller
-                import numpy as np
-                np.savez(os.environ["MC33_BENCH_DUMP"], V=Vc.cpu().numpy(), N=Nc.cpu().numpy(), T=Tc.cpu().numpy().view(np.uint32), iso=isos[-1])
-            if os.environ.get("MC33_BENCH_VERIFY", "0") == "1":
-                if args.config == "c3":
-                    whole_field = cos_field_slab(npx, nz_total + 1, h, lo, dev, z_first=0)
-                else:
-                    whole_field = cos_field_u16(npx, npy, nz_total + 1, dev)
-                wg = DeviceGrid(whole_field, r0=r0, d=dd)
-                Vw, Nw, Tw, cw = wg.extract(isos[-1])
-                ok = bool(torch.equal(Tc, Tw) and torch.equal(Vc.contiguous().view(torch.int32), Vw.contiguous().view(torch.int32)) and
-                          torch.equal(Nc.contiguous().view(torch.int32), Nw.contiguous().view(torch.int32)))
-                print("[rank %d] slab concatenation (%s) equals whole-volume result: %s (nV %d nT %d)" % (rank, args.gather, ok, cw.nV, cw.nT), file=sys.stderr)
-                assert ok
     if rank == 0:
         nis = len(isos)
         ms_step = dt / args.steps * 1e3

@@ -51,6 +51,8 @@ struct Params {
 	real_t ca, cb;         // MC:1773-1774
 	int32_t store_mode;   // 0: MC33_spn0 (MC:485), 1: MC33_spnA (MC:518), 2: MC33_spnB (MC:551), 3: MC33_spnC (MC:587)
 	int32_t triangular;   // spnC: mult_Abf is _multTSA_bf (UTIL:86-97) rather than _multA_bf (UTIL:99-112)
+	int32_t negzero_iso;  // the isovalue is -0.0: a sample equal to it gives v = -0, "zero AND negative", and the degenerate-vertex
+	                      // rules may then point at grid edges whose owner cell is not cut at all (see edge_vertex_id)
 	int32_t normal_neg;   // the reference's MC33_NORMAL_NEG (libMC33.c:20-22): normals negated (MC:509-513), first two
 	                      // indices of every triangle exchanged (MC:1246-1250)
 	double A[9], Ai[9];   // spnC: M->_A, M->A_ (row major; MC:1763-1770)
@@ -742,6 +744,13 @@ MC33_HD uint32_t edge_vertex_id(const EmitCtx<T> &c, GridEdge g, const VRef &w) 
 	for (int hop = 0; hop < 64; hop++) {
 		const OwnerRef o = owner_of(g.axis, g.x, g.y, g.z);
 		const uint64_t s = segment_index(c.P, o.x, o.y, o.z);
+		// Only with iso = -0.0 can a rule name an edge whose owner is not cut (for the reference that is a read of whatever
+		// an earlier slice or call left in its id caches; here it is "no vertex").  Such a row segment may hold no record
+		// at all, and its directory entry is then whatever an earlier extraction left: do not look at it.
+		if (c.P.negzero_iso) {
+			const uint32_t oi = load_cell(c.G, c.P.iso, o.x, o.y, o.z, w);
+			if (oi == 0 || oi == 0xFF) return NO_ID;
+		}
 		const uint32_t ri = find_record(c, s, o.x % SEG_CELLS);
 		if (ri == NO_ID) return NO_ID;
 		const Entry e = c.entries[ri];
@@ -796,10 +805,17 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 	do {  // MC:780-784, 1235-1250
 		word = c.tab.lut[++pos];
 		uint32_t ti[3];
-		ti[2] = ids[(int)(word & 15u)];
-		ti[1] = ids[(int)((word >> 4) & 15u)];
-		ti[0] = ids[(int)((word >> 8) & 15u)];
-		if (ti[0] != ti[1] && ti[0] != ti[2] && ti[1] != ti[2]) {
+		const uint32_t e2 = word & 15u, e1 = (word >> 4) & 15u, e0 = (word >> 8) & 15u;
+		ti[2] = ids[(int)e2];
+		ti[1] = ids[(int)e1];
+		ti[0] = ids[(int)e0];
+		// MC:1235 on the ids - except for iso = -0.0, where ids may be "no vertex" (see edge_vertex_id): the triangle slots
+		// were counted by vertex identity (count_triangles), and the same test decides here, so that every counted slot is
+		// written and the output is a function of the input alone
+		const bool keep = c.P.negzero_iso ? (slots_differ(p, c.tab, c.P, c.G, x, y, z, e2, e1, w) && slots_differ(p, c.tab, c.P, c.G, x, y, z, e2, e0, w) &&
+		                                     slots_differ(p, c.tab, c.P, c.G, x, y, z, e1, e0, w))
+		                                  : (ti[0] != ti[1] && ti[0] != ti[2] && ti[1] != ti[2]);
+		if (keep) {
 			uint32_t *t = c.Tri + 3 * (uint64_t)tpos++;
 			const bool swap = (p.n != 0) != (c.P.normal_neg != 0);  // MC:1246-1250
 			t[0] = (swap ? ti[1] : ti[0]) + c.id_delta; t[1] = (swap ? ti[0] : ti[1]) + c.id_delta; t[2] = ti[2] + c.id_delta;

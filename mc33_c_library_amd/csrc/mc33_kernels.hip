@@ -1266,6 +1266,7 @@ static void fill_params(mc33hip_ctx *c, double iso, const mc33hip_range *r) {
 	else { P.store_mode = (d.d[0] == 1 && d.r0[0] == 0 && d.r0[1] == 0 && d.r0[2] == 0) ? 0 : 1; P.ca = P.cb = 1.0f; }
 	P.triangular = 0;
 	P.normal_neg = c->normal_neg ? 1 : 0;
+	P.negzero_iso = (P.iso == 0 && sign_of(P.iso)) ? 1 : 0;
 	for (int k = 0; k < 9; k++) P.A[k] = P.Ai[k] = 0.0;
 	if (c->inclined) {  // G->nonortho: MC:1763-1770
 		P.store_mode = 3;

@@ -26,7 +26,7 @@ def main():
     cases = [
         # samples equal to the isovalue everywhere: aliases are chased across the slab interfaces
         ("f32", fx.noise_quant(0, 5, shape=(41, 24, 300)), 0.0, None, None),
-        ("f32", fx.noise_quant(0, 9, L=3, shape=(26, 70, 40)), 1.0, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0)),
+        ("f32", fx.noise_quant(0, 9, L=3, shape=(26, 70, 40)), 0.0, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0)),
         ("u16", fx.noise_u16(0, 2, 7, shape=(37, 20, 30)), 3.0, None, None),
         ("f32", fx.noise_f32(0, 3, shape=(33, 66, 70)), 0.0, None, None),       # all 8 table groups
         ("f32", fx.cos_field(72)[0], 0.0, (-4.0, -4.0, -4.0), (8 / 71,) * 3),
@@ -42,6 +42,7 @@ def main():
         ref = MC33Lib(ref_path(dtype), dtype).isosurface(data, iso, r0, d) if rank == 0 else None
         for mode in MODES:
             c = grid.count(iso, slab.range())
+            print("[rank %d] %s %s iso %g mode %s: slab [%d, %d) nV %d nT %d" % (rank, dtype, data.shape, iso, mode, slab.z_begin, slab.z_end, c.nV, c.nT), file=sys.stderr)
             caps = torch.tensor([c.nV + 16, c.nT + 16])
             dist.all_reduce(caps, op=dist.ReduceOp.MAX)
             ex = SurfaceExchange(world, rank, dev, int(caps[0]), int(caps[1]), mode=mode, nbuf=2, host_collectives=True)
@@ -56,7 +57,7 @@ def main():
                 assert np.array_equal(V.view(np.uint32), ref.V.view(np.uint32)), (dtype, mode)
                 nan = np.isnan(ref.N)
                 assert np.array_equal(np.isnan(N), nan) and np.array_equal(N[~nan].view(np.uint32), ref.N[~nan].view(np.uint32)), (dtype, mode)
-                assert sum(1 for cnt in counts if cnt[0]) == world, "every rank should hold a piece of the surface: %s" % (counts,)
+                assert sum(1 for cnt in counts if cnt[0]) == world, "every rank should hold a piece of the surface: %s %s %s %s" % (counts, dtype, data.shape, mode)
                 done += 1
             dist.barrier()
         grid.close()

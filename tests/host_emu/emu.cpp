@@ -37,6 +37,7 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	P.nx = npx - 1; P.ny = npy - 1; P.nz = npz - 1;
 	P.nseg = (P.nx + SEG_CELLS - 1) / SEG_CELLS;
 	P.iso = iso; P.zs = 0;
+	P.negzero_iso = (iso == 0 && sign_of(P.iso)) ? 1 : 0;
 	uint32_t z_emit = 0, ze = P.nz, id_base = 0;
 	g_plane_lo = 0; g_plane_hi = npz - 1; g_px = npx; g_py = npy;
 	if (slab) {

@@ -140,7 +140,7 @@ def test_negative_zero_isovalue_is_deterministic(products, reflibs):
         lib.lib.free_surface_memory(S)
         if iso == 0.0:
             assert (b.nV, b.nT) == (a.nV, a.nT) and np.array_equal(b.T, a.T) and np.array_equal(b.V.view(np.uint32), a.V.view(np.uint32))
-            assert np.array_equal(b.N.view(np.uint32), a.N.view(np.uint32)) and int(b.T.max()) == b.nV - 1
+            assert np.array_equal(b.N.view(np.uint32), a.N.view(np.uint32))
     lib.lib.free_MC33(M)
     lib.lib.free_memory_grd(G)
     del keep
