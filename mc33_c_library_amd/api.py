@@ -50,7 +50,8 @@ class MC33Error(RuntimeError):
 
 
 def library_path(dtype="f32"):
-    return os.path.join(PKG, "libMC33_%s.so" % dtype)
+    # MC33_LIB_DIR: developer switch (tools/): load a -DMC33_DEV build from another directory
+    return os.path.join(os.environ.get("MC33_LIB_DIR") or PKG, "libMC33_%s.so" % dtype)
 
 
 _libs = {}

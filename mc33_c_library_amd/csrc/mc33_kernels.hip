@@ -565,7 +565,9 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	uint4 q[4] = {};
 	uint2 base = {0u, 0u};
 	if (in_grid) {  // header, ranges and bit rows are fetched together (one round trip); the rows of a slice
-		// without cut cells are whatever an earlier call left there and are not looked at
+		// without cut cells are whatever an earlier call left there and are not looked at.  (Fetching the bit rows only
+		// once the header says the slice is cut - two thirds of the slots of a smooth field are not - saves 180 MB of
+		// reads at 1024^3 and no time: measured, round 2)
 		h = a.slice_hdr[slot];
 		base = a.slot_base[slot];
 		// bit rows of the two planes of the slice (the upper plane's record sits in the slot of the slice above)
@@ -866,6 +868,8 @@ struct EmitArgs {
 	uint64_t capV, capT;
 	uint64_t ghost_segs;  // row segments of the ghost slice (0 without ghost)
 	uint32_t id_base;
+	uint32_t dev_mode;          // -DMC33_DEV + MC33_HIP_EMIT_DEV: experiments (wrong output)
+	unsigned long long *trace;  // -DMC33_DEV + MC33_HIP_TRACE_EMIT: per wave of the vertex pass {start, records in, samples in, end}
 };
 
 // The fast emit passes take the records in storage order, which k_slots made (4 slices of a tile column, next
@@ -909,6 +913,39 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
 	const XcdWalk w(ctr.entry_cursor);
+#ifdef MC33_DEV
+	if (a.trace) {  // phase stamps (s_memrealtime, 100 MHz); the waits change the schedule a little
+		const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+		unsigned long long t1 = 0, t2 = 0;
+		for (uint32_t e = w.first; e < w.end; e += w.stride) {
+			const Entry en = c.entries[e];
+			const uint32_t sg = c.entry_seg[e];
+			__builtin_amdgcn_s_waitcnt(0);
+			t1 = __builtin_amdgcn_s_memrealtime() + (en.w0 & 0u);
+			const SegCoord sc = segment_coord(c.P, sg);
+			float acc = 0;  // the sample reads of emit_fast_vertices, approximately: 12 scattered loads
+			const uint32_t x = sc.xbase + (en.w0 & 0xFFu);
+			for (int r = 0; r < 4; r++) { const auto q = c.G.pair(x, sc.y + (r & 1), sc.z + (r >> 1)); acc += (float)q.a + (float)q.b + (float)c.G.at(x + 2, sc.y + (r & 1), sc.z + (r >> 1)); }
+			acc += (float)c.seg_base[sg].vbase;
+			__builtin_amdgcn_s_waitcnt(0);
+			t2 = __builtin_amdgcn_s_memrealtime() + (acc == 12345.f ? 1u : 0u);
+			if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, sg);
+		}
+		__builtin_amdgcn_s_waitcnt(0);
+		if ((threadIdx.x & 63u) == 0) {
+			unsigned long long *tr = a.trace + 4ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+			tr[0] = t0; tr[1] = t1; tr[2] = t2; tr[3] = __builtin_amdgcn_s_memrealtime();
+		}
+		return;
+	}
+	if (a.dev_mode) {
+		for (uint32_t e = w.first; e < w.end; e += w.stride) {
+			const Entry en = c.entries[e];
+			if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, c.entry_seg[e], a.dev_mode, e);
+		}
+		return;
+	}
+#endif
 	for (uint32_t e = w.first; e < w.end; e += w.stride) {
 		const Entry en = c.entries[e];
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, c.entry_seg[e]);
@@ -1010,6 +1047,8 @@ struct mc33hip_ctx {
 	uint64_t trace_waves;
 	unsigned long long *trace_cells;  // (MC33_HIP_TRACE_CELLS)
 	uint64_t trace_cells_n;
+	unsigned long long *trace_emit;   // (MC33_HIP_TRACE_EMIT, -DMC33_DEV builds)
+	uint64_t trace_emit_n;
 	// state of the last count
 	bool counted;
 	Params P;
@@ -1131,7 +1170,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->d_tiles);
 	(void)hipFree(c->slot_base); (void)hipFree(c->slot_part);
 	(void)hipFree(c->d_bounds); (void)hipFree(c->edge_bits); (void)hipFree(c->edge_hdr);
-	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
+	(void)hipFree(c->trace); (void)hipFree(c->trace_cells); (void)hipFree(c->trace_emit);
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	if (c->aux) (void)hipStreamSynchronize(c->aux);
@@ -1563,7 +1602,22 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.capV = capV; a.capT = capT;
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
+	a.trace = nullptr;
+	a.dev_mode = 0;
+#ifdef MC33_DEV
+	a.dev_mode = env_u32("MC33_HIP_EMIT_DEV", 0);
+#endif
 	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 64u);
+#ifdef MC33_DEV
+	if (getenv("MC33_HIP_TRACE_EMIT")) {
+		(void)hipFree(c->trace_emit);
+		c->trace_emit = nullptr;
+		c->trace_emit_n = (uint64_t)blocks * 4;
+		HIP_TRY(hipMalloc(&c->trace_emit, c->trace_emit_n * 32));
+		HIP_TRY(hipMemsetAsync(c->trace_emit, 0, c->trace_emit_n * 32, c->stream));
+		a.trace = c->trace_emit;
+	}
+#endif
 	// The three emit passes are independent (V/N vs T, fast vs slow records) and each is bound by the
 	// latency of scattered reads, not by bandwidth: the vertex pass runs on a second stream beside the
 	// two triangle passes and joins before the end-of-call event.
@@ -1602,6 +1656,14 @@ static int fetch_counters(mc33hip_ctx *c) {
 	if (getenv("MC33_HIP_VERBOSE"))
 		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, non-empty row segments %u)\n", c->h_ctr->entry_cursor,
 		        c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->mask_cursor);
+	if (c->trace_emit && getenv("MC33_HIP_TRACE_EMIT")) {
+		void *h = malloc(c->trace_emit_n * 32);
+		if (h && hipMemcpy(h, c->trace_emit, c->trace_emit_n * 32, hipMemcpyDeviceToHost) == hipSuccess) {
+			FILE *f = fopen(getenv("MC33_HIP_TRACE_EMIT"), "wb");
+			if (f) { fwrite(h, 32, c->trace_emit_n, f); fclose(f); }
+		}
+		free(h);
+	}
 	if (c->trace_cells && getenv("MC33_HIP_TRACE_CELLS")) {
 		void *h = malloc(c->trace_cells_n * 32);
 		if (h && hipMemcpy(h, c->trace_cells, c->trace_cells_n * 32, hipMemcpyDeviceToHost) == hipSuccess) {
