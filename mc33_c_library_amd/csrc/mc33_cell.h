@@ -70,11 +70,6 @@ struct __attribute__((packed, aligned(sizeof(T)))) SamplePair {  // two consecut
 };
 
 template <typename T>
-struct __attribute__((packed, aligned(sizeof(T)))) SampleTriple {
-	T a, b, c;
-};
-
-template <typename T>
 struct GridView {  // pitched copy of _GRD.F in HBM: sample (x,y,z) at p[(z-z0)*slice + y*pitch + x]
 	const T *p;
 	uint32_t pitch;  // samples per row (>= nx+1)
@@ -877,7 +872,7 @@ MC33_HD void fast_owned_vertex(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint
 // planes, plane z+2 on both rows) - instead of 8 + 8 per vertex scattered single loads.  The arithmetic and
 // its order are those of vertex_on_edge (MC:990-1000, 1029-1039, 1175-1185).
 template <typename T>
-MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s, uint32_t dev_mode = 0, uint32_t dev_index = 0) {
+MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s) {
 	const uint32_t r5 = (en.w2 >> 20) & 15u, r6 = (en.w2 >> 24) & 15u, r10 = (en.w3 >> 8) & 15u;
 	if ((r5 & r6 & r10) == 15u) return;  // the cell creates no vertex
 	const SegCoord sc = segment_coord(c.P, s);
@@ -886,19 +881,12 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 	const uint32_t x = sc.xbase + (en.w0 & 0xFFu);
 	const Params &P = c.P;
 	const GridView<T> &G = c.G;
-	uint32_t vbase = c.seg_base[s].vbase + (en.w1 & 0xFFFFu);
-	if (dev_mode & 1u) vbase = dev_index * 3u + c.v_skip;  // (developer experiment: stores in record order)
+	const uint32_t vbase = c.seg_base[s].vbase + (en.w1 & 0xFFFFu);
 	const bool xin = x + 1 < P.nx, yin = y + 1 < P.ny, zin = z + 1 < P.nz;  // the outer neighbours exist
 	// F[row][col]: rows 0..3 = (y,z) (y+1,z) (y,z+1) (y+1,z+1); col = x, x+1, x+2
 	T F[4][3];
 	for (int r = 0; r < 4; r++) {
 		const uint32_t yy = y + (r & 1), zz = z + (r >> 1);
-		if (dev_mode & 2u) { F[r][0] = (T)(x + r); F[r][1] = (T)(y + 2 * r); F[r][2] = (T)(z + 1); continue; }  // (no sample loads)
-		if ((dev_mode & 4u) && xin) {  // (developer experiment: one 3-sample load per row)
-			const SampleTriple<T> q = *(const SampleTriple<T> *)(G.p + ((uint64_t)(zz - G.z0) * G.slice + (uint64_t)yy * G.pitch + x));
-			F[r][0] = q.a; F[r][1] = q.b; F[r][2] = q.c;
-			continue;
-		}
 		const SamplePair<T> q = G.pair(x, yy, zz);
 		F[r][0] = q.a;
 		F[r][1] = q.b;
@@ -907,7 +895,6 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 	// rows outside the cell: Y2[p][col] = (y+2, z+p), Z2[q][col] = (y+q, z+2); col = x, x+1
 	T Y2[2][2], Z2[2][2];
 	for (int q = 0; q < 2; q++) {
-		if (dev_mode & 2u) { Y2[q][0] = (T)x; Y2[q][1] = (T)(y + 1); Z2[q][0] = (T)z; Z2[q][1] = (T)(q + 3); continue; }
 		const SamplePair<T> yq = G.pair(x, yin ? y + 2 : y, z + q), zq = G.pair(x, y + q, zin ? z + 2 : z);
 		Y2[q][0] = yq.a; Y2[q][1] = yq.b;
 		Z2[q][0] = zq.a; Z2[q][1] = zq.b;
@@ -924,7 +911,7 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 		r[4] = yin ? 0.5f * (sample_diff(F[0][1], Y2[0][1]) * (1 - t) + sample_diff(F[2][1], Y2[1][1]) * t)
 		           : (v5 - v4) * (1 - t) + (v6 - v7) * t;
 		r[5] = v6 - v5;
-		if (!(dev_mode & 16u) || r[3] == (real_t)12345.678f) store_vertex(P, r, c.V, c.N, vbase + r5 - c.v_skip);
+		store_vertex(P, r, c.V, c.N, vbase + r5 - c.v_skip);
 	}
 	if (r6 != 15u) {  // edge 6: (x+1, y, z+1) -> (x+1, y+1, z+1)
 		const real_t t = v7 / (v7 - v6);
@@ -934,7 +921,7 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 		r[4] = v6 - v7;
 		r[5] = zin ? 0.5f * (sample_diff(F[0][1], Z2[0][1]) * (1 - t) + sample_diff(F[1][1], Z2[1][1]) * t)
 		           : (v7 - v4) * (1 - t) + (v6 - v5) * t;
-		if (!(dev_mode & 16u) || r[3] == (real_t)12345.678f) store_vertex(P, r, c.V, c.N, vbase + r6 - c.v_skip);
+		store_vertex(P, r, c.V, c.N, vbase + r6 - c.v_skip);
 	}
 	if (r10 != 15u) {  // edge 10: (x, y+1, z+1) -> (x+1, y+1, z+1)
 		const real_t t = v2 / (v2 - v6);
@@ -944,7 +931,7 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 		           : (v2 - v3) * (1 - t) + (v6 - v7) * t;
 		r[5] = zin ? 0.5f * (sample_diff(F[1][0], Z2[1][0]) * (1 - t) + sample_diff(F[1][1], Z2[1][1]) * t)
 		           : (v2 - v1) * (1 - t) + (v6 - v5) * t;
-		if (!(dev_mode & 16u) || r[3] == (real_t)12345.678f) store_vertex(P, r, c.V, c.N, vbase + r10 - c.v_skip);
+		store_vertex(P, r, c.V, c.N, vbase + r10 - c.v_skip);
 	}
 }
 

@@ -32,6 +32,7 @@
 #include <cstring>
 #include <mutex>
 #include <algorithm>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -158,12 +159,35 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
 	return u64(__builtin_amdgcn_readlane((uint32_t)v, l), __builtin_amdgcn_readlane((uint32_t)(v >> 32), l));
 }
 
+// Bit-row layouts.  A wave keeps the sign bits of a sample row of its tile in four 64-bit words (in lane r for row r).
+// With one sample per lane and load (S = 1) bit j of word k is sample x = 64 k + j: the STANDARD layout, the one every
+// other pass and every record in HBM uses.  Narrow samples are loaded several to a dword (S = 2 unsigned short, S = 4
+// unsigned char: a wave request is 256 bytes whatever the type), and the ballot over the lanes then collects every
+// S-th sample:
+//     S = 2: word 2 k' + q, bit j  <->  x = 128 k' + 2 j + q            S = 4: word q, bit j  <->  x = 4 j + q
+// The sweep tests for cut cells in that layout (the neighbour x + 1 of a bit is the same bit of the next word, or the
+// next bit of the first word of the group) and converts the rows to the standard layout only when a slice is handed
+// on - a third of the slices of a smooth field, one conversion per lane = per row.
+template <int S>
+__device__ __forceinline__ void succ_words(const uint64_t (&A)[4], uint64_t halo, uint64_t (&N)[4]) {  // N: the bits of the samples x + 1
+	if (S == 1) {
+#pragma unroll
+		for (int k = 0; k < 4; k++) N[k] = (A[k] >> 1) | ((k < 3 ? (A[k < 3 ? k + 1 : 3] & 1ull) : halo) << 63);
+	} else if (S == 2) {
+		N[0] = A[1]; N[1] = (A[0] >> 1) | ((A[2] & 1ull) << 63);
+		N[2] = A[3]; N[3] = (A[2] >> 1) | (halo << 63);
+	} else {
+		N[0] = A[1]; N[1] = A[2]; N[2] = A[3]; N[3] = (A[0] >> 1) | (halo << 63);
+	}
+}
+
 // cells of a tile slice cut by the surface: NOT (all 8 sign bits one) and NOT (all zero)  (MC:1860).
-// prev/cur: bit rows of planes z / z+1 (lane = sample row), *_h: halo-column bits.
+// prev/cur: bit rows of planes z / z+1 (lane = sample row), *_h: halo-column bits; everything in layout S.
+template <int S = 1>
 __device__ __forceinline__ void active_cells(const uint64_t (&prev)[4], const uint64_t (&cur)[4], uint32_t prev_h, uint32_t cur_h,
                                              const uint64_t (&valid)[4], bool rowvalid, uint64_t (&act)[4]) {
 	const uint32_t prev_hn = row_above(prev_h), cur_hn = row_above(cur_h);
-	uint64_t A[4], O[4];
+	uint64_t A[4], O[4], As[4], Os[4];
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
 		const uint64_t pn = row_above(prev[k]), cn = row_above(cur[k]);
@@ -171,12 +195,69 @@ __device__ __forceinline__ void active_cells(const uint64_t (&prev)[4], const ui
 		O[k] = prev[k] | pn | cur[k] | cn;
 	}
 	const uint64_t hA = prev_h & prev_hn & cur_h & cur_hn, hO = prev_h | prev_hn | cur_h | cur_hn;
+	succ_words<S>(A, hA, As);
+	succ_words<S>(O, hO, Os);
 #pragma unroll
-	for (int k = 0; k < 4; k++) {
-		const uint64_t nA = (k < 3) ? (A[k < 3 ? k + 1 : 3] & 1ull) : hA;
-		const uint64_t nO = (k < 3) ? (O[k < 3 ? k + 1 : 3] & 1ull) : hO;
-		const uint64_t As = (A[k] >> 1) | (nA << 63), Os = (O[k] >> 1) | (nO << 63);
-		act[k] = rowvalid ? (~((A[k] & As) | ~(O[k] | Os)) & valid[k]) : 0ull;
+	for (int k = 0; k < 4; k++) act[k] = rowvalid ? (~((A[k] & As[k]) | ~(O[k] | Os[k])) & valid[k]) : 0ull;
+}
+
+__device__ __forceinline__ uint64_t spread2(uint32_t v) {  // bit i -> bit 2 i
+	uint64_t x = v;
+	x = (x | x << 16) & 0x0000FFFF0000FFFFull; x = (x | x << 8) & 0x00FF00FF00FF00FFull; x = (x | x << 4) & 0x0F0F0F0F0F0F0F0Full;
+	x = (x | x << 2) & 0x3333333333333333ull; x = (x | x << 1) & 0x5555555555555555ull;
+	return x;
+}
+__device__ __forceinline__ uint64_t spread4(uint32_t v) {  // bit i (< 16) -> bit 4 i
+	uint64_t x = v & 0xFFFFu;
+	x = (x | x << 24) & 0x000000FF000000FFull; x = (x | x << 12) & 0x000F000F000F000Full; x = (x | x << 6) & 0x0303030303030303ull;
+	x = (x | x << 3) & 0x1111111111111111ull;
+	return x;
+}
+__device__ __forceinline__ uint32_t gather2(uint64_t x) {  // bit 2 i -> bit i
+	x &= 0x5555555555555555ull;
+	x = (x | x >> 1) & 0x3333333333333333ull; x = (x | x >> 2) & 0x0F0F0F0F0F0F0F0Full; x = (x | x >> 4) & 0x00FF00FF00FF00FFull;
+	x = (x | x >> 8) & 0x0000FFFF0000FFFFull; x = (x | x >> 16) & 0x00000000FFFFFFFFull;
+	return (uint32_t)x;
+}
+__device__ __forceinline__ uint32_t gather4(uint64_t x) {  // bit 4 i -> bit i (16 bits)
+	x &= 0x1111111111111111ull;
+	x = (x | x >> 3) & 0x0303030303030303ull; x = (x | x >> 6) & 0x000F000F000F000Full; x = (x | x >> 12) & 0x000000FF000000FFull;
+	x = (x | x >> 24) & 0xFFFFull;
+	return (uint32_t)x;
+}
+template <int S>
+__device__ __forceinline__ void to_standard(const uint64_t (&w)[4], uint64_t (&o)[4]) {
+	if (S == 1) {
+#pragma unroll
+		for (int k = 0; k < 4; k++) o[k] = w[k];
+	} else if (S == 2) {
+#pragma unroll
+		for (int g = 0; g < 2; g++) {
+			o[2 * g] = spread2((uint32_t)w[2 * g]) | spread2((uint32_t)w[2 * g + 1]) << 1;
+			o[2 * g + 1] = spread2((uint32_t)(w[2 * g] >> 32)) | spread2((uint32_t)(w[2 * g + 1] >> 32)) << 1;
+		}
+	} else {
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			o[q] = spread4((uint32_t)(w[0] >> (16 * q))) | spread4((uint32_t)(w[1] >> (16 * q))) << 1 | spread4((uint32_t)(w[2] >> (16 * q))) << 2 |
+			       spread4((uint32_t)(w[3] >> (16 * q))) << 3;
+	}
+}
+template <int S>
+__device__ __forceinline__ void from_standard(const uint64_t (&w)[4], uint64_t (&o)[4]) {
+	if (S == 1) {
+#pragma unroll
+		for (int k = 0; k < 4; k++) o[k] = w[k];
+	} else if (S == 2) {
+#pragma unroll
+		for (int g = 0; g < 2; g++) {
+			o[2 * g] = (uint64_t)gather2(w[2 * g]) | (uint64_t)gather2(w[2 * g + 1]) << 32;
+			o[2 * g + 1] = (uint64_t)gather2(w[2 * g] >> 1) | (uint64_t)gather2(w[2 * g + 1] >> 1) << 32;
+		}
+	} else {
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			o[q] = (uint64_t)gather4(w[0] >> q) | (uint64_t)gather4(w[1] >> q) << 16 | (uint64_t)gather4(w[2] >> q) << 32 | (uint64_t)gather4(w[3] >> q) << 48;
 	}
 }
 
@@ -244,7 +325,21 @@ __device__ __forceinline__ void hand_over_slice(const SweepArgs &a, uint64_t slo
 // below is put together by k_boundary from the bit rows both tiles leave behind (2 KiB each) - re-reading that
 // plane instead cost 1/depth of the traffic (6 % at depth 16).
 // ---------------------------------------------------------------------------------------------------
+#if defined(MC33_GRD_U16)
+constexpr int SWEEP_PACK = 2;  // samples per dword
+#elif defined(MC33_GRD_U8)
+constexpr int SWEEP_PACK = 4;
+#else
+constexpr int SWEEP_PACK = 1;
+#endif
+
+// S: samples per lane and load.  S = 1: every lane loads single samples (all types); S = SWEEP_PACK > 1: dwords of 2
+// unsigned shorts / 4 unsigned chars - needs rows that start on a dword boundary (the host checks), and makes a batch
+// 8 / 16 sample rows instead of 4, so that a wave keeps the same 16 x 256 bytes in flight.
+template <int S>
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
+	constexpr int LPR = 4 / S;    // loads per sample row
+	constexpr int RB = 16 / LPR;  // sample rows per batch
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wtile = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, in an SGPR
 	if (wtile >= a.ntiles) return;
@@ -259,20 +354,26 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	const bool has_above = z_hi < a.z_end;
 	const real_t iso = P.iso;
 
-	// per-lane byte offsets of its four samples inside a row (clamped into the row: bits of samples
-	// beyond the grid belong to cells that the valid masks remove)
+	// per-lane byte offsets of its loads inside a row (clamped into the row: bits of samples beyond the grid belong
+	// to cells that the valid masks remove)
 	const uint32_t rowbytes = a.G.pitch * (uint32_t)sizeof(sample_t);
-	uint32_t xo[4];
+	uint32_t xo[LPR];
 #pragma unroll
-	for (int k = 0; k < 4; k++) xo[k] = min(xbase + 64u * k + lane, P.nx) * (uint32_t)sizeof(sample_t);
+	for (int k = 0; k < LPR; k++)
+		xo[k] = S == 1 ? min(xbase + 64u * k + lane, P.nx) * (uint32_t)sizeof(sample_t)
+		               : min(xbase + (256u / LPR) * k + (uint32_t)S * lane, P.nx & ~(uint32_t)(S - 1)) * (uint32_t)sizeof(sample_t);
 	uint64_t valid[4];
-	valid_masks(xbase, P.nx, valid);
+	{
+		uint64_t vstd[4];
+		valid_masks(xbase, P.nx, vstd);
+		from_standard<S>(vstd, valid);
+	}
 	const bool rowvalid = lane < 63u && y0 + lane < P.ny;
 	// halo column: lane r needs the first sample of the next segment in row r; it is fetched by the batch
-	// that holds row r (4 lanes per batch; the other lanes aim outside the descriptor: no memory access)
+	// that holds row r (RB lanes per batch; the other lanes aim outside the descriptor: no memory access)
 	const uint32_t xh = min(lane, nrows - 1) * rowbytes + min(xbase + SEG_CELLS, P.nx) * (uint32_t)sizeof(sample_t);
 
-	// sign bits of the tile: word k of sample row r lives in lane r.  *_h: the halo sample's bit;
+	// sign bits of the tile: word k of sample row r lives in lane r (layout S).  *_h: the halo sample's bit;
 	// *_z (wave-uniform): "some sample of this plane of the tile (halo included) equals the isovalue"
 	uint64_t cur[4], prev[4] = {0, 0, 0, 0};
 	uint32_t c_lo[4] = {0, 0, 0, 0}, c_hi[4] = {0, 0, 0, 0};
@@ -281,11 +382,11 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	bool cur_written = false, prev_written = false;  // the plane's bit rows are already in slice_bits
 	real_t zmin = 1;  // min |iso - F| over the lane's samples of the plane being assembled
 
-	// The tile is consumed as a linear stream of batches of 4 sample rows (16 coalesced 256-byte loads per
+	// The tile is consumed as a linear stream of batches of RB sample rows (16 coalesced 256-byte loads per
 	// wave), plane after plane.  Two register buffers: the loads of batch t+1 are in flight while batch t
 	// is turned into bit rows.  Loads go through a buffer descriptor per plane (scalar base + 32-bit
 	// offsets, hardware range check).
-	const uint32_t NB = (nrows + 3u) / 4u;
+	const uint32_t NB = (nrows + (uint32_t)RB - 1u) / (uint32_t)RB;
 	const uint32_t T = (z_hi - pl0 + 1u) * NB;
 	const uint32_t tile_bytes = nrows * rowbytes;
 #if defined(MC33_GRD_U16)
@@ -299,31 +400,41 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 #else
 #define MC33_LOAD(rs, vo, so) (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0)))
 #endif
+	typedef typename std::conditional<S == 1, real_t, uint32_t>::type raw_t;  // what a load leaves in a register
 	// every batch is exactly 17 loads, whatever the position in the tile (the wait counts the compiler
 	// derives are then exact and the prefetched batch really stays in flight)
-	auto issue = [&](real_t (&d)[16], real_t &hv, uint32_t p, uint32_t bi) {
+	auto issue = [&](raw_t (&d)[16], real_t &hv, uint32_t p, uint32_t bi) {
 		const sample_t *base = a.G.p + (uint64_t)(p - a.G.z0) * a.G.slice + (uint64_t)y0 * a.G.pitch;
 		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, tile_bytes, 0x00020000);
-		const uint32_t r = bi * 4u;
+		const uint32_t r = bi * (uint32_t)RB;
 #pragma unroll
-		for (int rr = 0; rr < 4; rr++) {
+		for (int rr = 0; rr < RB; rr++) {
 			const uint32_t so = min(r + rr, nrows - 1) * rowbytes;
 #pragma unroll
-			for (int k = 0; k < 4; k++) d[rr * 4 + k] = MC33_LOAD(rs, xo[k], so);
+			for (int k = 0; k < LPR; k++) {
+				if constexpr (S == 1) d[rr * LPR + k] = MC33_LOAD(rs, xo[k], so);
+				else d[rr * LPR + k] = __builtin_amdgcn_raw_buffer_load_b32(rs, xo[k], so, 0);
+			}
 		}
-		hv = MC33_LOAD(rs, (lane >> 2) == bi ? xh : 0xFFFFFFF0u, 0u);
+		hv = MC33_LOAD(rs, (lane / (uint32_t)RB) == bi ? xh : 0xFFFFFFF0u, 0u);
+	};
+	// the four samples of row rr of a batch in word order of layout S
+	auto sample = [&](const raw_t (&dd)[16], int rr, int k) -> real_t {
+		if constexpr (S == 1) return dd[rr * 4 + k];
+		else if constexpr (S == 2) return (real_t)((dd[rr * 2 + (k >> 1)] >> (16 * (k & 1))) & 0xFFFFu);
+		else return (real_t)((dd[rr] >> (8 * k)) & 0xFFu);
 	};
 
 	real_t halo = 0;  // lane r: halo sample of row r of the plane being assembled
-	auto process = [&](const real_t (&dd)[16], const real_t &hv, uint32_t p, uint32_t bi) {
-		const uint32_t r = bi * 4u;
-		halo = (lane >> 2) == bi ? hv : halo;
+	auto process = [&](const raw_t (&dd)[16], const real_t &hv, uint32_t p, uint32_t bi) {
+		const uint32_t r = bi * (uint32_t)RB;
+		halo = (lane / (uint32_t)RB) == bi ? hv : halo;
 #pragma unroll
-		for (int rr = 0; rr < 4; rr++) {
+		for (int rr = 0; rr < RB; rr++) {
 			uint32_t m[8];
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
-				const real_t d = iso - dd[rr * 4 + k];                   // MC:1852-1855
+				const real_t d = iso - sample(dd, rr, k);                 // MC:1852-1855
 				uint64_t bb = __ballot(sign_of(d) != 0);                  // MC:1856-1859 (sign bit)
 #ifdef MC33_NAN_SAMPLES
 				bb ^= __ballot(d != d);  // NaN sample: the sign the reference sees is the NaN's own (see iso_diff)
@@ -357,10 +468,12 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 			cur_z = __ballot(zmin == 0) != 0ull;  // some sample of this plane of the tile equals the isovalue
 			zmin = 1;
 		}
-		auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary
+		auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary (standard layout)
+			uint64_t w[4];
+			to_standard<S>(cur, w);
 			uint4 *e = a.edge_bits + ((uint64_t)wtile * 2u + which) * 128u + lane;
-			e[0] = uint4{(uint32_t)cur[0], (uint32_t)(cur[0] >> 32), (uint32_t)cur[1], (uint32_t)(cur[1] >> 32)};
-			e[64] = uint4{(uint32_t)cur[2], (uint32_t)(cur[2] >> 32), (uint32_t)cur[3], (uint32_t)(cur[3] >> 32)};
+			e[0] = uint4{(uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32)};
+			e[64] = uint4{(uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32)};
 			const uint64_t bh = __ballot(cur_h != 0);
 			if (lane == 0) a.edge_hdr[(uint64_t)wtile * 2u + which] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), cur_z ? 1u : 0u, 0u};
 		};
@@ -369,9 +482,12 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 			if (p == pl0 && pl0 != z_lo) leave_edge(0);
 			if (p > pl0) {
 				uint64_t act[4];
-				active_cells(prev, cur, prev_h, cur_h, valid, rowvalid, act);
+				active_cells<S>(prev, cur, prev_h, cur_h, valid, rowvalid, act);
 				if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(MC33_DEBUG_BITS(a) & 16u)) {  // wave-uniform: hand the slice to k_cells
-					hand_over_slice(a, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), prev, cur,
+					uint64_t ps[4], cs[4];  // (the counts only need popcounts of act: any layout)
+					to_standard<S>(prev, ps);
+					to_standard<S>(cur, cs);
+					hand_over_slice(a, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), ps, cs,
 					                !prev_written, true, __ballot(prev_h != 0), __ballot(cur_h != 0), prev_z || cur_z, act);
 					cur_written = true;
 				}
@@ -386,7 +502,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		cur_written = false;
 	};
 
-	real_t dA[16], dB[16], hA = 0, hB = 0;
+	raw_t dA[16], dB[16];
+	real_t hA = 0, hB = 0;
 	uint32_t ip = pl0, ib = 0, pp = pl0, pb = 0;  // (plane, batch) of the next issue / of the next process
 	// past the end of the tile the prefetch simply re-reads the last batch (it is never processed)
 #define MC33_ADV(p_, b_) do { if (++(b_) == NB) { (b_) = 0; ++(p_); } } while (0)
@@ -868,8 +985,6 @@ struct EmitArgs {
 	uint64_t capV, capT;
 	uint64_t ghost_segs;  // row segments of the ghost slice (0 without ghost)
 	uint32_t id_base;
-	uint32_t dev_mode;          // -DMC33_DEV + MC33_HIP_EMIT_DEV: experiments (wrong output)
-	unsigned long long *trace;  // -DMC33_DEV + MC33_HIP_TRACE_EMIT: per wave of the vertex pass {start, records in, samples in, end}
 };
 
 // The fast emit passes take the records in storage order, which k_slots made (4 slices of a tile column, next
@@ -913,39 +1028,6 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 	EmitCtx<sample_t> c = a.c;
 	if (!emit_prepare(a, c, ctr)) return;
 	const XcdWalk w(ctr.entry_cursor);
-#ifdef MC33_DEV
-	if (a.trace) {  // phase stamps (s_memrealtime, 100 MHz); the waits change the schedule a little
-		const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-		unsigned long long t1 = 0, t2 = 0;
-		for (uint32_t e = w.first; e < w.end; e += w.stride) {
-			const Entry en = c.entries[e];
-			const uint32_t sg = c.entry_seg[e];
-			__builtin_amdgcn_s_waitcnt(0);
-			t1 = __builtin_amdgcn_s_memrealtime() + (en.w0 & 0u);
-			const SegCoord sc = segment_coord(c.P, sg);
-			float acc = 0;  // the sample reads of emit_fast_vertices, approximately: 12 scattered loads
-			const uint32_t x = sc.xbase + (en.w0 & 0xFFu);
-			for (int r = 0; r < 4; r++) { const auto q = c.G.pair(x, sc.y + (r & 1), sc.z + (r >> 1)); acc += (float)q.a + (float)q.b + (float)c.G.at(x + 2, sc.y + (r & 1), sc.z + (r >> 1)); }
-			acc += (float)c.seg_base[sg].vbase;
-			__builtin_amdgcn_s_waitcnt(0);
-			t2 = __builtin_amdgcn_s_memrealtime() + (acc == 12345.f ? 1u : 0u);
-			if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, sg);
-		}
-		__builtin_amdgcn_s_waitcnt(0);
-		if ((threadIdx.x & 63u) == 0) {
-			unsigned long long *tr = a.trace + 4ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
-			tr[0] = t0; tr[1] = t1; tr[2] = t2; tr[3] = __builtin_amdgcn_s_memrealtime();
-		}
-		return;
-	}
-	if (a.dev_mode) {
-		for (uint32_t e = w.first; e < w.end; e += w.stride) {
-			const Entry en = c.entries[e];
-			if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, c.entry_seg[e], a.dev_mode, e);
-		}
-		return;
-	}
-#endif
 	for (uint32_t e = w.first; e < w.end; e += w.stride) {
 		const Entry en = c.entries[e];
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, c.entry_seg[e]);
@@ -1047,8 +1129,6 @@ struct mc33hip_ctx {
 	uint64_t trace_waves;
 	unsigned long long *trace_cells;  // (MC33_HIP_TRACE_CELLS)
 	uint64_t trace_cells_n;
-	unsigned long long *trace_emit;   // (MC33_HIP_TRACE_EMIT, -DMC33_DEV builds)
-	uint64_t trace_emit_n;
 	// state of the last count
 	bool counted;
 	Params P;
@@ -1170,7 +1250,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->d_tiles);
 	(void)hipFree(c->slot_base); (void)hipFree(c->slot_part);
 	(void)hipFree(c->d_bounds); (void)hipFree(c->edge_bits); (void)hipFree(c->edge_hdr);
-	(void)hipFree(c->trace); (void)hipFree(c->trace_cells); (void)hipFree(c->trace_emit);
+	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	if (c->aux) (void)hipStreamSynchronize(c->aux);
@@ -1389,7 +1469,7 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 	if (c->d_tiles && c->tiles_zs == zs && c->tiles_ze == ze && c->tiles_depth == depth) return 0;
 	if (!c->resident_blocks) {
 		int per_cu = 0, cus = 0;
-		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep, 256, 0));
+		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<1>, 256, 0));
 		HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
 		const uint32_t want = env_u32("MC33_HIP_SWEEP_BLOCKS_PER_CU", 4);
 		c->resident_blocks = (uint32_t)std::max(1, cus) * (uint32_t)std::max(1, std::min(per_cu, (int)want));
@@ -1543,7 +1623,12 @@ static int enqueue_count(mc33hip_ctx *c) {
 	// nothing is cleared between extractions: headers carry the epoch, k_slots resets the counters and the
 	// partial sums of the next call, k_cells writes every row segment count of the range
 	if (c->timing_level > 0) HIP_TRY(hipEventRecord(c->ev[0], st));
-	hipLaunchKernelGGL(k_sweep, dim3((uint32_t)blocks), dim3(256), 0, st, a);
+	// narrow samples are loaded as dwords when every row of the grid starts on a dword boundary (always true for the
+	// library's own pitched copy; a caller's device buffer may have any pitch)
+	const bool packed = SWEEP_PACK > 1 && !env_u32("MC33_HIP_NO_PACK", 0) && ((uintptr_t)c->d_grid % 4u) == 0 &&
+	                    (c->pitch * sizeof(sample_t)) % 4u == 0 && (c->slice * sizeof(sample_t)) % 4u == 0;
+	if (packed) hipLaunchKernelGGL(k_sweep<SWEEP_PACK>, dim3((uint32_t)blocks), dim3(256), 0, st, a);
+	else hipLaunchKernelGGL(k_sweep<1>, dim3((uint32_t)blocks), dim3(256), 0, st, a);
 	HIP_TRY(hipGetLastError());
 	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[1], st));
 	if (c->nbounds && !(MC33_DEBUG_BITS(a) & 2u)) hipLaunchKernelGGL(k_boundary, dim3((uint32_t)((c->nbounds + 3) / 4)), dim3(256), 0, st, a, c->d_bounds, (uint32_t)c->nbounds);
@@ -1602,22 +1687,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.capV = capV; a.capT = capT;
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
-	a.trace = nullptr;
-	a.dev_mode = 0;
-#ifdef MC33_DEV
-	a.dev_mode = env_u32("MC33_HIP_EMIT_DEV", 0);
-#endif
 	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 64u);
-#ifdef MC33_DEV
-	if (getenv("MC33_HIP_TRACE_EMIT")) {
-		(void)hipFree(c->trace_emit);
-		c->trace_emit = nullptr;
-		c->trace_emit_n = (uint64_t)blocks * 4;
-		HIP_TRY(hipMalloc(&c->trace_emit, c->trace_emit_n * 32));
-		HIP_TRY(hipMemsetAsync(c->trace_emit, 0, c->trace_emit_n * 32, c->stream));
-		a.trace = c->trace_emit;
-	}
-#endif
 	// The three emit passes are independent (V/N vs T, fast vs slow records) and each is bound by the
 	// latency of scattered reads, not by bandwidth: the vertex pass runs on a second stream beside the
 	// two triangle passes and joins before the end-of-call event.
@@ -1656,14 +1726,6 @@ static int fetch_counters(mc33hip_ctx *c) {
 	if (getenv("MC33_HIP_VERBOSE"))
 		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, non-empty row segments %u)\n", c->h_ctr->entry_cursor,
 		        c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->mask_cursor);
-	if (c->trace_emit && getenv("MC33_HIP_TRACE_EMIT")) {
-		void *h = malloc(c->trace_emit_n * 32);
-		if (h && hipMemcpy(h, c->trace_emit, c->trace_emit_n * 32, hipMemcpyDeviceToHost) == hipSuccess) {
-			FILE *f = fopen(getenv("MC33_HIP_TRACE_EMIT"), "wb");
-			if (f) { fwrite(h, 32, c->trace_emit_n, f); fclose(f); }
-		}
-		free(h);
-	}
 	if (c->trace_cells && getenv("MC33_HIP_TRACE_CELLS")) {
 		void *h = malloc(c->trace_cells_n * 32);
 		if (h && hipMemcpy(h, c->trace_cells, c->trace_cells_n * 32, hipMemcpyDeviceToHost) == hipSuccess) {

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Developer tool (-DMC33_DEV build in tools/_dev): sweep time per sample type with the developer switches of k_sweep
+(MC33_HIP_DEBUG=2: the read stream alone; 16: stream + cut-cell test, nothing handed on)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from mc33_c_library_amd import api, fields  # noqa: E402
+
+dev = torch.device("cuda:0")
+which = sys.argv[1] if len(sys.argv) > 1 else "u16"
+if which == "f32":
+    t, r0, d = fields.cos_field_cube(1024, dev)
+    iso = 0.0
+else:
+    t = fields.cos_field_u16(1024, 1024, 1024, dev)
+    iso = 32768.5
+g = api.DeviceGrid(t)
+best = 1e9
+for _ in range(8):
+    g.count(iso)
+    best = min(best, g.timing().sweep_ms)
+gb = t.numel() * t.element_size() / 1e9
+print("%s DEBUG=%s NO_PACK=%s: sweep %.3f ms  %.0f GB/s" % (which, os.environ.get("MC33_HIP_DEBUG", "0"), os.environ.get("MC33_HIP_NO_PACK", "0"), best, gb / best * 1e3))
