@@ -119,7 +119,7 @@ struct SweepArgs {
 	                         // rows.  A plane is written once, by the first slice with cut cells that touches it: writes are
 	                         // what the sweep pays for (100 MB of them cost as much as 600 MB of reads), and consecutive slices
 	                         // share a plane
-	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz)
+	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz), {start, end} (s_memtime, shader clock)
 	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: rows << 32 | cells of the slices of that chunk
 	uint32_t epoch;          // number of this extraction (stamped into the slice headers)
 	uint32_t z_end;          // end of the classified range: tiles that reach it have no tile above
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	const uint32_t yt = tile.yt, seg = tile.seg;
 	const Params &P = a.P;
 	const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+	const unsigned long long c_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
 	const uint32_t nrows = min(64u, P.ny + 1 - y0);  // sample rows of this tile
 	const uint32_t z_lo = tile.z_lo, z_hi = tile.z_hi;
@@ -516,8 +517,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		if (t + 1 < T) { process(dB, hB, pp, pb); MC33_ADV(pp, pb); }
 	}
 	if (a.trace && lane == 0) {
-		unsigned long long *tr = a.trace + 2ull * wtile;
-		tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
+		unsigned long long *tr = a.trace + 4ull * wtile;
+		tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime(); tr[2] = c_start; tr[3] = __builtin_amdgcn_s_memtime();
 	}
 #undef MC33_ADV_ISSUE
 #undef MC33_ADV
@@ -1616,8 +1617,8 @@ static int enqueue_count(mc33hip_ctx *c) {
 		(void)hipFree(c->trace);
 		c->trace = nullptr;
 		c->trace_waves = blocks * 4;
-		HIP_TRY(hipMalloc(&c->trace, c->trace_waves * 16));
-		HIP_TRY(hipMemsetAsync(c->trace, 0, c->trace_waves * 16, st));
+		HIP_TRY(hipMalloc(&c->trace, c->trace_waves * 32));
+		HIP_TRY(hipMemsetAsync(c->trace, 0, c->trace_waves * 32, st));
 		a.trace = c->trace;
 	}
 	// nothing is cleared between extractions: headers carry the epoch, k_slots resets the counters and the
@@ -1735,10 +1736,10 @@ static int fetch_counters(mc33hip_ctx *c) {
 		free(h);
 	}
 	if (c->trace && getenv("MC33_HIP_TRACE_FILE")) {  // developer tracing: per-wave stamps of the last sweep
-		void *h = malloc(c->trace_waves * 16);
-		if (h && hipMemcpy(h, c->trace, c->trace_waves * 16, hipMemcpyDeviceToHost) == hipSuccess) {
+		void *h = malloc(c->trace_waves * 32);
+		if (h && hipMemcpy(h, c->trace, c->trace_waves * 32, hipMemcpyDeviceToHost) == hipSuccess) {
 			FILE *f = fopen(getenv("MC33_HIP_TRACE_FILE"), "wb");
-			if (f) { fwrite(h, 16, c->trace_waves, f); fclose(f); }
+			if (f) { fwrite(h, 32, c->trace_waves, f); fclose(f); }
 		}
 		free(h);
 	}

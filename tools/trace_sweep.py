@@ -27,7 +27,7 @@ for _ in range(3):
     cnt = g.count(0.0)
 torch.cuda.synchronize()
 print("nV", cnt.nV, "nT", cnt.nT, "timing", g.timing())
-t = np.fromfile(out, dtype=np.uint64).reshape(-1, 2).astype(np.int64)
+t = np.fromfile(out, dtype=np.uint64).reshape(-1, 4).astype(np.int64)
 t = t[t[:, 1] > 0]
 t0 = t[:, 0].min()
 s = (t[:, 0] - t0) / 100.0  # us (100 MHz)
