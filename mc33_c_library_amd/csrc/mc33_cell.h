@@ -667,13 +667,25 @@ inline void build_fast_table(const uint16_t *lut, uint32_t *fast /*[256]*/) {
 // Directory of the row segments.  A row segment = the cells (x in [256 s, 256 s + 256), y, z).  Records
 // are STORED in the order [z][s][y] (the 63 rows a wave handles are contiguous: coalesced writes), while
 // the prefix sums run over them in the reference's sweep order [z][y][s] (segment_sweep_to_store).
-struct SegDir {
-	uint32_t first;    // first work record of the segment
-	uint32_t nent;     // number of records (bit 31: the sweep left cells for the slow kernel)
-	uint32_t maskidx;  // seg_mask[4*maskidx .. +3]: which of the 256 cells are active, 64 per word
-	uint32_t pre;      // active cells in words 0 | 0..1 | 0..2 (one byte each): record index of a cell is
-	                   // first + (bytes of pre for its word) + popcount(lower bits of its word)
+struct alignas(64) SegDir {
+	// One cache line per row segment, laid out so that ONE 16-byte read answers "which record is cell x": for each of
+	// the four 64-cell words k of the segment
+	//   q[k] = { activity mask of the word (lo, hi), index of the first work record of the word's cells, nent }
+	// nent = number of records of the whole segment (bit 31: the sweep left cells for the slow kernel).  Written only
+	// for segments that hold records; nobody looks at the others.
+	uint32_t q[4][4];
 };
+MC33_HD uint32_t segdir_first(const SegDir &d) { return d.q[0][2]; }
+MC33_HD uint32_t segdir_nent(const SegDir &d) { return d.q[0][3]; }
+MC33_HD SegDir make_segdir(uint32_t first, uint32_t nent_flags, const uint64_t *mask /*[4]*/) {
+	SegDir d;
+	uint32_t at = first;
+	for (int k = 0; k < 4; k++) {
+		d.q[k][0] = (uint32_t)mask[k]; d.q[k][1] = (uint32_t)(mask[k] >> 32); d.q[k][2] = at; d.q[k][3] = nent_flags;
+		at += (uint32_t)__builtin_popcountll(mask[k]);
+	}
+	return d;
+}
 struct SegBase {
 	uint32_t vbase, tbase;  // exclusive scans of the per-segment counts, in sweep order
 };
@@ -699,7 +711,6 @@ MC33_HD SegCoord segment_coord(const Params &P, uint32_t s) {
 	c.z = t / P.nseg + P.zs;
 	return c;
 }
-MC33_HD uint32_t pack_prefix(uint32_t n0, uint32_t n1, uint32_t n2) { return n0 | (n0 + n1) << 8 | (n0 + n1 + n2) << 16; }
 
 template <typename T>
 struct EmitCtx {
@@ -708,7 +719,6 @@ struct EmitCtx {
 	GridView<T> G;
 	const SegBase *seg_base;
 	const SegDir *seg_dir;
-	const uint64_t *seg_mask;
 	const Entry *entries;
 	const uint32_t *entry_seg;  // row segment of each entry
 	real_t *V;
@@ -723,19 +733,26 @@ struct EmitCtx {
 // per-segment counts packed in one word: vertices (<= 13*256) | triangles (<= 12*256) << 16
 MC33_HD uint32_t seg_pack(uint32_t nv, uint32_t nt) { return nv | nt << 16; }
 
-// work record of the active cell (x,y,z), through the directory (no search: the segment's activity mask
-// gives the rank of the cell among the segment's records)
-MC33_HD uint32_t record_rank(const SegDir &d, uint64_t word, uint32_t xl) {
-	const uint32_t k = xl >> 6;
-	const uint32_t before = k ? (d.pre >> (8 * (k - 1))) & 0xFFu : 0u;
-	return d.first + before + (uint32_t)__builtin_popcountll(word & ((1ull << (xl & 63u)) - 1ull));
+// work record of the active cell (x,y,z), through the directory (no search: the activity mask of the cell's word
+// gives the rank of the cell among the word's records); w = the directory word q[xl >> 6] of the cell's row segment
+struct DirWord {
+	uint32_t mlo, mhi, first, nent;
+};
+template <typename T>
+MC33_HD DirWord dir_word(const EmitCtx<T> &c, uint64_t s, uint32_t xl) {
+	const uint32_t *q = c.seg_dir[s].q[xl >> 6];
+	return DirWord{q[0], q[1], q[2], q[3]};
+}
+MC33_HD uint32_t record_rank(const DirWord &w, uint32_t xl) {
+	const uint64_t m = (uint64_t)w.mhi << 32 | w.mlo;
+	return w.first + (uint32_t)__builtin_popcountll(m & ((1ull << (xl & 63u)) - 1ull));
 }
 template <typename T>
 MC33_HD uint32_t find_record(const EmitCtx<T> &c, uint64_t s, uint32_t xl) {
-	const SegDir d = c.seg_dir[s];
-	const uint64_t word = c.seg_mask[4ull * d.maskidx + (xl >> 6)];
-	if (!((word >> (xl & 63u)) & 1ull)) return NO_ID;
-	return record_rank(d, word, xl);
+	const DirWord w = dir_word(c, s, xl);
+	const uint64_t m = (uint64_t)w.mhi << 32 | w.mlo;
+	if (!((m >> (xl & 63u)) & 1ull)) return NO_ID;
+	return record_rank(w, xl);
 }
 
 // id of the vertex on a grid edge, through the owner's entry (emit pass).  w: scratch for 8 values.
@@ -941,8 +958,8 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 //             o3 (x,y,z-1): 4->6, 9->10 | o4 (x,y-1,z): 7->5, 11->10 | o5 (x,y-1,z-1): 8->10
 // They sit in three other row segments - A = (y, z-1): o3 and, one record before it, o0; B = (y-1, z): o4, o2;
 // C = (y-1, z-1): o5 - and o1 is the record right before this cell's own.  All directory records are fetched
-// together, then the three activity-mask words, then the (at most five) work records: three dependent
-// round trips.  Neighbours that are not needed are redirected to this cell's own records (valid, cached
+// together (one 16-byte word each: the activity mask of the cell's 64-cell word and the index of its first record), then
+// the (at most five) work records: two dependent round trips.  Neighbours that are not needed are redirected to this cell's own records (valid, cached
 // addresses), so the loads carry no control flow.  The edges have no end point equal to the isovalue (they
 // are edges of a fast cell), so their owners created regular vertices: no alias to follow.
 template <typename T>
@@ -965,18 +982,17 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 		// segments A, B, C (index 0..2); x-1 lies in the same segments as x
 		const bool needseg[3] = {need[0] || need[3], need[2] || need[4], need[5]};
 		const uint32_t sdy[3] = {0, 1, 1}, sdz[3] = {1, 0, 1};
-		SegDir sd[3];
+		DirWord sd[3];
 		uint32_t svb[3];
-		for (int g = 0; g < 3; g++) {  // round trip 1
+		for (int g = 0; g < 3; g++) {  // round trip 1: one 16-byte directory word per segment
 			const uint64_t gs = needseg[g] ? segment_index(c.P, x, y - sdy[g], z - sdz[g]) : (uint64_t)s;
-			sd[g] = c.seg_dir[gs];
+			sd[g] = dir_word(c, gs, xl);
 			svb[g] = c.seg_base[gs].vbase;
 		}
 		const Entry prev = c.entries[need[1] ? self_index - 1 : self_index];  // o1: the cell x-1 is active whenever needed
 		uint32_t below[3];
-		for (int g = 0; g < 3; g++)  // round trip 2: records of the segment below x
-			below[g] = record_rank(sd[g], c.seg_mask[4ull * sd[g].maskidx + (xl >> 6)], xl);
-		// round trip 3: the records (x-1 is the record before x's position, it is active whenever needed)
+		for (int g = 0; g < 3; g++) below[g] = record_rank(sd[g], xl);  // the record of x in that segment (or where it would be)
+		// round trip 2: the records (x-1 is the record before x's position, it is active whenever needed)
 		oe[3] = c.entries[need[3] ? below[0] : self_index];
 		oe[0] = c.entries[need[0] ? below[0] - 1 : self_index];
 		oe[4] = c.entries[need[4] ? below[1] : self_index];
@@ -991,9 +1007,9 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 			const uint32_t ox = x - odx[o];
 			const uint64_t os = need[o] ? segment_index(c.P, ox, y - ody[o], z - odz[o]) : (uint64_t)s;
 			const uint32_t oxl = need[o] ? ox % SEG_CELLS : xl;
-			const SegDir d = c.seg_dir[os];
+			const DirWord d = dir_word(c, os, oxl);
 			ovb[o] = c.seg_base[os].vbase;
-			oe[o] = c.entries[need[o] ? record_rank(d, c.seg_mask[4ull * d.maskidx + (oxl >> 6)], oxl) : self_index];
+			oe[o] = c.entries[need[o] ? record_rank(d, oxl) : self_index];
 		}
 	}
 	uint32_t ob[6];

@@ -633,7 +633,6 @@ struct CellsArgs {
 	const uint2 *slot_base;  // [slice_slot]: {first work record, first mask record} (k_slots)
 	uint32_t *seg_cnt;
 	SegDir *seg_dir;
-	uint64_t *seg_mask;
 	Entry *entries;
 	uint32_t *entry_seg;
 	uint32_t *slow_list, *dirty_list;
@@ -712,7 +711,6 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	}
 	const uint32_t c0 = __popcll(act[0]), c1 = __popcll(act[1]), c2 = __popcll(act[2]);
 	const uint32_t cnt = c0 + c1 + c2 + __popcll(act[3]);
-	const uint64_t havem = __ballot(cnt != 0);
 	uint32_t incl = cnt;  // inclusive prefix of the per-row counts over the lanes
 #pragma unroll
 	for (int dlt = 1; dlt < 64; dlt <<= 1) {
@@ -721,7 +719,7 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	}
 	const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
 	const unsigned long long t_bits = a.trace ? __builtin_amdgcn_s_memrealtime() + (total & 0u) : 0ull;
-	const uint32_t ebase = base.x, mbase = base.y;
+	const uint32_t ebase = base.x;
 
 	// rows whose cells cannot take the fast path: on the y = 0 / z = 0 faces (extra owned edges), or in a
 	// tile plane pair that holds a sample equal to the isovalue
@@ -732,12 +730,6 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	L.run[lane] = 0;
 	L.slowrow[lane] = (y == 0 || planeslow) ? 1u : 0u;  // becomes 2 when a cell of the row went to the slow list
 	const uint32_t first = ebase + incl - cnt;
-	const uint32_t maskidx = mbase + (uint32_t)__popcll(havem & ((1ull << lane) - 1ull));
-	if (cnt && maskidx < a.entry_cap) {
-		uint4 *mr = (uint4 *)(a.seg_mask + 4ull * maskidx);
-		mr[0] = uint4{(uint32_t)act[0], (uint32_t)(act[0] >> 32), (uint32_t)act[1], (uint32_t)(act[1] >> 32)};
-		mr[1] = uint4{(uint32_t)act[2], (uint32_t)(act[2] >> 32), (uint32_t)act[3], (uint32_t)(act[3] >> 32)};
-	}
 	const unsigned long long t_rows = a.trace ? __builtin_amdgcn_s_memrealtime() + (first & 0u) : 0ull;
 	const uint64_t sidx0 = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y0;
 
@@ -809,7 +801,12 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		const bool dirty = (L.slowrow[lane] & 2u) != 0;
 		const uint32_t run = L.run[lane];
 		a.seg_cnt[sidx] = dirty ? 0u : seg_pack(run & 0xFFFFu, run >> 16);
-		a.seg_dir[sidx] = SegDir{first, cnt | (dirty ? SEG_DIRTY : 0u), maskidx, pack_prefix(c0, c1, c2)};
+		const uint32_t nf = cnt | (dirty ? SEG_DIRTY : 0u);
+		uint4 *dq = (uint4 *)a.seg_dir[sidx].q;  // one 64-byte line per row, the rows of a wave back to back
+		dq[0] = uint4{(uint32_t)act[0], (uint32_t)(act[0] >> 32), first, nf};
+		dq[1] = uint4{(uint32_t)act[1], (uint32_t)(act[1] >> 32), first + c0, nf};
+		dq[2] = uint4{(uint32_t)act[2], (uint32_t)(act[2] >> 32), first + c0 + c1, nf};
+		dq[3] = uint4{(uint32_t)act[3], (uint32_t)(act[3] >> 32), first + c0 + c1 + c2, nf};
 		if (dirty && first < a.entry_cap) a.dirty_list[atomicAdd(&a.ctr->dirty_cursor, 1u)] = (uint32_t)sidx;
 	}
 	if (a.trace && lane == 0) {
@@ -840,7 +837,7 @@ struct SlowArgs {
 __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 	__shared__ real_t s_v[8][256];
 	__shared__ real_t s_w[8][256];
-	if (a.ctr->entry_cursor > a.entry_cap || a.ctr->mask_cursor > a.entry_cap) return;  // the sweep will be repeated with more room
+	if (a.ctr->entry_cursor > a.entry_cap) return;  // the sweep will be repeated with more room
 	const uint32_t n = a.ctr->slow_cursor;
 	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
 	const Params &P = a.P;
@@ -862,15 +859,14 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 
 // one thread per row segment that holds slow cells: running offsets of its records, segment totals
 __global__ __launch_bounds__(256) void k_seg_fix(const SlowArgs a) {
-	if (a.ctr->entry_cursor > a.entry_cap || a.ctr->mask_cursor > a.entry_cap) return;
+	if (a.ctr->entry_cursor > a.entry_cap) return;
 	const uint32_t n = a.ctr->dirty_cursor;
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
 		const uint32_t s = a.dirty_list[t];
-		const SegDir se = a.seg_dir[s];
-		const uint32_t cnt = se.nent & ~SEG_DIRTY;
+		const uint32_t first = a.seg_dir[s].q[0][2], cnt = a.seg_dir[s].q[0][3] & ~SEG_DIRTY;
 		uint32_t nv = 0, nt = 0;
 		for (uint32_t k = 0; k < cnt; k++) {
-			Entry *e = a.entries + se.first + k;
+			Entry *e = a.entries + first + k;
 			e->w1 = nv | nt << 16;
 			nv += entry_nnew(*e);
 			nt += entry_ntri(*e);
@@ -1012,7 +1008,7 @@ struct XcdWalk {
 // capacity / overflow check shared by both emit kernels; fills the slab offsets of the context
 __device__ __forceinline__ bool emit_prepare(const EmitArgs &a, EmitCtx<sample_t> &c, const Counters &ctr) {
 	const uint64_t gV = a.ghost_segs ? ctr.ghostV : 0, gT = a.ghost_segs ? ctr.ghostT : 0;
-	if (ctr.entry_cursor > a.entry_cap || ctr.mask_cursor > a.entry_cap || ctr.totV - gV > a.capV || ctr.totT - gT > a.capT || ctr.totV > 0xFFFFFFFFull ||
+	if (ctr.entry_cursor > a.entry_cap || ctr.totV - gV > a.capV || ctr.totT - gT > a.capT || ctr.totV > 0xFFFFFFFFull ||
 	    ctr.totT > 0xFFFFFFFFull || (uint64_t)a.id_base + (ctr.totV - gV) > 0xFFFFFFFFull) {
 		if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->emit_skipped = 1;
 		return false;
@@ -1096,7 +1092,6 @@ struct mc33hip_ctx {
 	uint32_t *seg_cnt;
 	SegDir *seg_dir;
 	SegBase *seg_base;
-	uint64_t *seg_mask;
 	uint64_t seg_cap;
 	uint64_t *bsV, *bsT;
 	uint64_t bs_cap;
@@ -1245,7 +1240,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	else (void)hipDeviceSynchronize();
 	if (c->owns_grid) (void)hipFree(c->d_grid);
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_rules); (void)hipFree(c->d_rule_index); (void)hipFree(c->d_fast);
-	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base); (void)hipFree(c->seg_mask);
+	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
 	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
 	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->d_tiles);
@@ -1412,16 +1407,13 @@ static uint32_t env_u32(const char *name, uint32_t dflt) {
 
 static int alloc_entries(mc33hip_ctx *c, uint64_t cap) {
 	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
-	(void)hipFree(c->seg_mask);
 	c->entries = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr;
-	c->seg_mask = nullptr;
 	c->entry_cap = 0;
 	if (cap > 0xFFFFFF00ull) cap = 0xFFFFFF00ull;
 	HIP_TRY(hipMalloc(&c->entries, cap * sizeof(Entry)));
 	HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
 	HIP_TRY(hipMalloc(&c->slow_list, cap * 4));
 	HIP_TRY(hipMalloc(&c->dirty_list, cap * 4));
-	HIP_TRY(hipMalloc(&c->seg_mask, cap * 32));  // one 256-bit activity mask per row segment with records
 	c->entry_cap = cap;
 	return 0;
 }
@@ -1638,7 +1630,7 @@ static int enqueue_count(mc33hip_ctx *c) {
 	ca.ze = ze; ca.nYT = a.nYT; ca.nseg_pad = a.nseg_pad;
 	ca.slice_hdr = c->slice_hdr; ca.slice_bits = c->slice_bits; ca.slot_base = c->slot_base;
 	ca.epoch = c->epoch;
-	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir; ca.seg_mask = c->seg_mask;
+	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir;
 	ca.entries = c->entries; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
 	ca.entry_cap = (uint32_t)c->entry_cap;
 	ca.ctr = c->d_ctr;
@@ -1678,7 +1670,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.c.tab.lut = c->d_lut; a.c.tab.rule_words = c->d_rules; a.c.tab.rule_index = c->d_rule_index;
 	a.c.P = c->P;
 	a.c.G.p = c->d_grid; a.c.G.pitch = (uint32_t)c->pitch; a.c.G.z0 = c->desc.plane0; a.c.G.slice = c->slice;
-	a.c.seg_base = c->seg_base; a.c.seg_dir = c->seg_dir; a.c.seg_mask = c->seg_mask;
+	a.c.seg_base = c->seg_base; a.c.seg_dir = c->seg_dir;
 	a.c.entries = c->entries; a.c.entry_seg = c->entry_seg;
 	a.c.V = (real_t *)dV; a.c.N = (float *)dN; a.c.Tri = (uint32_t *)dT;
 	a.c.z_emit = c->range.z_begin; a.c.v_skip = a.c.t_skip = a.c.id_delta = 0;
@@ -1787,8 +1779,8 @@ extern "C" int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *ra
 		if ((rc = enqueue_count(c))) return rc;
 		launches++;
 		if ((rc = fetch_counters(c))) return rc;
-		if (c->h_ctr->entry_cursor <= c->entry_cap && c->h_ctr->mask_cursor <= c->entry_cap) break;
-		if ((rc = grow_entries(c, c->h_ctr->entry_cursor > c->h_ctr->mask_cursor ? c->h_ctr->entry_cursor : c->h_ctr->mask_cursor))) return rc;
+		if (c->h_ctr->entry_cursor <= c->entry_cap) break;
+		if ((rc = grow_entries(c, c->h_ctr->entry_cursor))) return rc;
 	}
 	read_timing(c, false, launches);
 	if ((rc = finish_counts(c, out))) return rc;
@@ -1843,8 +1835,8 @@ extern "C" int mc33hip_extract(mc33hip_ctx *c, double iso, const mc33hip_range *
 		launches++;
 		if ((rc = enqueue_emit(c, dV, dN, dT, capV, capT))) return rc;  // checks capacities on the device
 		if ((rc = fetch_counters(c))) return rc;
-		if (c->h_ctr->entry_cursor <= c->entry_cap && c->h_ctr->mask_cursor <= c->entry_cap) break;
-		if ((rc = grow_entries(c, c->h_ctr->entry_cursor > c->h_ctr->mask_cursor ? c->h_ctr->entry_cursor : c->h_ctr->mask_cursor))) return rc;
+		if (c->h_ctr->entry_cursor <= c->entry_cap) break;
+		if ((rc = grow_entries(c, c->h_ctr->entry_cursor))) return rc;
 	}
 	read_timing(c, true, launches);
 	if ((rc = finish_counts(c, out))) return rc;

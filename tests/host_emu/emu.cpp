@@ -53,9 +53,10 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 
 	const uint64_t nsegs = (uint64_t)(ze - P.zs) * P.ny * P.nseg;
 	std::vector<uint32_t> seg_cnt(nsegs, 0);
-	std::vector<SegDir> seg_dir(nsegs, SegDir{0, 0, 0, 0});
+	std::vector<SegDir> seg_dir(nsegs, SegDir{});
+	std::vector<uint32_t> seg_first(nsegs, 0), seg_nent(nsegs, 0);
 	std::vector<SegBase> seg_base(nsegs);
-	std::vector<uint64_t> seg_mask;
+	std::vector<uint64_t> seg_mask(4 * nsegs, 0ull);
 	uint32_t fast[256];
 	build_fast_table(mc33_lut, fast);
 	const char *force = getenv("MC33_EMU_FORCE_SLOW");  // "all": no fast path; "odd": cells with odd x go slow
@@ -73,12 +74,8 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 				const uint32_t i = load_cell(G, iso, x, y, z, v);
 				if (i == 0 || i == 0xFF) continue;
 				const uint64_t s = segment_index(P, x, y, z);
-				if (seg_dir[s].nent == 0) {
-					seg_dir[s].first = (uint32_t)entries.size();
-					seg_dir[s].maskidx = (uint32_t)(seg_mask.size() / 4);
-					seg_mask.insert(seg_mask.end(), 4, 0ull);
-				}
-				seg_mask[4ull * seg_dir[s].maskidx + ((x % SEG_CELLS) >> 6)] |= 1ull << (x & 63u);
+				if (seg_nent[s] == 0) seg_first[s] = (uint32_t)entries.size();
+				seg_mask[4ull * s + ((x % SEG_CELLS) >> 6)] |= 1ull << (x & 63u);
 				const uint32_t voff = seg_cnt[s] & 0xFFFF, toff = seg_cnt[s] >> 16;
 				bool zero = false;
 				for (int k = 0; k < 8; k++) zero |= v[k] == 0;
@@ -96,14 +93,10 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 					seg_cnt[s] = seg_pack(voff + p.nnew, toff + nt);
 				}
 				entry_seg.push_back((uint32_t)s);
-				seg_dir[s].nent++;
+				seg_nent[s]++;
 			}
 	for (uint64_t s = 0; s < nsegs; s++)
-		if (seg_dir[s].nent) {
-			const uint64_t *m = &seg_mask[4ull * seg_dir[s].maskidx];
-			seg_dir[s].pre = pack_prefix((uint32_t)__builtin_popcountll(m[0]), (uint32_t)__builtin_popcountll(m[1]),
-			                             (uint32_t)__builtin_popcountll(m[2]));
-		}
+		if (seg_nent[s]) seg_dir[s] = make_segdir(seg_first[s], seg_nent[s], &seg_mask[4ull * s]);
 	// scan in sweep order over records stored in [z][segment][y] order
 	uint64_t nV = 0, nT = 0;
 	for (uint64_t q = 0; q < nsegs; q++) {
@@ -119,7 +112,7 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	memset(out->T, 0xFF, nT * 12);
 	EmitCtx<T> c;
 	c.tab = tab; c.P = P; c.G = G;
-	c.seg_base = seg_base.data(); c.seg_dir = seg_dir.data(); c.seg_mask = seg_mask.data();
+	c.seg_base = seg_base.data(); c.seg_dir = seg_dir.data();
 	c.entries = entries.data(); c.entry_seg = entry_seg.data();
 	c.V = out->V; c.N = out->N; c.Tri = out->T;
 	c.z_emit = z_emit; c.v_skip = gV; c.t_skip = gT; c.id_delta = id_base - gV;
