@@ -233,6 +233,8 @@ def main():
         N = torch.empty_like(V)
         T = torch.empty((capT, 3), dtype=torch.int32, device=dev)
 
+    # c5 is an iso sweep over ONE resident grid: classify the 8 isovalues together (MC33_BENCH_SWEEP_MANY=0: eight independent calls)
+    sweep_many = len(isos) > 1 and os.environ.get("MC33_BENCH_SWEEP_MANY", "1") != "0"
     sweep_ms, scan_ms, emit_ms, step_ms = [], [], [], []
     state = {"step": 0, "counts": None, "b": 0}
 
@@ -240,6 +242,8 @@ def main():
         """all isovalues of the config once; returns (nV, nT) summed over the isovalues, this rank"""
         nV = nT = 0
         t0 = time.perf_counter()
+        if sweep_many:  # iso sweep: the volume is streamed once per 4 isovalues, the calls below find their sweep made
+            grid.sweep_many(isos, slab.range())
         for iso in isos:
             if not multi:
                 c, ok = grid.extract_into(iso, V, N, T, slab.range())
@@ -385,6 +389,7 @@ def main():
                "step_ms_min": spread(step_ms)["min"], "step_ms_median": spread(step_ms)["median"], "step_ms_max": spread(step_ms)["max"],
                "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": workload, "name": args.config, "cells": cells_all, "isovalues_per_step": nis,
+                          "sweep": ("one pass over the grid per 4 isovalues (mc33hip_sweep_many)" if sweep_many else "one pass over the grid per isovalue"),
                           "vertices": nV_all, "triangles": nT_all,
                           "parallelism": "z-slab x%d" % world if multi else "single GPU"},
                "mtris_per_s": nT_all / (dt / args.steps) / 1e6,

@@ -91,6 +91,14 @@ int mc33hip_set_stream(mc33hip_ctx *c, void *hip_stream);
  * Synchronises the stream. */
 int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *range, mc33hip_counts *out);
 
+/* Iso sweep over the resident grid (BASELINE.json configs[4]; the caller of calculate_isosurfaces): classifies the
+ * samples against n <= 8 isovalues while streaming the volume ONCE per 4 isovalues, instead of once per isovalue as n
+ * separate calls do (the reference re-reads all of F for every isovalue, MC:1832-1868).  Nothing is returned: the
+ * mc33hip_count / mc33hip_extract calls that follow with one of these isovalues and the same range find the sweep
+ * already made and only run the passes after it.  A sweep made ahead is used once and is dropped when the grid changes.
+ * Asynchronous on the context's stream. */
+int mc33hip_sweep_many(mc33hip_ctx *c, const double *isos, int n, const mc33hip_range *range);
+
 /* Global number of the first vertex of the range last counted (z-slab decomposition: known only after
  * the ranks have exchanged their counts).  Takes effect in the next mc33hip_emit. */
 int mc33hip_set_id_base(mc33hip_ctx *c, unsigned int id_base);

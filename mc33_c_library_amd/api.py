@@ -35,7 +35,7 @@ class Timing(C.Structure):
 HIP_API = ["mc33hip_set_id_base", "mc33hip_create", "mc33hip_destroy", "mc33hip_last_error", "mc33hip_upload_rows",
            "mc33hip_upload_contiguous", "mc33hip_adopt_device", "mc33hip_set_stream", "mc33hip_count",
            "mc33hip_emit", "mc33hip_extract", "mc33hip_last_timing", "mc33hip_download",
-           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many", "mc33hip_set_normal_neg"]
+           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many", "mc33hip_set_normal_neg", "mc33hip_sweep_many"]
 REFERENCE_API = ["create_MC33", "calculate_isosurface", "size_of_isosurface", "free_MC33", "free_surface_memory",
                  "adjustvectorlenght_s", "DefaultColorMC", "free_memory_grd", "alloc_F", "grid_from_data_pointer",
                  "generate_grid_from_fn", "_multTSA_bf", "_multA_bf", "mult_Abf",
@@ -89,6 +89,7 @@ def load_library(dtype="f32"):
     lib.mc33hip_device_free.argtypes = [V, V]
     lib.mc33hip_set_inclined.argtypes = [V, V, V, C.c_int]
     lib.mc33hip_set_normal_neg.argtypes = [V, C.c_int]
+    lib.mc33hip_sweep_many.argtypes = [V, P(C.c_double), C.c_int, P(Range)]
     _libs[dtype] = lib
     return lib
 
@@ -160,6 +161,13 @@ class DeviceGrid:
         cnt = Counts()
         _check(self.lib, self.lib.mc33hip_count(self.ctx, C.c_double(iso), C.byref(rng), C.byref(cnt)))
         return cnt
+
+    def sweep_many(self, isos, rng=None):
+        """Classify up to 8 isovalues in one go (the grid is streamed once per 4 of them); the count / extract calls
+        for these isovalues over the same range then skip their sweep."""
+        rng = rng or self.full_range()
+        arr = (C.c_double * len(isos))(*[float(x) for x in isos])
+        _check(self.lib, self.lib.mc33hip_sweep_many(self.ctx, arr, len(isos), C.byref(rng)))
 
     def extract_into(self, iso, V, N, T, rng=None):
         """One extraction into caller-owned device tensors V, N [capV,3] float32 and T [capT,3] int32.

@@ -418,11 +418,22 @@ unsigned int calculate_isosurfaces(MC33 *M, const MC33_real *iso, unsigned int n
 	if (!p || !iso)
 		return 0;
 	M->memoryfault = 0;
+	if (refresh_grid(p) != MC33HIP_OK)
+		return 0;
 	struct download_job job;
 	pthread_t th;
 	int running = 0;
 	unsigned int running_k = 0;
 	for (unsigned int k = 0; k != n; k++) {
+		if (k % 8 == 0 && n - k > 1) { /* the sweeps of the next (up to) 8 isovalues in one or two passes over the grid */
+			double many[8];
+			const unsigned int m = n - k < 8 ? n - k : 8;
+			mc33hip_range r;
+			r.z_begin = 0; r.z_end = M->nz; r.ghost_below = 0; r.id_base = 0;
+			for (unsigned int q = 0; q != m; q++) many[q] = iso[k + q];
+			if (!p->reupload)
+				(void)mc33hip_sweep_many(p->ctx, many, (int)m, &r); /* (on failure the single calls sweep for themselves) */
+		}
 		/* surface k is computed into set k&1 while the helper thread copies surface k-1 out of the other set */
 		struct staging *g = &p->set[k & 1];
 		mc33hip_counts cnt;

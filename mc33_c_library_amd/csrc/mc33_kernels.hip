@@ -108,25 +108,34 @@ __host__ __device__ inline uint64_t slice_slot(uint32_t dz, uint32_t yt, uint32_
 	return ((((uint64_t)(dz >> 2) * nYT + yt) * nseg_pad + seg) << 2) | (dz & 3u);
 }
 
-struct SweepArgs {
-	GridView<sample_t> G;
-	Params P;
-	const SweepTile *tiles;  // [wave]: the waves of a block are independent, a block is any four consecutive tiles
-	uint32_t ntiles;
-	uint32_t nYT, nseg_pad;  // y tiles, row segments per slot row (= P.nseg)
+// What one sweep leaves behind for ONE isovalue.  k_sweep can classify the samples it streams against several isovalues
+// at once (NI lanes): an iso sweep over the resident grid (calculate_isosurfaces, BASELINE.json configs[4]) then reads
+// the volume once per NI isovalues instead of once per isovalue.
+constexpr int SWEEP_MAXNI = 4;
+struct SweepLane {
 	SliceHeader *slice_hdr;  // [slice_slot]
 	uint4 *slice_bits;       // [slice_slot of the PLANE][half][lane]: {word 2*half lo, hi, word 2*half+1 lo, hi} of the plane's bit
 	                         // rows.  A plane is written once, by the first slice with cut cells that touches it: writes are
 	                         // what the sweep pays for (100 MB of them cost as much as 600 MB of reads), and consecutive slices
 	                         // share a plane
-	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz), {start, end} (s_memtime, shader clock)
 	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: rows << 32 | cells of the slices of that chunk
-	uint32_t epoch;          // number of this extraction (stamped into the slice headers)
-	uint32_t z_end;          // end of the classified range: tiles that reach it have no tile above
 	uint4 *edge_bits;        // [tile * 2 + (0 bottom | 1 top)][2][lane]: bit rows of the tile's first / last plane
 	uint4 *edge_hdr;         // ... their halo-column bits and "a sample equals the isovalue" flag
+	uint32_t epoch;          // number of this extraction (stamped into the slice headers)
+	real_t iso;
+};
+
+struct SweepArgs {
+	GridView<sample_t> G;
+	Params P;                // (P.iso is not used by the sweep: every lane has its own)
+	const SweepTile *tiles;  // [wave]: the waves of a block are independent, a block is any four consecutive tiles
+	uint32_t ntiles;
+	uint32_t nYT, nseg_pad;  // y tiles, row segments per slot row (= P.nseg)
+	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz), {start, end} (s_memtime, shader clock)
+	uint32_t z_end;          // end of the classified range: tiles that reach it have no tile above
 	uint32_t debug;          // MC33_HIP_DEBUG, developer builds (-DMC33_DEV) only - timing experiments, every count is 0: 2 = stream
 	                         // only, 16 = stream + the cut-cell test of every slice but no slice is handed on
+	SweepLane lane[SWEEP_MAXNI];
 };
 #ifdef MC33_DEV
 #define MC33_DEBUG_BITS(a) ((a).debug)
@@ -275,7 +284,7 @@ __device__ __forceinline__ void valid_masks(uint32_t xbase, uint32_t nx, uint64_
 // A slice with cut cells is handed to k_cells: its bit rows (4 KiB), the halo-column bits, flags and counts; the
 // counts also go into the partial sum of the slot's chunk (k_slots).  prev / cur: bit rows of planes z / z+1, lane =
 // sample row; bp / bc: ballots of the halo-column bits.  Wave-uniform call.
-__device__ __forceinline__ void store_plane_bits(const SweepArgs &a, uint64_t plane_slot, const uint64_t (&w)[4]) {
+__device__ __forceinline__ void store_plane_bits(const SweepLane &a, uint64_t plane_slot, const uint64_t (&w)[4]) {
 	uint4 *bits = a.slice_bits + plane_slot * 128u + (threadIdx.x & 63u);
 	bits[0] = uint4{(uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32)};
 	bits[64] = uint4{(uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32)};
@@ -283,7 +292,7 @@ __device__ __forceinline__ void store_plane_bits(const SweepArgs &a, uint64_t pl
 
 // (slot: of the slice; slot_up: of the slice above = the slot of the upper plane; write_prev / write_cur: the
 // plane has not been written by this wave yet)
-__device__ __forceinline__ void hand_over_slice(const SweepArgs &a, uint64_t slot, uint64_t slot_up, const uint64_t (&prev)[4],
+__device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slot, uint64_t slot_up, const uint64_t (&prev)[4],
                                                 const uint64_t (&cur)[4], bool write_prev, bool write_cur, uint64_t bp, uint64_t bc,
                                                 bool has_iso, const uint64_t (&act)[4]) {
 	const uint32_t lane = threadIdx.x & 63u;
@@ -336,7 +345,7 @@ constexpr int SWEEP_PACK = 1;
 // S: samples per lane and load.  S = 1: every lane loads single samples (all types); S = SWEEP_PACK > 1: dwords of 2
 // unsigned shorts / 4 unsigned chars - needs rows that start on a dword boundary (the host checks), and makes a batch
 // 8 / 16 sample rows instead of 4, so that a wave keeps the same 16 x 256 bytes in flight.
-template <int S>
+template <int S, int NI>
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	constexpr int LPR = 4 / S;    // loads per sample row
 	constexpr int RB = 16 / LPR;  // sample rows per batch
@@ -353,7 +362,6 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	const uint32_t z_lo = tile.z_lo, z_hi = tile.z_hi;
 	const uint32_t pl0 = z_lo == P.zs ? z_lo : z_lo + 1u;  // first plane this tile reads
 	const bool has_above = z_hi < a.z_end;
-	const real_t iso = P.iso;
 
 	// per-lane byte offsets of its loads inside a row (clamped into the row: bits of samples beyond the grid belong
 	// to cells that the valid masks remove)
@@ -376,12 +384,21 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 
 	// sign bits of the tile: word k of sample row r lives in lane r (layout S).  *_h: the halo sample's bit;
 	// *_z (wave-uniform): "some sample of this plane of the tile (halo included) equals the isovalue"
-	uint64_t cur[4], prev[4] = {0, 0, 0, 0};
-	uint32_t c_lo[4] = {0, 0, 0, 0}, c_hi[4] = {0, 0, 0, 0};
-	uint32_t cur_h = 0, prev_h = 0;
-	bool cur_z = false, prev_z = false;
-	bool cur_written = false, prev_written = false;  // the plane's bit rows are already in slice_bits
-	real_t zmin = 1;  // min |iso - F| over the lane's samples of the plane being assembled
+	// (one set per isovalue lane)
+	uint64_t cur[NI][4], prev[NI][4];
+	uint32_t c_lo[NI][4], c_hi[NI][4];
+	uint32_t cur_h[NI], prev_h[NI];
+	bool cur_z[NI], prev_z[NI];
+	bool cur_written[NI], prev_written[NI];  // the plane's bit rows are already in slice_bits
+	real_t zmin[NI];  // min |iso - F| over the lane's samples of the plane being assembled
+	real_t iso[NI];
+#pragma unroll
+	for (int q = 0; q < NI; q++) {
+#pragma unroll
+		for (int k = 0; k < 4; k++) { prev[q][k] = 0; c_lo[q][k] = c_hi[q][k] = 0; }
+		cur_h[q] = prev_h[q] = 0; cur_z[q] = prev_z[q] = false; cur_written[q] = prev_written[q] = false; zmin[q] = 1;
+		iso[q] = a.lane[q].iso;
+	}
 
 	// The tile is consumed as a linear stream of batches of RB sample rows (16 coalesced 256-byte loads per
 	// wave), plane after plane.  Two register buffers: the loads of batch t+1 are in flight while batch t
@@ -432,75 +449,85 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 		halo = (lane / (uint32_t)RB) == bi ? hv : halo;
 #pragma unroll
 		for (int rr = 0; rr < RB; rr++) {
-			uint32_t m[8];
+			real_t f[4];
 #pragma unroll
-			for (int k = 0; k < 4; k++) {
-				const real_t d = iso - sample(dd, rr, k);                 // MC:1852-1855
-				uint64_t bb = __ballot(sign_of(d) != 0);                  // MC:1856-1859 (sign bit)
+			for (int k = 0; k < 4; k++) f[k] = sample(dd, rr, k);
+#pragma unroll
+			for (int q = 0; q < NI; q++) {
+				uint32_t m[8];
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const real_t d = iso[q] - f[k];                           // MC:1852-1855
+					uint64_t bb = __ballot(sign_of(d) != 0);                  // MC:1856-1859 (sign bit)
 #ifdef MC33_NAN_SAMPLES
-				bb ^= __ballot(d != d);  // NaN sample: the sign the reference sees is the NaN's own (see iso_diff)
+					bb ^= __ballot(d != d);  // NaN sample: the sign the reference sees is the NaN's own (see iso_diff)
 #endif
-				m[2 * k] = (uint32_t)bb; m[2 * k + 1] = (uint32_t)(bb >> 32);
-				zmin = real_min(zmin, real_abs(d));
+					m[2 * k] = (uint32_t)bb; m[2 * k + 1] = (uint32_t)(bb >> 32);
+					zmin[q] = real_min(zmin[q], real_abs(d));
+				}
+				// park the bit row of sample row r+rr in lane r+rr: v_writelane takes its lane select from M0
+				// when the data operand is an SGPR too (one SGPR per VOP3 on gfx9-class encodings)
+				asm volatile(
+				    "s_mov_b32 m0, %16\n\t"
+				    "v_writelane_b32 %0, %8, m0\n\tv_writelane_b32 %1, %9, m0\n\t"
+				    "v_writelane_b32 %2, %10, m0\n\tv_writelane_b32 %3, %11, m0\n\t"
+				    "v_writelane_b32 %4, %12, m0\n\tv_writelane_b32 %5, %13, m0\n\t"
+				    "v_writelane_b32 %6, %14, m0\n\tv_writelane_b32 %7, %15, m0"
+				    : "+v"(c_lo[q][0]), "+v"(c_hi[q][0]), "+v"(c_lo[q][1]), "+v"(c_hi[q][1]), "+v"(c_lo[q][2]), "+v"(c_hi[q][2]), "+v"(c_lo[q][3]), "+v"(c_hi[q][3])
+				    : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), "s"(r + rr)
+				    : "m0");
 			}
-			// park the bit row of sample row r+rr in lane r+rr: v_writelane takes its lane select from M0
-			// when the data operand is an SGPR too (one SGPR per VOP3 on gfx9-class encodings)
-			asm volatile(
-			    "s_mov_b32 m0, %16\n\t"
-			    "v_writelane_b32 %0, %8, m0\n\tv_writelane_b32 %1, %9, m0\n\t"
-			    "v_writelane_b32 %2, %10, m0\n\tv_writelane_b32 %3, %11, m0\n\t"
-			    "v_writelane_b32 %4, %12, m0\n\tv_writelane_b32 %5, %13, m0\n\t"
-			    "v_writelane_b32 %6, %14, m0\n\tv_writelane_b32 %7, %15, m0"
-			    : "+v"(c_lo[0]), "+v"(c_hi[0]), "+v"(c_lo[1]), "+v"(c_hi[1]), "+v"(c_lo[2]), "+v"(c_hi[2]), "+v"(c_lo[3]), "+v"(c_hi[3])
-			    : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), "s"(r + rr)
-			    : "m0");
 		}
 		if (bi != NB - 1) return;
 		// ---- the plane is complete ----
 #pragma unroll
-		for (int k = 0; k < 4; k++) { cur[k] = u64(c_lo[k], c_hi[k]); c_lo[k] = c_hi[k] = 0; }
-		{
-			const real_t dh = iso - halo;
-			cur_h = sign_of(dh);
-#ifdef MC33_NAN_SAMPLES
-			cur_h ^= (uint32_t)(dh != dh);
-#endif
-			if (lane < nrows) zmin = real_min(zmin, real_abs(dh));  // lanes past the tile never loaded a halo sample
-			cur_z = __ballot(zmin == 0) != 0ull;  // some sample of this plane of the tile equals the isovalue
-			zmin = 1;
-		}
-		auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary (standard layout)
-			uint64_t w[4];
-			to_standard<S>(cur, w);
-			uint4 *e = a.edge_bits + ((uint64_t)wtile * 2u + which) * 128u + lane;
-			e[0] = uint4{(uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32)};
-			e[64] = uint4{(uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32)};
-			const uint64_t bh = __ballot(cur_h != 0);
-			if (lane == 0) a.edge_hdr[(uint64_t)wtile * 2u + which] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), cur_z ? 1u : 0u, 0u};
-		};
-		if (MC33_DEBUG_BITS(a) & 2u) {
-		} else {
-			if (p == pl0 && pl0 != z_lo) leave_edge(0);
-			if (p > pl0) {
-				uint64_t act[4];
-				active_cells<S>(prev, cur, prev_h, cur_h, valid, rowvalid, act);
-				if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(MC33_DEBUG_BITS(a) & 16u)) {  // wave-uniform: hand the slice to k_cells
-					uint64_t ps[4], cs[4];  // (the counts only need popcounts of act: any layout)
-					to_standard<S>(prev, ps);
-					to_standard<S>(cur, cs);
-					hand_over_slice(a, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), ps, cs,
-					                !prev_written, true, __ballot(prev_h != 0), __ballot(cur_h != 0), prev_z || cur_z, act);
-					cur_written = true;
-				}
-			}
-			if (p == z_hi && has_above) leave_edge(1);
-		}
+		for (int q = 0; q < NI; q++) {
+			const SweepLane &L = a.lane[q];
 #pragma unroll
-		for (int k = 0; k < 4; k++) prev[k] = cur[k];
-		prev_h = cur_h;
-		prev_z = cur_z;
-		prev_written = cur_written;
-		cur_written = false;
+			for (int k = 0; k < 4; k++) { cur[q][k] = u64(c_lo[q][k], c_hi[q][k]); c_lo[q][k] = c_hi[q][k] = 0; }
+			{
+				const real_t dh = iso[q] - halo;
+				cur_h[q] = sign_of(dh);
+#ifdef MC33_NAN_SAMPLES
+				cur_h[q] ^= (uint32_t)(dh != dh);
+#endif
+				if (lane < nrows) zmin[q] = real_min(zmin[q], real_abs(dh));  // lanes past the tile never loaded a halo sample
+				cur_z[q] = __ballot(zmin[q] == 0) != 0ull;  // some sample of this plane of the tile equals the isovalue
+				zmin[q] = 1;
+			}
+			auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary (standard layout)
+				uint64_t w[4];
+				to_standard<S>(cur[q], w);
+				uint4 *e = L.edge_bits + ((uint64_t)wtile * 2u + which) * 128u + lane;
+				e[0] = uint4{(uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32)};
+				e[64] = uint4{(uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32)};
+				const uint64_t bh = __ballot(cur_h[q] != 0);
+				if (lane == 0) L.edge_hdr[(uint64_t)wtile * 2u + which] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), cur_z[q] ? 1u : 0u, 0u};
+			};
+			if (MC33_DEBUG_BITS(a) & 2u) {
+			} else {
+				if (p == pl0 && pl0 != z_lo) leave_edge(0);
+				if (p > pl0) {
+					uint64_t act[4];
+					active_cells<S>(prev[q], cur[q], prev_h[q], cur_h[q], valid, rowvalid, act);
+					if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(MC33_DEBUG_BITS(a) & 16u)) {  // wave-uniform: hand the slice to k_cells
+						uint64_t ps[4], cs[4];  // (the counts only need popcounts of act: any layout)
+						to_standard<S>(prev[q], ps);
+						to_standard<S>(cur[q], cs);
+						hand_over_slice(L, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), ps, cs,
+						                !prev_written[q], true, __ballot(prev_h[q] != 0), __ballot(cur_h[q] != 0), prev_z[q] || cur_z[q], act);
+						cur_written[q] = true;
+					}
+				}
+				if (p == z_hi && has_above) leave_edge(1);
+			}
+#pragma unroll
+			for (int k = 0; k < 4; k++) prev[q][k] = cur[q][k];
+			prev_h[q] = cur_h[q];
+			prev_z[q] = cur_z[q];
+			prev_written[q] = cur_written[q];
+			cur_written[q] = false;
+		}
 	};
 
 	raw_t dA[16], dB[16];
@@ -531,7 +558,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 // ---------------------------------------------------------------------------------------------------
 struct TileBoundary { uint32_t below, above, z, yt, seg, pad_[3]; };  // tile (wave) indices of k_sweep; slice z
 
-__global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileBoundary *bounds, uint32_t nbounds) {
+__global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileBoundary *bounds, uint32_t nbounds, uint32_t lane_no) {
+	const SweepLane &L = a.lane[lane_no];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t bi = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	if (bi >= nbounds) return;
@@ -539,9 +567,9 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 	const Params &P = a.P;
 	const uint32_t seg = b.seg;
 	const uint64_t rp = (uint64_t)b.below * 2u + 1u, rc = (uint64_t)b.above * 2u;  // top of below, bottom of above
-	const uint4 p0 = a.edge_bits[rp * 128u + lane], p1 = a.edge_bits[rp * 128u + 64u + lane];
-	const uint4 c0 = a.edge_bits[rc * 128u + lane], c1 = a.edge_bits[rc * 128u + 64u + lane];
-	const uint4 hp = a.edge_hdr[rp], hc = a.edge_hdr[rc];
+	const uint4 p0 = L.edge_bits[rp * 128u + lane], p1 = L.edge_bits[rp * 128u + 64u + lane];
+	const uint4 c0 = L.edge_bits[rc * 128u + lane], c1 = L.edge_bits[rc * 128u + 64u + lane];
+	const uint4 hp = L.edge_hdr[rp], hc = L.edge_hdr[rc];
 	const uint64_t prev[4] = {u64(p0.x, p0.y), u64(p0.z, p0.w), u64(p1.x, p1.y), u64(p1.z, p1.w)};
 	const uint64_t cur[4] = {u64(c0.x, c0.y), u64(c0.z, c0.w), u64(c1.x, c1.y), u64(c1.z, c1.w)};
 	const uint64_t bp = u64(hp.x, hp.y), bc = u64(hc.x, hc.y);
@@ -551,7 +579,7 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 	active_cells(prev, cur, (uint32_t)((bp >> lane) & 1ull), (uint32_t)((bc >> lane) & 1ull), valid, rowvalid, act);
 	if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull))
 		// (the two tiles may have written these planes for slices of their own: same bytes again)
-		hand_over_slice(a, slice_slot(b.z - P.zs, b.yt, seg, a.nYT, a.nseg_pad), slice_slot(b.z + 1u - P.zs, b.yt, seg, a.nYT, a.nseg_pad), prev, cur,
+		hand_over_slice(L, slice_slot(b.z - P.zs, b.yt, seg, a.nYT, a.nseg_pad), slice_slot(b.z + 1u - P.zs, b.yt, seg, a.nYT, a.nseg_pad), prev, cur,
 		                true, true, bp, bc, (hp.z | hc.z) != 0u, act);
 }
 
@@ -1078,6 +1106,22 @@ static void set_err(const char *fmt, ...) {
 		}                                                                                     \
 	} while (0)
 
+// Per-isovalue output of the sweep (SweepLane) and its bookkeeping on the host
+constexpr int MC33_LANES = 8;
+struct IsoLane {
+	SliceHeader *slice_hdr;   // one record per (wave tile, cell slice) of the sweep
+	uint4 *slice_bits;
+	unsigned long long *slot_part;
+	uint4 *edge_bits, *edge_hdr;
+	uint64_t slice_cap, edge_cap;
+	uint32_t epoch;           // extractions since the slice headers were last cleared
+	// a sweep made ahead of time by mc33hip_sweep_many, waiting for the count / extract call of its isovalue
+	bool swept, boundary_done;
+	double iso;
+	mc33hip_range range;
+	float sweep_ms;           // its share of the sweep's time
+};
+
 struct mc33hip_ctx {
 	mc33hip_grid_desc desc;
 	int device;
@@ -1098,21 +1142,20 @@ struct mc33hip_ctx {
 	Entry *entries;
 	uint32_t *entry_seg, *slow_list, *dirty_list;
 	uint64_t entry_cap;
-	SliceHeader *slice_hdr;   // one record per (wave tile, cell slice) of the sweep
-	uint4 *slice_bits;
+	IsoLane lanes[MC33_LANES]; // what a sweep leaves behind, per isovalue (lane 0: the single-isovalue calls)
 	uint2 *slot_base;
-	unsigned long long *slot_part;
-	uint32_t epoch;           // extractions since the slice headers were last cleared
+	uint64_t slot_base_cap;
 	uint32_t epoch_wrap;      // the stamps start over at this count (2^30; MC33_HIP_EPOCH_WRAP for the test that crosses it)
-	uint64_t slice_cap;
+	IsoLane *cur_lane;        // the lane the last count used (its epoch is what the emit pass needs)
+	bool lane_presweeped;     // ... and it had been filled by mc33hip_sweep_many
 	SweepTile *d_tiles;       // block plan of k_sweep for the current range
 	TileBoundary *d_bounds;   // pairs of tiles that meet in z (k_boundary)
-	uint4 *edge_bits, *edge_hdr;
 	uint64_t tiles_cap, ntiles, nbounds;
 	uint32_t tiles_zs, tiles_ze, tiles_depth;
 	uint32_t resident_blocks; // k_sweep blocks the device holds at once
 	Counters *d_ctr, *h_ctr;
 	hipEvent_t ev[4];
+	hipEvent_t ev_many[2];    // mc33hip_sweep_many's pass timing
 	hipStream_t aux, aux2;    // the triangle pass and the slow-record pass run beside the vertex pass
 	hipStream_t copy;         // mc33hip_download_concurrent
 	hipEvent_t ev_fork, ev_join, ev_join2;
@@ -1221,6 +1264,7 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	CREATE_TRY(hipMalloc(&c->d_ctr, sizeof(Counters)));
 	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
 	for (int k = 0; k < 4; k++) CREATE_TRY(hipEventCreate(&c->ev[k]));
+	for (int k = 0; k < 2; k++) CREATE_TRY(hipEventCreate(&c->ev_many[k]));
 	CREATE_TRY(pool_take(c->device, &c->aux));
 	CREATE_TRY(pool_take(c->device, &c->aux2));
 	CREATE_TRY(pool_take(c->device, &c->copy));
@@ -1243,9 +1287,13 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
 	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
-	(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits); (void)hipFree(c->d_tiles);
-	(void)hipFree(c->slot_base); (void)hipFree(c->slot_part);
-	(void)hipFree(c->d_bounds); (void)hipFree(c->edge_bits); (void)hipFree(c->edge_hdr);
+	for (int k = 0; k < MC33_LANES; k++) {
+		IsoLane &L = c->lanes[k];
+		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.slot_part); (void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
+	}
+	(void)hipFree(c->d_tiles);
+	(void)hipFree(c->slot_base);
+	(void)hipFree(c->d_bounds);
 	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
 	(void)hipFree(c->d_ctr);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
@@ -1253,11 +1301,16 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	if (c->aux2) (void)hipStreamSynchronize(c->aux2);
 	if (c->copy) (void)hipStreamSynchronize(c->copy);
 	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
+	for (int k = 0; k < 2; k++) if (c->ev_many[k]) (void)hipEventDestroy(c->ev_many[k]);
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
 	pool_give(c->device, c->aux); pool_give(c->device, c->aux2); pool_give(c->device, c->copy);  // after the events
 	free(c);
+}
+
+static void forget_sweeps(mc33hip_ctx *c) {  // the grid changed: sweeps made ahead of time are worthless
+	for (int k = 0; k < MC33_LANES; k++) c->lanes[k].swept = false;
 }
 
 extern "C" int mc33hip_set_stream(mc33hip_ctx *c, void *s) {
@@ -1317,6 +1370,7 @@ extern "C" int mc33hip_upload_contiguous(mc33hip_ctx *c, const void *host) {
 		HIP_TRY(hipMemcpy2D(c->d_grid, c->pitch * sizeof(sample_t), host, rowb, rowb, (size_t)c->desc.npy * c->desc.npz_resident,
 		                    hipMemcpyHostToDevice));
 	c->counted = false;
+	forget_sweeps(c);
 	return MC33HIP_OK;
 }
 
@@ -1337,6 +1391,7 @@ extern "C" int mc33hip_upload_rows(mc33hip_ctx *c, const void *const *const *F) 
 	// rows are separate allocations (alloc_F, reference MC33_util_grd.c:147-169)
 	if ((rc = upload_staged(c, [=](uint32_t k, uint32_t j) { return (const char *)F[k][j]; }))) return rc;
 	c->counted = false;
+	forget_sweeps(c);
 	return MC33HIP_OK;
 }
 
@@ -1350,6 +1405,7 @@ extern "C" int mc33hip_adopt_device(mc33hip_ctx *c, const void *dptr, size_t pit
 	c->pitch = pitch;
 	c->slice = slice;
 	c->counted = false;
+	forget_sweeps(c);
 	return MC33HIP_OK;
 }
 
@@ -1462,7 +1518,7 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 	if (c->d_tiles && c->tiles_zs == zs && c->tiles_ze == ze && c->tiles_depth == depth) return 0;
 	if (!c->resident_blocks) {
 		int per_cu = 0, cus = 0;
-		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<1>, 256, 0));
+		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<1, 1>, 256, 0));
 		HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
 		const uint32_t want = env_u32("MC33_HIP_SWEEP_BLOCKS_PER_CU", 4);
 		c->resident_blocks = (uint32_t)std::max(1, cus) * (uint32_t)std::max(1, std::min(per_cu, (int)want));
@@ -1534,11 +1590,9 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 	}
 	HIP_TRY(hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(SweepTile), hipMemcpyHostToDevice));
 	c->ntiles = tiles.size();
-	(void)hipFree(c->d_bounds); (void)hipFree(c->edge_bits); (void)hipFree(c->edge_hdr);
-	c->d_bounds = nullptr; c->edge_bits = nullptr; c->edge_hdr = nullptr;
+	(void)hipFree(c->d_bounds);
+	c->d_bounds = nullptr;
 	c->nbounds = bounds.size();
-	HIP_TRY(hipMalloc(&c->edge_bits, tiles.size() * 2 * 128 * sizeof(uint4)));
-	HIP_TRY(hipMalloc(&c->edge_hdr, tiles.size() * 2 * sizeof(uint4)));
 	if (c->nbounds) {
 		HIP_TRY(hipMalloc(&c->d_bounds, bounds.size() * sizeof(TileBoundary)));
 		HIP_TRY(hipMemcpy(c->d_bounds, bounds.data(), bounds.size() * sizeof(TileBoundary), hipMemcpyHostToDevice));
@@ -1550,86 +1604,112 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 	return 0;
 }
 
-// enqueue sweep + cell records + slow-cell planning + scans on the context's stream (no synchronisation)
-static int enqueue_count(mc33hip_ctx *c) {
+// slot geometry of the range being classified
+struct SlotGeom {
+	uint32_t nYT, nseg;
+	uint64_t cell_blocks, nslots, nchunks;
+};
+static int slot_geometry(mc33hip_ctx *c, SlotGeom &g) {
 	const Params &P = c->P;
-	hipStream_t st = c->stream;
-	SweepArgs a;
-	a.G.p = c->d_grid; a.G.pitch = (uint32_t)c->pitch; a.G.z0 = c->desc.plane0; a.G.slice = c->slice;
-	a.P = P;
-	const uint32_t ze = c->range.z_end;
-	a.nYT = (P.ny + 62) / 63;
-	a.nseg_pad = P.nseg;  // (no padding needed any more: the slots of a slice group are its real row segments)
-	if (int rc = plan_sweep(c, P.zs, ze)) return rc;
-	a.tiles = c->d_tiles;
-	const uint64_t blocks = (c->ntiles + 3) / 4;
-	a.ntiles = (uint32_t)c->ntiles;
-	const uint64_t cell_blocks = (uint64_t)((ze - P.zs + 3) / 4) * a.nYT * a.nseg_pad;
-	if (cell_blocks > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
-	const uint64_t nslots = cell_blocks * 4;
-	if (c->slice_cap < nslots) {
-		(void)hipFree(c->slice_hdr); (void)hipFree(c->slice_bits);
-		c->slice_hdr = nullptr; c->slice_bits = nullptr; c->slice_cap = 0;
-		HIP_TRY(hipMalloc(&c->slice_hdr, nslots * sizeof(SliceHeader)));
-		HIP_TRY(hipMalloc(&c->slice_bits, (nslots + 4ull * a.nYT * a.nseg_pad) * 2048));  // planes: one more than slices
-		(void)hipFree(c->slot_base); (void)hipFree(c->slot_part);
-		c->slot_base = nullptr; c->slot_part = nullptr;
-		HIP_TRY(hipMalloc(&c->slot_base, nslots * sizeof(uint2)));
-		const uint64_t part_bytes = ((nslots + SLOT_CHUNK - 1) / SLOT_CHUNK) * 8;
-		HIP_TRY(hipMalloc(&c->slot_part, 2 * part_bytes));  // two halves, used by alternate extractions
-		HIP_TRY(hipMemsetAsync(c->slice_hdr, 0, nslots * sizeof(SliceHeader), st));
-		HIP_TRY(hipMemsetAsync(c->slot_part, 0, 2 * part_bytes, st));
-		c->epoch = 0;
-		c->slice_cap = nslots;
+	g.nYT = (P.ny + 62) / 63;
+	g.nseg = P.nseg;  // (the slots of a slice group are its real row segments)
+	g.cell_blocks = (uint64_t)((c->range.z_end - P.zs + 3) / 4) * g.nYT * g.nseg;
+	if (g.cell_blocks > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
+	g.nslots = g.cell_blocks * 4;
+	g.nchunks = 0;
+	return 0;
+}
+
+// buffers of one isovalue lane for the current range and tile plan; a new extraction number (epoch)
+static int begin_lane(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g, hipStream_t st) {
+	if (L.slice_cap < g.nslots) {
+		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.slot_part);
+		L.slice_hdr = nullptr; L.slice_bits = nullptr; L.slot_part = nullptr; L.slice_cap = 0;
+		HIP_TRY(hipMalloc(&L.slice_hdr, g.nslots * sizeof(SliceHeader)));
+		HIP_TRY(hipMalloc(&L.slice_bits, (g.nslots + 4ull * g.nYT * g.nseg) * 2048));  // planes: one more than slices
+		const uint64_t part_bytes = ((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK) * 8;
+		HIP_TRY(hipMalloc(&L.slot_part, 2 * part_bytes));  // two halves, used by alternate extractions
+		HIP_TRY(hipMemsetAsync(L.slice_hdr, 0, g.nslots * sizeof(SliceHeader), st));
+		HIP_TRY(hipMemsetAsync(L.slot_part, 0, 2 * part_bytes, st));
+		L.epoch = 0;
+		L.slice_cap = g.nslots;
 	}
-	a.slice_hdr = c->slice_hdr; a.slice_bits = c->slice_bits;
-	a.debug = 0;
-#ifdef MC33_DEV
-	a.debug = env_u32("MC33_HIP_DEBUG", 0);
-	if (a.debug) {  // never silent: with this set the call measures the sweep's read stream and finds no surface
-		static bool warned = false;
-		if (!warned) fprintf(stderr, "[mc33hip] MC33_HIP_DEBUG=%u: timing experiment, every extraction returns an EMPTY surface\n", a.debug);
-		warned = true;
+	if (L.edge_cap < c->ntiles) {
+		(void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
+		L.edge_bits = nullptr; L.edge_hdr = nullptr; L.edge_cap = 0;
+		HIP_TRY(hipMalloc(&L.edge_bits, c->ntiles * 2 * 128 * sizeof(uint4)));
+		HIP_TRY(hipMalloc(&L.edge_hdr, c->ntiles * 2 * sizeof(uint4)));
+		L.edge_cap = c->ntiles;
 	}
-#endif
-	const uint64_t nchunks = (c->slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;  // (capacity: the halves keep their place)
-	if (++c->epoch >= c->epoch_wrap) {  // stamps wrap: start over with clean headers AND clean partial sums - the call before
+	const uint64_t nchunks = (L.slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;  // (capacity: the halves keep their place)
+	if (++L.epoch >= c->epoch_wrap) {  // stamps wrap: start over with clean headers AND clean partial sums - the call before
 		// accumulated into the half an odd epoch selects and cleared only the other one, and epoch 1 is odd again
-		HIP_TRY(hipMemsetAsync(c->slice_hdr, 0, c->slice_cap * sizeof(SliceHeader), st));
-		HIP_TRY(hipMemsetAsync(c->slot_part, 0, 2 * nchunks * 8, st));
-		c->epoch = 1;
+		HIP_TRY(hipMemsetAsync(L.slice_hdr, 0, L.slice_cap * sizeof(SliceHeader), st));
+		HIP_TRY(hipMemsetAsync(L.slot_part, 0, 2 * nchunks * 8, st));
+		L.epoch = 1;
 	}
-	unsigned long long *part_now = c->slot_part + (c->epoch & 1u) * nchunks, *part_next = c->slot_part + ((c->epoch + 1u) & 1u) * nchunks;
-	a.slot_part = part_now;
-	a.epoch = c->epoch;
-	a.z_end = ze;
-	a.edge_bits = c->edge_bits; a.edge_hdr = c->edge_hdr;
+	L.swept = false;
+	L.boundary_done = false;
+	return 0;
+}
+static unsigned long long *lane_part(const IsoLane &L, bool next) {
+	const uint64_t nchunks = (L.slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;
+	return L.slot_part + ((L.epoch + (next ? 1u : 0u)) & 1u) * nchunks;
+}
+
+static void sweep_args(mc33hip_ctx *c, const SlotGeom &g, SweepArgs &a) {
+	a.G.p = c->d_grid; a.G.pitch = (uint32_t)c->pitch; a.G.z0 = c->desc.plane0; a.G.slice = c->slice;
+	a.P = c->P;
+	a.nYT = g.nYT; a.nseg_pad = g.nseg;
+	a.tiles = c->d_tiles;
+	a.ntiles = (uint32_t)c->ntiles;
+	a.z_end = c->range.z_end;
 	a.trace = nullptr;
-	if (getenv("MC33_HIP_TRACE_FILE")) {
-		(void)hipFree(c->trace);
-		c->trace = nullptr;
-		c->trace_waves = blocks * 4;
-		HIP_TRY(hipMalloc(&c->trace, c->trace_waves * 32));
-		HIP_TRY(hipMemsetAsync(c->trace, 0, c->trace_waves * 32, st));
-		a.trace = c->trace;
-	}
-	// nothing is cleared between extractions: headers carry the epoch, k_slots resets the counters and the
-	// partial sums of the next call, k_cells writes every row segment count of the range
-	if (c->timing_level > 0) HIP_TRY(hipEventRecord(c->ev[0], st));
+	a.debug = 0;
+	for (int q = 0; q < SWEEP_MAXNI; q++) a.lane[q] = SweepLane{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, (real_t)0};
+}
+static void set_lane(SweepArgs &a, int q, const IsoLane &L, double iso) {
+	a.lane[q] = SweepLane{L.slice_hdr, L.slice_bits, lane_part(L, false), L.edge_bits, L.edge_hdr, L.epoch, (real_t)iso};
+}
+
+// one k_sweep launch over NI = 1, 2 or 4 lanes that begin_lane has prepared
+template <int NI>
+static void launch_sweep_ni(mc33hip_ctx *c, const SweepArgs &a, hipStream_t st) {
+	const uint64_t blocks = (c->ntiles + 3) / 4;
 	// narrow samples are loaded as dwords when every row of the grid starts on a dword boundary (always true for the
 	// library's own pitched copy; a caller's device buffer may have any pitch)
 	const bool packed = SWEEP_PACK > 1 && !env_u32("MC33_HIP_NO_PACK", 0) && ((uintptr_t)c->d_grid % 4u) == 0 &&
 	                    (c->pitch * sizeof(sample_t)) % 4u == 0 && (c->slice * sizeof(sample_t)) % 4u == 0;
-	if (packed) hipLaunchKernelGGL(k_sweep<SWEEP_PACK>, dim3((uint32_t)blocks), dim3(256), 0, st, a);
-	else hipLaunchKernelGGL(k_sweep<1>, dim3((uint32_t)blocks), dim3(256), 0, st, a);
-	HIP_TRY(hipGetLastError());
-	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[1], st));
-	if (c->nbounds && !(MC33_DEBUG_BITS(a) & 2u)) hipLaunchKernelGGL(k_boundary, dim3((uint32_t)((c->nbounds + 3) / 4)), dim3(256), 0, st, a, c->d_bounds, (uint32_t)c->nbounds);
+	if (packed) hipLaunchKernelGGL((k_sweep<SWEEP_PACK, NI>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
+	else hipLaunchKernelGGL((k_sweep<1, NI>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
+}
+
+// everything after the sweep for the slices lane L holds: tile boundaries, record ranges, cell records, slow-cell
+// planning, scans - on the context's stream, no synchronisation
+static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
+	const Params &P = c->P;
+	hipStream_t st = c->stream;
+	const uint32_t ze = c->range.z_end;
+	if (c->slot_base_cap < g.nslots) {
+		(void)hipFree(c->slot_base);
+		c->slot_base = nullptr; c->slot_base_cap = 0;
+		HIP_TRY(hipMalloc(&c->slot_base, g.nslots * sizeof(uint2)));
+		c->slot_base_cap = g.nslots;
+	}
+	SweepArgs a;
+	sweep_args(c, g, a);
+	set_lane(a, 0, L, P.iso);
+#ifdef MC33_DEV
+	a.debug = env_u32("MC33_HIP_DEBUG", 0);
+#endif
+	if (c->nbounds && !L.boundary_done && !(MC33_DEBUG_BITS(a) & 2u))
+		hipLaunchKernelGGL(k_boundary, dim3((uint32_t)((c->nbounds + 3) / 4)), dim3(256), 0, st, a, c->d_bounds, (uint32_t)c->nbounds, 0u);
+	L.boundary_done = true;  // (its slices are in the partial sums now: a repeated tail - more room for records - must not add them again)
 	CellsArgs ca;
 	ca.P = P; ca.fast = c->d_fast;
-	ca.ze = ze; ca.nYT = a.nYT; ca.nseg_pad = a.nseg_pad;
-	ca.slice_hdr = c->slice_hdr; ca.slice_bits = c->slice_bits; ca.slot_base = c->slot_base;
-	ca.epoch = c->epoch;
+	ca.ze = ze; ca.nYT = g.nYT; ca.nseg_pad = g.nseg;
+	ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.slot_base = c->slot_base;
+	ca.epoch = L.epoch;
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir;
 	ca.entries = c->entries; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
 	ca.entry_cap = (uint32_t)c->entry_cap;
@@ -1638,14 +1718,15 @@ static int enqueue_count(mc33hip_ctx *c) {
 	if (getenv("MC33_HIP_TRACE_CELLS")) {
 		(void)hipFree(c->trace_cells);
 		c->trace_cells = nullptr;
-		c->trace_cells_n = nslots;
-		HIP_TRY(hipMalloc(&c->trace_cells, nslots * 32));
-		HIP_TRY(hipMemsetAsync(c->trace_cells, 0, nslots * 32, st));
+		c->trace_cells_n = g.nslots;
+		HIP_TRY(hipMalloc(&c->trace_cells, g.nslots * 32));
+		HIP_TRY(hipMemsetAsync(c->trace_cells, 0, g.nslots * 32, st));
 		ca.trace = c->trace_cells;
 	}
-	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((nslots + SLOT_CHUNK - 1) / SLOT_CHUNK)), dim3(256), 0, st, c->slice_hdr, part_now, part_next,
-	                   (uint32_t)nchunks, c->epoch, nslots, c->slot_base, c->d_ctr);
-	hipLaunchKernelGGL(k_cells, dim3((uint32_t)cell_blocks), dim3(256), 0, st, ca);
+	const uint64_t nchunks = (L.slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;
+	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK)), dim3(256), 0, st, L.slice_hdr, lane_part(L, false), lane_part(L, true),
+	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr);
+	hipLaunchKernelGGL(k_cells, dim3((uint32_t)g.cell_blocks), dim3(256), 0, st, ca);
 	SlowArgs sa;
 	sa.G = a.G; sa.P = P;
 	sa.tab.lut = c->d_lut; sa.tab.rule_words = c->d_rules; sa.tab.rule_index = c->d_rule_index;
@@ -1661,7 +1742,103 @@ static int enqueue_count(mc33hip_ctx *c) {
 	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, c->seg_base,
 	                   c->ghost_segs, c->d_ctr);
 	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+static bool same_range(const mc33hip_range &x, const mc33hip_range &y) {
+	return x.z_begin == y.z_begin && x.z_end == y.z_end && (x.ghost_below != 0) == (y.ghost_below != 0);
+}
+
+// enqueue sweep + cell records + slow-cell planning + scans on the context's stream (no synchronisation).  When
+// mc33hip_sweep_many has already classified this isovalue over this range, its lane is used and nothing is streamed.
+static int enqueue_count(mc33hip_ctx *c, bool rerun = false) {
+	const Params &P = c->P;
+	hipStream_t st = c->stream;
+	if (int rc = plan_sweep(c, P.zs, c->range.z_end)) return rc;
+	SlotGeom g;
+	if (int rc = slot_geometry(c, g)) return rc;
+	IsoLane *L = nullptr;
+	if (rerun && c->cur_lane && c->lane_presweeped) L = c->cur_lane;  // same call, more room for records: the sweep's result stands
+	else
+		for (int k = 0; k < MC33_LANES && !L; k++)
+			if (c->lanes[k].swept && (real_t)c->lanes[k].iso == P.iso && same_range(c->lanes[k].range, c->range) &&
+			    c->lanes[k].slice_cap >= g.nslots && c->lanes[k].edge_cap >= c->ntiles)
+				L = &c->lanes[k];
+	if (c->timing_level > 0) HIP_TRY(hipEventRecord(c->ev[0], st));
+	if (L) {
+		L->swept = false;  // used once
+		c->lane_presweeped = true;
+	} else {
+		L = &c->lanes[0];
+		if (int rc = begin_lane(c, *L, g, st)) return rc;
+		c->lane_presweeped = false;
+		SweepArgs a;
+		sweep_args(c, g, a);
+		set_lane(a, 0, *L, P.iso);
+#ifdef MC33_DEV
+		a.debug = env_u32("MC33_HIP_DEBUG", 0);
+		if (a.debug) {  // never silent: with this set the call measures the sweep's read stream and finds no surface
+			static bool warned = false;
+			if (!warned) fprintf(stderr, "[mc33hip] MC33_HIP_DEBUG=%u: timing experiment, every extraction returns an EMPTY surface\n", a.debug);
+			warned = true;
+		}
+#endif
+		if (getenv("MC33_HIP_TRACE_FILE")) {
+			(void)hipFree(c->trace);
+			c->trace = nullptr;
+			c->trace_waves = ((c->ntiles + 3) / 4) * 4;
+			HIP_TRY(hipMalloc(&c->trace, c->trace_waves * 32));
+			HIP_TRY(hipMemsetAsync(c->trace, 0, c->trace_waves * 32, st));
+			a.trace = c->trace;
+			if (c->timing_level > 0) HIP_TRY(hipEventRecord(c->ev[0], st));
+		}
+		// nothing is cleared between extractions: headers carry the epoch, k_slots resets the counters and the
+		// partial sums of the next call, k_cells writes every row segment count of the range
+		launch_sweep_ni<1>(c, a, st);
+		HIP_TRY(hipGetLastError());
+	}
+	c->cur_lane = L;
+	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[1], st));
+	if (int rc = enqueue_tail(c, *L, g)) return rc;
 	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[2], st));
+	return 0;
+}
+
+// Sweeps for n isovalues over one range, SWEEP_MAXNI isovalues per pass over the grid; the count / extract calls that
+// follow (same isovalue, same range) find their lane and go straight to the tail.
+static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n) {
+	hipStream_t st = c->stream;
+	if (int rc = plan_sweep(c, c->P.zs, c->range.z_end)) return rc;
+	SlotGeom g;
+	if (int rc = slot_geometry(c, g)) return rc;
+	int k = 0;
+	while (k < n) {
+		const int ni = (n - k >= 4) ? 4 : (n - k >= 2) ? 2 : 1;
+		SweepArgs a;
+		sweep_args(c, g, a);
+		for (int q = 0; q < ni; q++) {
+			IsoLane &L = c->lanes[k + q];
+			if (int rc = begin_lane(c, L, g, st)) return rc;
+			set_lane(a, q, L, isos[k + q]);
+		}
+		hipEvent_t e0 = c->ev_many[0], e1 = c->ev_many[1];
+		if (c->timing_level > 0) HIP_TRY(hipEventRecord(e0, st));
+		if (ni == 4) launch_sweep_ni<4>(c, a, st);
+		else if (ni == 2) launch_sweep_ni<2>(c, a, st);
+		else launch_sweep_ni<1>(c, a, st);
+		HIP_TRY(hipGetLastError());
+		float ms = 0.f;
+		if (c->timing_level > 0) {  // (developer timing only: waits for the pass)
+			HIP_TRY(hipEventRecord(e1, st));
+			HIP_TRY(hipEventSynchronize(e1));
+			(void)hipEventElapsedTime(&ms, e0, e1);
+		}
+		for (int q = 0; q < ni; q++) {
+			IsoLane &L = c->lanes[k + q];
+			L.swept = true; L.iso = isos[k + q]; L.range = c->range; L.sweep_ms = ms / (float)ni;
+		}
+		k += ni;
+	}
 	return 0;
 }
 
@@ -1764,6 +1941,10 @@ static void read_timing(mc33hip_ctx *c, bool with_emit, unsigned launches) {
 	}
 	if (c->timing_level > 0 && with_emit) (void)hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[3]);
 	else if (c->timing_level > 1) (void)hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[2]);
+	if (c->lane_presweeped && c->cur_lane && c->timing_level > 0) {  // the sweep was made ahead of time, NI isovalues per pass: its share
+		t.sweep_ms += c->cur_lane->sweep_ms;
+		t.total_ms += c->cur_lane->sweep_ms;
+	}
 }
 
 extern "C" int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *range, mc33hip_counts *out) {
@@ -1776,7 +1957,7 @@ extern "C" int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *ra
 	if ((rc = ensure_workspaces(c))) return rc;
 	unsigned launches = 0;
 	for (;;) {
-		if ((rc = enqueue_count(c))) return rc;
+		if ((rc = enqueue_count(c, launches > 0))) return rc;
 		launches++;
 		if ((rc = fetch_counters(c))) return rc;
 		if (c->h_ctr->entry_cursor <= c->entry_cap) break;
@@ -1786,6 +1967,17 @@ extern "C" int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *ra
 	if ((rc = finish_counts(c, out))) return rc;
 	c->counted = true;
 	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_sweep_many(mc33hip_ctx *c, const double *isos, int n, const mc33hip_range *range) {
+	if (!c || !isos || n < 1 || n > MC33_LANES) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	if ((rc = check_range(c, range))) return rc;
+	c->counted = false;
+	fill_params(c, isos[0], range);
+	if ((rc = ensure_workspaces(c))) return rc;
+	return enqueue_sweep_many(c, isos, n);
 }
 
 extern "C" int mc33hip_set_inclined(mc33hip_ctx *c, const double *grd_A, const double *grd_Ai, int triangular) {
@@ -1831,7 +2023,7 @@ extern "C" int mc33hip_extract(mc33hip_ctx *c, double iso, const mc33hip_range *
 	if ((rc = ensure_workspaces(c))) return rc;
 	unsigned launches = 0;
 	for (;;) {
-		if ((rc = enqueue_count(c))) return rc;
+		if ((rc = enqueue_count(c, launches > 0))) return rc;
 		launches++;
 		if ((rc = enqueue_emit(c, dV, dN, dT, capV, capT))) return rc;  // checks capacities on the device
 		if ((rc = fetch_counters(c))) return rc;

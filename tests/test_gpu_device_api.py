@@ -127,3 +127,40 @@ def test_one_context_many_extractions_of_different_extent(reflibs):
             assert (cnt.nV, cnt.nT) == (cnt2.nV, cnt2.nT), (step, iso, zr)
             assert torch.equal(T, T2) and torch.equal(V.view(torch.int32), V2.view(torch.int32)) and torch.equal(N.view(torch.int32), N2.view(torch.int32))
             g2.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u16", "u8"])
+def test_sweep_many_equals_single_sweeps(reflibs, dtype):
+    """mc33hip_sweep_many classifies up to 8 isovalues per pass over the grid (4 per kernel launch); the extractions
+    that follow must be exactly what they are without it - and the reference's.  Odd counts (4 + 2 + 1 lanes), a slab with
+    a ghost slice, an isovalue that is not among the swept ones, a sweep that is never used, one used after a regrow."""
+    import torch
+    from mc33_c_library_amd import DeviceGrid, Range
+    if dtype == "f32":
+        data, isos = fx.noise_quant(0, 3, shape=(40, 70, 300)), [0.0, 1.0, -1.0, 0.5, 1.5, -0.5, 2.0]
+    elif dtype == "u16":
+        data, isos = fx.cos_field_u16(300, 130, 50), [15268.5 + 5000.0 * k for k in range(8)]
+    else:
+        data, isos = fx.noise_u8(0, 4, 5, shape=(30, 66, 258)), [2.0, 1.5, 3.0]
+    t = torch.from_numpy(data).cuda()
+    if t.dtype == torch.uint16:
+        t = t.view(torch.int16)
+    g = DeviceGrid(t)
+    g.sweep_many(isos)
+    for iso in isos + [isos[0]]:  # (the last one: its sweep was used up - the call sweeps for itself)
+        V, N, T, cnt = g.extract(iso)
+        ref = reflibs[dtype].isosurface(data, iso)
+        assert (cnt.nV, cnt.nT) == (ref.nV, ref.nT), (dtype, iso)
+        assert np.array_equal(T.cpu().numpy().view(np.uint32), ref.T) and beq(V.cpu().numpy(), ref.V), (dtype, iso)
+        nan = np.isnan(ref.N)
+        assert np.array_equal(N.cpu().numpy()[~nan].view(np.uint32), ref.N[~nan].view(np.uint32)), (dtype, iso)
+    # a slab with ghost slice; sweeps that are dropped unused; another range in between
+    nz = data.shape[0] - 1
+    rng = Range(nz // 2, nz, 1, 0)
+    g.sweep_many(isos[:3], rng)
+    V0, N0, T0, c0 = g.extract(isos[1])          # whole volume: no matching sweep
+    V1, N1, T1, c1 = g.extract(isos[1], rng)     # the slab: uses lane 1
+    g2 = DeviceGrid(t)
+    V2, N2, T2, c2 = g2.extract(isos[1], rng)
+    assert (c1.nV, c1.nT) == (c2.nV, c2.nT) and torch.equal(T1, T2) and torch.equal(V1.view(torch.int32), V2.view(torch.int32))
+    assert c0.nV == reflibs[dtype].isosurface(data, isos[1]).nV
