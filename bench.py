@@ -363,22 +363,32 @@ def main():
         # by the host layer outside the timed device path, so it is not credited here)
         out_bytes = (last[0] * 24 + last[1] * 12) / nis
         dev_ms = (sw + avg(scan_ms) + avg(emit_ms)) if (sw and emit_ms) else None
-        roof = {"bound": "hbm", "kernel": "k_sweep", "achieved": grid_bytes_alg / (sw * 1e-3) / 1e9 if sw else None,
+        # The dominant kernel is the sweep.  One launch reads every sample of the rank's slab once = its algorithmic bytes;
+        # with the iso sweep (c5) that one read serves `per_launch` isovalues, and the library reports each isovalue's
+        # share of the launch time: launch time = share x per_launch.
+        per_launch = 4 if sweep_many else 1
+        launch_ms = sw * per_launch
+        roof = {"bound": "hbm", "kernel": "k_sweep" + ("<%d isovalues per launch>" % per_launch if sweep_many else ""),
+                "achieved": grid_bytes_alg / (launch_ms * 1e-3) / 1e9 if sw else None,
                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": (grid_bytes_alg / (sw * 1e-3) / 1e9 / PEAK_HBM_GBS) if sw else None,
+                "frac": (grid_bytes_alg / (launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if sw else None,
                 "traffic": None, "traffic_source": None,
                 "algorithmic_bytes_per_launch": grid_bytes_alg,
-                # hipEvent brackets of the library, average per launch (= per isovalue): the sweep alone; k_cells +
+                "isovalues_per_launch": per_launch,
+                "launch_ms": launch_ms,
+                # hipEvent brackets of the library, average per isovalue: the sweep (its share of a launch); k_cells +
                 # slow-cell planning + the scan kernels; the emit kernels
                 "kernel_ms": {"k_sweep": sw, "k_cells_slow_scans": avg(scan_ms), "k_emit": avg(emit_ms) if emit_ms else None},
                 "kernel_ms_spread": {"k_sweep": spread(sweep_ms), "k_cells_slow_scans": spread(scan_ms), "k_emit": spread(emit_ms)},
+                # per calculate_isosurface call: the grid once + V, N, T - what the call would have to move
+                # on its own; the iso sweep moves less than that per call, which is the point of it
                 "whole_call": {"algorithmic_bytes": grid_bytes_alg + out_bytes, "device_ms": dev_ms,
                                "frac": ((grid_bytes_alg + out_bytes) / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if dev_ms else None}}
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc) and not multi:  # NOT measured in this run: replayed from the committed PMC passes of the same workload
             try:
                 j = json.load(open(pmc))
-                e = j.get(args.config if (args.points or 1024) == 1024 else "none")
+                e = j.get((args.config + ("" if not sweep_many else "_sweep_many")) if (args.points or 1024) == 1024 else "none")
                 if e:
                     roof["traffic"] = e.get("k_sweep_bytes_per_launch")
                     roof["traffic_source"] = "replayed: %s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this workload, build %s)" % (e.get("source"), e.get("build"))
