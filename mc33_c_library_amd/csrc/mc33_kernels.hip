@@ -830,11 +830,14 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		const uint32_t run = L.run[lane];
 		a.seg_cnt[sidx] = dirty ? 0u : seg_pack(run & 0xFFFFu, run >> 16);
 		const uint32_t nf = cnt | (dirty ? SEG_DIRTY : 0u);
-		uint4 *dq = (uint4 *)a.seg_dir[sidx].q;  // one 64-byte line per row, the rows of a wave back to back
-		dq[0] = uint4{(uint32_t)act[0], (uint32_t)(act[0] >> 32), first, nf};
-		dq[1] = uint4{(uint32_t)act[1], (uint32_t)(act[1] >> 32), first + c0, nf};
-		dq[2] = uint4{(uint32_t)act[2], (uint32_t)(act[2] >> 32), first + c0 + c1, nf};
-		dq[3] = uint4{(uint32_t)act[3], (uint32_t)(act[3] >> 32), first + c0 + c1 + c2, nf};
+		// one 64-byte line per row; only the words that hold cells are written (a lookup reads the word of an ACTIVE
+		// cell), and word 0 of a row with slow cells (k_seg_fix takes the record range from it): the few cut cells of
+		// a row mostly sit in one word, and these lines were the largest thing k_cells wrote
+		uint4 *dq = (uint4 *)a.seg_dir[sidx].q;
+		if (act[0] || dirty) dq[0] = uint4{(uint32_t)act[0], (uint32_t)(act[0] >> 32), first, nf};
+		if (act[1]) dq[1] = uint4{(uint32_t)act[1], (uint32_t)(act[1] >> 32), first + c0, nf};
+		if (act[2]) dq[2] = uint4{(uint32_t)act[2], (uint32_t)(act[2] >> 32), first + c0 + c1, nf};
+		if (act[3]) dq[3] = uint4{(uint32_t)act[3], (uint32_t)(act[3] >> 32), first + c0 + c1 + c2, nf};
 		if (dirty && first < a.entry_cap) a.dirty_list[atomicAdd(&a.ctr->dirty_cursor, 1u)] = (uint32_t)sidx;
 	}
 	if (a.trace && lane == 0) {
@@ -991,7 +994,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uin
 #pragma unroll
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
 		if (q0 + k < n) {
-			seg_base[st_idx[k]] = SegBase{ev, et};
+			if (cv[k] | ct[k]) seg_base[st_idx[k]] = SegBase{ev, et};  // (nobody asks for the base of a row segment that holds nothing)
 			if (q0 + k == ghost_segs) { ctr->ghostV = ev; ctr->ghostT = et; }  // first segment of the emitted range
 		}
 		ev += cv[k]; et += ct[k];
