@@ -384,8 +384,11 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 
 	// sign bits of the tile: word k of sample row r lives in lane r (layout S).  *_h: the halo sample's bit;
 	// *_z (wave-uniform): "some sample of this plane of the tile (halo included) equals the isovalue"
-	// (one set per isovalue lane)
-	uint64_t cur[NI][4], prev[NI][4];
+	// (one set per isovalue lane; with 4 lanes the bit rows of the plane below wait in LDS - they are touched once per
+	// plane, and in registers they cost the kernel a third of its waves)
+	constexpr bool PREV_LDS = NI >= 4;
+	__shared__ uint64_t s_prev[PREV_LDS ? NI : 1][4][PREV_LDS ? 256 : 1];
+	uint64_t cur[NI][4], prev[PREV_LDS ? 1 : NI][4];
 	uint32_t c_lo[NI][4], c_hi[NI][4];
 	uint32_t cur_h[NI], prev_h[NI];
 	bool cur_z[NI], prev_z[NI];
@@ -395,7 +398,10 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 #pragma unroll
 	for (int q = 0; q < NI; q++) {
 #pragma unroll
-		for (int k = 0; k < 4; k++) { prev[q][k] = 0; c_lo[q][k] = c_hi[q][k] = 0; }
+		for (int k = 0; k < 4; k++) {
+			if constexpr (PREV_LDS) s_prev[q][k][threadIdx.x] = 0; else prev[q][k] = 0;
+			c_lo[q][k] = c_hi[q][k] = 0;
+		}
 		cur_h[q] = prev_h[q] = 0; cur_z[q] = prev_z[q] = false; cur_written[q] = prev_written[q] = false; zmin[q] = 1;
 		iso[q] = a.lane[q].iso;
 	}
@@ -508,11 +514,15 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 			} else {
 				if (p == pl0 && pl0 != z_lo) leave_edge(0);
 				if (p > pl0) {
-					uint64_t act[4];
-					active_cells<S>(prev[q], cur[q], prev_h[q], cur_h[q], valid, rowvalid, act);
+					uint64_t act[4], pq[4];
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						if constexpr (PREV_LDS) pq[k] = s_prev[q][k][threadIdx.x]; else pq[k] = prev[q][k];
+					}
+					active_cells<S>(pq, cur[q], prev_h[q], cur_h[q], valid, rowvalid, act);
 					if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(MC33_DEBUG_BITS(a) & 16u)) {  // wave-uniform: hand the slice to k_cells
 						uint64_t ps[4], cs[4];  // (the counts only need popcounts of act: any layout)
-						to_standard<S>(prev[q], ps);
+						to_standard<S>(pq, ps);
 						to_standard<S>(cur[q], cs);
 						hand_over_slice(L, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), ps, cs,
 						                !prev_written[q], true, __ballot(prev_h[q] != 0), __ballot(cur_h[q] != 0), prev_z[q] || cur_z[q], act);
@@ -522,7 +532,9 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				if (p == z_hi && has_above) leave_edge(1);
 			}
 #pragma unroll
-			for (int k = 0; k < 4; k++) prev[q][k] = cur[q][k];
+			for (int k = 0; k < 4; k++) {
+				if constexpr (PREV_LDS) s_prev[q][k][threadIdx.x] = cur[q][k]; else prev[q][k] = cur[q][k];
+			}
 			prev_h[q] = cur_h[q];
 			prev_z[q] = cur_z[q];
 			prev_written[q] = cur_written[q];
