@@ -1,7 +1,7 @@
 """Python view of the C ABI (include/mc33_hip.h, include/marching_cubes_33.h).
 
 Plumbing only: device memory and streams come from PyTorch-ROCm, the work is done by the HIP kernels
-inside libMC33_{f32,u16}.so.  There is no CPU fallback: loading fails loudly when the shared object is
+inside libMC33_{f32,f64,u8,u16,u32}.so (one library per grid sample type).  There is no CPU fallback: loading fails loudly when the shared object is
 missing, and every call into it fails loudly when no GPU is present.
 """
 import ctypes as C
