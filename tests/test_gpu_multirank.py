@@ -118,3 +118,16 @@ def test_programs_built_against_the_reference_header(launcher):
             assert got["stdout"] == want["stdout"], (n, got["stdout"], want["stdout"])
             compared += 1
     assert compared >= 7
+
+
+@pytest.mark.parametrize("gather", ["allgather", "pairs", "root"])
+def test_bench_rccl_code_path_with_one_rank(launcher, gather):
+    """The N > 1 branch of bench.py with the REAL backend (RCCL through torch.distributed's "nccl"), as far as a one-GPU
+    box allows: MC33_BENCH_FORCE_DIST=1 runs one rank through init_process_group("nccl"), the second communicator of
+    the count exchange, the device-tensor collectives and the overlapped (async) exchange of two buffer sets."""
+    for args in (["--points", "160"], ["--config", "c5", "--points", "64"]):
+        res, out = bench(launcher, ["--steps", "4", "--warmup", "2", "--gather", gather, "--no-cpu-baseline"] + args,
+                         {"MC33_BENCH_REHEARSAL": "0", "MC33_BENCH_FORCE_DIST": "1", "MC33_BENCH_VERIFY": "1", "MASTER_PORT": str(PORT[0] + 500)})
+        PORT[0] += 1
+        assert res["n_gpus"] == 1 and res["gather"]["mode"] == gather and res["gather"]["overlapped_with_next_extraction"] is True
+        assert "equals whole-volume result: True" in out["stderr"]
