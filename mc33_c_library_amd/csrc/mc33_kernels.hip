@@ -294,10 +294,16 @@ __device__ __forceinline__ void store_plane_bits(const SweepLane &a, uint64_t pl
 // plane has not been written by this wave yet)
 __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slot, uint64_t slot_up, const uint64_t (&prev)[4],
                                                 const uint64_t (&cur)[4], bool write_prev, bool write_cur, uint64_t bp, uint64_t bc,
-                                                bool has_iso, const uint64_t (&act)[4]) {
+                                                bool has_iso, const uint64_t (&act)[4], uint32_t dev = 0) {
 	const uint32_t lane = threadIdx.x & 63u;
+#ifdef MC33_DEV  // MC33_HIP_DEBUG 32: no bit-plane stores, no header; 128: the bit-plane stores alone (the later passes see nothing)
+	if (dev & 32u) { write_prev = write_cur = false; }
+#endif
 	if (write_prev) store_plane_bits(a, slot, prev);
 	if (write_cur) store_plane_bits(a, slot_up, cur);
+#ifdef MC33_DEV
+	if (dev & (32u | 128u)) return;
+#endif
 	// cut cells and non-empty rows of the slice: the record ranges are prefix sums of these (k_slots)
 	uint32_t ncell = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
 	const uint32_t nrow = (uint32_t)__popcll(__ballot(ncell != 0));
@@ -525,7 +531,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 						to_standard<S>(pq, ps);
 						to_standard<S>(cur[q], cs);
 						hand_over_slice(L, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), ps, cs,
-						                !prev_written[q], true, __ballot(prev_h[q] != 0), __ballot(cur_h[q] != 0), prev_z[q] || cur_z[q], act);
+						                !prev_written[q], true, __ballot(prev_h[q] != 0), __ballot(cur_h[q] != 0), prev_z[q] || cur_z[q], act,
+						                MC33_DEBUG_BITS(a));
 						cur_written[q] = true;
 					}
 				}

@@ -18,9 +18,13 @@ else:
     t = fields.cos_field_u16(1024, 1024, 1024, dev)
     iso = 32768.5
 g = api.DeviceGrid(t)
-best = 1e9
-for _ in range(8):
-    g.count(iso)
-    best = min(best, g.timing().sweep_ms)
 gb = t.numel() * t.element_size() / 1e9
-print("%s DEBUG=%s NO_PACK=%s: sweep %.3f ms  %.0f GB/s" % (which, os.environ.get("MC33_HIP_DEBUG", "0"), os.environ.get("MC33_HIP_NO_PACK", "0"), best, gb / best * 1e3))
+# several settings in ONE process (same buffer: the allocation lottery of the sweep's speed is taken out)
+for dbg in (sys.argv[2].split(",") if len(sys.argv) > 2 else [os.environ.get("MC33_HIP_DEBUG", "0")]):
+    os.environ["MC33_HIP_DEBUG"] = dbg
+    ts = []
+    for _ in range(10):
+        g.count(iso)
+        ts.append(g.timing().sweep_ms)
+    ts.sort()
+    print("%s DEBUG=%s NO_PACK=%s: sweep min %.3f median %.3f ms  %.0f GB/s" % (which, dbg, os.environ.get("MC33_HIP_NO_PACK", "0"), ts[0], ts[len(ts) // 2], gb / ts[0] * 1e3))
