@@ -6,11 +6,13 @@
 //     -DMC33_GRD_U8 / _U16 / _U32 -> unsigned char / short / int samples (libMC33_u8 / _u16 / _u32.so)
 //
 // Passes of one extraction, in launch order ("MC:" = reference source/marching_cubes_33.c):
-//   k_sweep       - streams the volume once (MC:1832-1868) and does nothing else that costs bandwidth: sign bit
+//   k_sweep<S,NI> - streams the volume once (MC:1832-1868) and does nothing else that costs bandwidth: sign bit
 //                   per sample by wave ballot, the bit rows of a 64-row x 256-sample tile slice parked one row
 //                   per LANE, so that "is any cell of this slice cut" is a handful of 64-bit logic ops.  For
 //                   each slice that is cut it leaves the two 2 KiB bit planes (each plane once), a 32-byte
-//                   header (active cells, active rows, halo bits) and a partial sum for k_slots.
+//                   header (active cells, active rows, halo bits) and a partial sum for k_slots.  S: narrow
+//                   samples are loaded S to a dword; NI: isovalues classified per pass (mc33hip_sweep_many),
+//                   each with its own "lane" of output buffers.
 //   k_boundary    - the slice between two z-tiles of k_sweep, from the edge planes both left behind.
 //   k_slots       - exclusive sums of (cells, rows) over the slice slots in sweep order.
 //   k_cells       - one wave per cut slice, 64 active cells per step: case index from the bit planes, fast
