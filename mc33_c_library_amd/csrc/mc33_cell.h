@@ -645,6 +645,43 @@ MC33_HD Entry make_pending_entry(uint32_t xl, uint32_t i) {
 	return e;
 }
 
+// Storage of the work records.  In registers a record is an Entry; in HBM it is split in two 8-byte halves kept in two
+// arrays with the same index:
+//   A: x in the segment (8) | sign index (8) | nnew (4) | triangles (4) | slow flag (1 << 24)   ;   vertex offset (16) | triangle offset (16)
+//   B: ranks of edges 0..7   ;   ranks of edges 8..11 (16) | pattern offset (12) << 16
+// Half B of a FAST record is a function of its sign index (fast_b_table): it is never written or read - a fast
+// record costs 8 bytes of HBM traffic per pass instead of 16 (writes are what the passes after the sweep pay for most).
+struct EntryA { uint32_t a0, a1; };
+struct EntryB { uint32_t b0, b1; };
+constexpr uint32_t ENTRYA_SLOW = 1u << 24;
+MC33_HD EntryA entry_a(const Entry &e) {
+	return EntryA{(e.w0 & 0xFFFFu) | (e.w0 >> 28) << 16 | ((e.w3 >> 16) & 15u) << 20 | ((e.w3 & ENTRY_SLOW) ? ENTRYA_SLOW : 0u), e.w1};
+}
+MC33_HD EntryB entry_b(const Entry &e) { return EntryB{e.w2, (e.w3 & 0xFFFFu) | ((e.w0 >> 16) & 0xFFFu) << 16}; }
+MC33_HD Entry entry_join(const EntryA &a, const EntryB &b) {
+	Entry e;
+	e.w0 = (a.a0 & 0xFFFFu) | (b.b1 >> 16) << 16 | ((a.a0 >> 16) & 15u) << 28;
+	e.w1 = a.a1;
+	e.w2 = b.b0;
+	e.w3 = (b.b1 & 0xFFFFu) | ((a.a0 >> 20) & 15u) << 16 | ((a.a0 & ENTRYA_SLOW) ? ENTRY_SLOW : 0u);
+	return e;
+}
+MC33_HD uint32_t entrya_nnew(const EntryA &a) { return (a.a0 >> 16) & 15u; }
+MC33_HD uint32_t entrya_ntri(const EntryA &a) { return (a.a0 >> 20) & 15u; }
+// half B of the fast record of every sign index (zeros where the index is not fast)
+inline void fast_b_table(const uint32_t *fast /*[256]*/, EntryB *out /*[256]*/) {
+	for (uint32_t i = 0; i < 256; i++) {
+		out[i] = EntryB{0, 0};
+		if (fast[i] != FAST_NONE) out[i] = entry_b(make_fast_entry(0, i, fast[i], 0, 0));
+	}
+}
+// a record from its halves: half B from the table unless the record is slow
+MC33_HD Entry load_entry(const EntryA *ea, const EntryB *eb, const EntryB *fast_b, uint32_t ri) {
+	const EntryA a = ea[ri];
+	const EntryB b = (a.a0 & ENTRYA_SLOW) ? eb[ri] : fast_b[(a.a0 >> 8) & 0xFFu];
+	return entry_join(a, b);
+}
+
 inline void build_fast_table(const uint16_t *lut, uint32_t *fast /*[256]*/) {
 	Tables tab{lut, nullptr, nullptr};
 	Params P{};
@@ -713,13 +750,20 @@ MC33_HD SegCoord segment_coord(const Params &P, uint32_t s) {
 }
 
 template <typename T>
+struct EmitCtx;
+template <typename T>
+MC33_HD Entry ctx_entry(const EmitCtx<T> &c, uint32_t ri);
+
+template <typename T>
 struct EmitCtx {
 	Tables tab;
 	Params P;
 	GridView<T> G;
 	const SegBase *seg_base;
 	const SegDir *seg_dir;
-	const Entry *entries;
+	const EntryA *entries_a;    // work records, half A (all) and half B (slow records only)
+	const EntryB *entries_b;
+	const EntryB *fast_b;       // [256] half B of the fast records (may point into LDS)
 	const uint32_t *entry_seg;  // row segment of each entry
 	real_t *V;
 	float *N;
@@ -729,6 +773,9 @@ struct EmitCtx {
 	// known globally as k + id_delta; local triangle k is stored at k - t_skip.
 	uint32_t z_emit, v_skip, t_skip, id_delta;
 };
+
+template <typename T>
+MC33_HD Entry ctx_entry(const EmitCtx<T> &c, uint32_t ri) { return load_entry(c.entries_a, c.entries_b, c.fast_b, ri); }
 
 // per-segment counts packed in one word: vertices (<= 13*256) | triangles (<= 12*256) << 16
 MC33_HD uint32_t seg_pack(uint32_t nv, uint32_t nt) { return nv | nt << 16; }
@@ -770,7 +817,7 @@ MC33_HD uint32_t edge_vertex_id(const EmitCtx<T> &c, GridEdge g, const VRef &w) 
 		}
 		const uint32_t ri = find_record(c, s, o.x % SEG_CELLS);
 		if (ri == NO_ID) return NO_ID;
-		const Entry e = c.entries[ri];
+		const Entry e = ctx_entry(c, ri);
 		const uint32_t r = entry_rank(e, o.e);
 		if (r != 15u) return c.seg_base[s].vbase + (e.w1 & 0xFFFFu) + r;
 		// the owner itself took the id from another grid edge: recompute its plan to learn which
@@ -787,7 +834,7 @@ MC33_HD uint32_t edge_vertex_id(const EmitCtx<T> &c, GridEdge g, const VRef &w) 
 // v, w: 8-value scratch arrays; ids: 13-slot scratch.
 template <typename T>
 MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v, const VRef &w, const URef &ids) {
-	const Entry en = c.entries[entry_index];
+	const Entry en = ctx_entry(c, entry_index);
 	const uint32_t s = c.entry_seg[entry_index];
 	const SegCoord sc = segment_coord(c.P, s);
 	const uint32_t y = sc.y, z = sc.z;
@@ -989,15 +1036,15 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 			sd[g] = dir_word(c, gs, xl);
 			svb[g] = c.seg_base[gs].vbase;
 		}
-		const Entry prev = c.entries[need[1] ? self_index - 1 : self_index];  // o1: the cell x-1 is active whenever needed
+		const Entry prev = ctx_entry(c, need[1] ? self_index - 1 : self_index);  // o1: the cell x-1 is active whenever needed
 		uint32_t below[3];
 		for (int g = 0; g < 3; g++) below[g] = record_rank(sd[g], xl);  // the record of x in that segment (or where it would be)
 		// round trip 2: the records (x-1 is the record before x's position, it is active whenever needed)
-		oe[3] = c.entries[need[3] ? below[0] : self_index];
-		oe[0] = c.entries[need[0] ? below[0] - 1 : self_index];
-		oe[4] = c.entries[need[4] ? below[1] : self_index];
-		oe[2] = c.entries[need[2] ? below[1] - 1 : self_index];
-		oe[5] = c.entries[need[5] ? below[2] : self_index];
+		oe[3] = ctx_entry(c, need[3] ? below[0] : self_index);
+		oe[0] = ctx_entry(c, need[0] ? below[0] - 1 : self_index);
+		oe[4] = ctx_entry(c, need[4] ? below[1] : self_index);
+		oe[2] = ctx_entry(c, need[2] ? below[1] - 1 : self_index);
+		oe[5] = ctx_entry(c, need[5] ? below[2] : self_index);
 		oe[1] = prev;
 		ovb[0] = ovb[3] = svb[0]; ovb[2] = ovb[4] = svb[1]; ovb[5] = svb[2]; ovb[1] = sb.vbase;
 	} else {
@@ -1009,7 +1056,7 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 			const uint32_t oxl = need[o] ? ox % SEG_CELLS : xl;
 			const DirWord d = dir_word(c, os, oxl);
 			ovb[o] = c.seg_base[os].vbase;
-			oe[o] = c.entries[need[o] ? record_rank(d, oxl) : self_index];
+			oe[o] = ctx_entry(c, need[o] ? record_rank(d, oxl) : self_index);
 		}
 	}
 	uint32_t ob[6];

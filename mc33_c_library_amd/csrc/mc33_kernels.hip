@@ -682,7 +682,7 @@ struct CellsArgs {
 	const uint2 *slot_base;  // [slice_slot]: {first work record, first mask record} (k_slots)
 	uint32_t *seg_cnt;
 	SegDir *seg_dir;
-	Entry *entries;
+	EntryA *entries_a;       // work records, half A (half B only exists for slow records: k_slow_plan)
 	uint32_t *entry_seg;
 	uint32_t *slow_list, *dirty_list;
 	uint32_t entry_cap;
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 				if (ri < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = ri;
 			}
 			if (ri < a.entry_cap) {
-				a.entries[ri] = e;
+				a.entries_a[ri] = entry_a(e);  // (half B of a fast record follows from its sign index; k_slow_plan writes the others')
 				a.entry_seg[ri] = (uint32_t)(sidx0 + r);
 			}
 			if (kin + 1u == rowcnt || lane == 63u) L.run[r] = off + val;  // last cell of the row in this batch
@@ -876,7 +876,8 @@ struct SlowArgs {
 	Params P;
 	Tables tab;
 	uint32_t z_emit;  // slices below are ghosts of a z-slab
-	Entry *entries;
+	EntryA *entries_a;
+	EntryB *entries_b;
 	const uint32_t *entry_seg;
 	const uint32_t *slow_list;
 	uint32_t *seg_cnt;
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
 		const uint32_t ei = a.slow_list[t];
 		const uint32_t s = a.entry_seg[ei];
-		const uint32_t xl = a.entries[ei].w0 & 0xFFu;
+		const uint32_t xl = a.entries_a[ei].a0 & 0xFFu;
 		const SegCoord sc = segment_coord(P, s);
 		const uint32_t y = sc.y, z = sc.z, x = sc.xbase + xl;
 		const uint32_t i = load_cell(a.G, P.iso, x, y, z, v);
@@ -905,7 +906,9 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 		// Ghost cells only lend vertex ids to the slab above; their triangle count cancels out of every
 		// offset, so the identity test (which may read one more plane below) is skipped.
 		const uint32_t nt = z < a.z_emit ? pl.ntri : count_triangles(pl, a.tab, P, a.G, x, y, z, w);
-		a.entries[ei] = make_entry(xl, i, pl, nt, 0, 0, true);
+		const Entry en = make_entry(xl, i, pl, nt, 0, 0, true);
+		a.entries_a[ei] = entry_a(en);
+		a.entries_b[ei] = entry_b(en);
 	}
 }
 
@@ -918,10 +921,10 @@ __global__ __launch_bounds__(256) void k_seg_fix(const SlowArgs a) {
 		const uint32_t first = a.seg_dir[s].q[0][2], cnt = a.seg_dir[s].q[0][3] & ~SEG_DIRTY;
 		uint32_t nv = 0, nt = 0;
 		for (uint32_t k = 0; k < cnt; k++) {
-			Entry *e = a.entries + first + k;
-			e->w1 = nv | nt << 16;
-			nv += entry_nnew(*e);
-			nt += entry_ntri(*e);
+			EntryA *e = a.entries_a + first + k;  // (counts and offsets live in half A)
+			e->a1 = nv | nt << 16;
+			nv += entrya_nnew(*e);
+			nt += entrya_ntri(*e);
 		}
 		a.seg_cnt[s] = seg_pack(nv, nt);
 	}
@@ -1073,12 +1076,16 @@ __device__ __forceinline__ bool emit_prepare(const EmitArgs &a, EmitCtx<sample_t
 
 // vertices of the fast records (positions + normals)
 __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
+	__shared__ EntryB s_fast_b[256];
+	s_fast_b[threadIdx.x] = a.c.fast_b[threadIdx.x];
+	__syncthreads();
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
+	c.fast_b = s_fast_b;
 	if (!emit_prepare(a, c, ctr)) return;
 	const XcdWalk w(ctr.entry_cursor);
 	for (uint32_t e = w.first; e < w.end; e += w.stride) {
-		const Entry en = c.entries[e];
+		const Entry en = ctx_entry(c, e);
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, c.entry_seg[e]);
 	}
 }
@@ -1086,13 +1093,17 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 // triangles of the fast records (ids of shared edges through the owners' records)
 __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	__shared__ uint32_t s_id[12][256];
+	__shared__ EntryB s_fast_b[256];
+	s_fast_b[threadIdx.x] = a.c.fast_b[threadIdx.x];
+	__syncthreads();
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
+	c.fast_b = s_fast_b;
 	if (!emit_prepare(a, c, ctr)) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
 	const XcdWalk w(ctr.entry_cursor);
 	for (uint32_t e = w.first; e < w.end; e += w.stride) {
-		const Entry en = c.entries[e];
+		const Entry en = ctx_entry(c, e);
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, c.entry_seg[e], e, ids);
 	}
 }
@@ -1163,7 +1174,9 @@ struct mc33hip_ctx {
 	uint64_t seg_cap;
 	uint64_t *bsV, *bsT;
 	uint64_t bs_cap;
-	Entry *entries;
+	EntryA *entries_a;
+	EntryB *entries_b;
+	EntryB *d_fast_b;
 	uint32_t *entry_seg, *slow_list, *dirty_list;
 	uint64_t entry_cap;
 	IsoLane lanes[MC33_LANES]; // what a sweep leaves behind, per isovalue (lane 0: the single-isovalue calls)
@@ -1284,6 +1297,10 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 		fast_record_table(fast, rec);
 		CREATE_TRY(hipMalloc(&c->d_fast, sizeof rec));
 		CREATE_TRY(hipMemcpy(c->d_fast, rec, sizeof rec, hipMemcpyHostToDevice));
+		EntryB fb[256];
+		fast_b_table(fast, fb);
+		CREATE_TRY(hipMalloc(&c->d_fast_b, sizeof fb));
+		CREATE_TRY(hipMemcpy(c->d_fast_b, fb, sizeof fb, hipMemcpyHostToDevice));
 	}
 	CREATE_TRY(hipMalloc(&c->d_ctr, sizeof(Counters)));
 	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
@@ -1310,7 +1327,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_rules); (void)hipFree(c->d_rule_index); (void)hipFree(c->d_fast);
 	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
-	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
+	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->d_fast_b); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
 	for (int k = 0; k < MC33_LANES; k++) {
 		IsoLane &L = c->lanes[k];
 		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.slot_part); (void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
@@ -1486,11 +1503,12 @@ static uint32_t env_u32(const char *name, uint32_t dflt) {
 }
 
 static int alloc_entries(mc33hip_ctx *c, uint64_t cap) {
-	(void)hipFree(c->entries); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
-	c->entries = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr;
+	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
+	c->entries_a = nullptr; c->entries_b = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr;
 	c->entry_cap = 0;
 	if (cap > 0xFFFFFF00ull) cap = 0xFFFFFF00ull;
-	HIP_TRY(hipMalloc(&c->entries, cap * sizeof(Entry)));
+	HIP_TRY(hipMalloc(&c->entries_a, cap * sizeof(EntryA)));
+	HIP_TRY(hipMalloc(&c->entries_b, cap * sizeof(EntryB)));  // (touched for slow records only)
 	HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
 	HIP_TRY(hipMalloc(&c->slow_list, cap * 4));
 	HIP_TRY(hipMalloc(&c->dirty_list, cap * 4));
@@ -1517,7 +1535,7 @@ static int ensure_workspaces(mc33hip_ctx *c) {
 		HIP_TRY(hipMalloc(&c->bsT, nb * 8));
 		c->bs_cap = nb;
 	}
-	if (!c->entries) {
+	if (!c->entries_a) {
 		// first guess: one cell in 32 is cut (BASELINE fields: 0.4-6 % of the cells); grown on demand
 		const uint64_t cells = (uint64_t)c->P.nx * c->P.ny * (c->range.z_end - c->P.zs);
 		return alloc_entries(c, cells / 32 + 65536);
@@ -1735,7 +1753,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.slot_base = c->slot_base;
 	ca.epoch = L.epoch;
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir;
-	ca.entries = c->entries; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
+	ca.entries_a = c->entries_a; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
 	ca.entry_cap = (uint32_t)c->entry_cap;
 	ca.ctr = c->d_ctr;
 	ca.trace = nullptr;
@@ -1755,7 +1773,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	sa.G = a.G; sa.P = P;
 	sa.tab.lut = c->d_lut; sa.tab.rule_words = c->d_rules; sa.tab.rule_index = c->d_rule_index;
 	sa.z_emit = c->range.z_begin;
-	sa.entries = c->entries; sa.entry_seg = c->entry_seg; sa.slow_list = c->slow_list;
+	sa.entries_a = c->entries_a; sa.entries_b = c->entries_b; sa.entry_seg = c->entry_seg; sa.slow_list = c->slow_list;
 	sa.seg_cnt = c->seg_cnt; sa.seg_dir = c->seg_dir; sa.dirty_list = c->dirty_list;
 	sa.entry_cap = (uint32_t)c->entry_cap; sa.ctr = c->d_ctr;
 	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 256);
@@ -1872,7 +1890,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.c.P = c->P;
 	a.c.G.p = c->d_grid; a.c.G.pitch = (uint32_t)c->pitch; a.c.G.z0 = c->desc.plane0; a.c.G.slice = c->slice;
 	a.c.seg_base = c->seg_base; a.c.seg_dir = c->seg_dir;
-	a.c.entries = c->entries; a.c.entry_seg = c->entry_seg;
+	a.c.entries_a = c->entries_a; a.c.entries_b = c->entries_b; a.c.fast_b = c->d_fast_b; a.c.entry_seg = c->entry_seg;
 	a.c.V = (real_t *)dV; a.c.N = (float *)dN; a.c.Tri = (uint32_t *)dT;
 	a.c.z_emit = c->range.z_begin; a.c.v_skip = a.c.t_skip = a.c.id_delta = 0;
 	a.ctr = c->d_ctr;

@@ -113,7 +113,18 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	EmitCtx<T> c;
 	c.tab = tab; c.P = P; c.G = G;
 	c.seg_base = seg_base.data(); c.seg_dir = seg_dir.data();
-	c.entries = entries.data(); c.entry_seg = entry_seg.data();
+	// the records as the kernels store them: half A for all, half B only for slow records (fast ones: from the table)
+	std::vector<EntryA> ea(entries.size());
+	std::vector<EntryB> eb(entries.size(), EntryB{0xDEADBEEFu, 0xDEADBEEFu});
+	EntryB fast_b[256];
+	fast_b_table(fast, fast_b);
+	for (size_t k = 0; k < entries.size(); k++) {
+		ea[k] = entry_a(entries[k]);
+		if (entries[k].w3 & ENTRY_SLOW) eb[k] = entry_b(entries[k]);
+		const Entry back = load_entry(ea.data(), eb.data(), fast_b, (uint32_t)k);
+		if (back.w0 != entries[k].w0 || back.w1 != entries[k].w1 || back.w2 != entries[k].w2 || back.w3 != entries[k].w3) return -7;  // split / join must be lossless
+	}
+	c.entries_a = ea.data(); c.entries_b = eb.data(); c.fast_b = fast_b; c.entry_seg = entry_seg.data();
 	c.V = out->V; c.N = out->N; c.Tri = out->T;
 	c.z_emit = z_emit; c.v_skip = gV; c.t_skip = gT; c.id_delta = id_base - gV;
 	for (size_t k = 0; k < entries.size(); k++) {

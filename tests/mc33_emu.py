@@ -38,6 +38,7 @@ class Emu:
                             C.c_float, C.POINTER(OSURF)]
         self.lib.emu_free.argtypes = [C.POINTER(OSURF)]
         self.slab_fn = getattr(self.lib, "emu_slab_" + dtype)
+        self.slab_fn.restype = C.c_int
         self.slab_fn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.c_float, C.POINTER(SLAB), C.POINTER(OSURF), C.POINTER(C.c_ulonglong)]
         self.lib.emu_last_violations.restype = C.c_ulonglong
@@ -51,11 +52,13 @@ class Emu:
         da = (C.c_double * 3)(*(d if d is not None else (1.0, 1.0, 1.0)))
         s = OSURF()
         if slab is None:
-            self.fn(data.ctypes.data, nx, ny, nz, r0a, da, C.c_float(iso), C.byref(s))
+            rc = self.fn(data.ctypes.data, nx, ny, nz, r0a, da, C.c_float(iso), C.byref(s))
+            assert rc == 0, "emulator failed: %d" % rc
             self.violations = self.lib.emu_last_violations()
         else:
             viol = C.c_ulonglong(0)
-            self.slab_fn(data.ctypes.data, nx, ny, nz, r0a, da, C.c_float(iso), C.byref(SLAB(*slab)), C.byref(s), C.byref(viol))
+            rc = self.slab_fn(data.ctypes.data, nx, ny, nz, r0a, da, C.c_float(iso), C.byref(SLAB(*slab)), C.byref(s), C.byref(viol))
+            assert rc == 0, "emulator failed: %d" % rc
             self.violations = viol.value
 
         def arr(ptr, n, dt):
