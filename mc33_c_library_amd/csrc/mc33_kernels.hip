@@ -87,11 +87,18 @@ struct Counters {
 // that hold at least one cut cell; k_cells turns them into work records.
 struct SliceHeader {
 	uint32_t flags;       // bit 0: record valid (the slice holds cut cells); bit 1: a sample of the two tile
-	                      // planes equals the isovalue (no fast path for this slice)
+	                      // planes equals the isovalue
 	uint32_t prevh_lo, prevh_hi, curh_lo, curh_hi;  // halo-column bits of the 64 sample rows (ballots)
-	uint32_t cells, rows;  // cut cells of the slice / rows that hold some: what k_slots turns into record ranges
-	uint32_t pad_;
+	uint32_t cells;       // cut cells of the slice: what k_slots turns into record ranges
+	uint32_t zr_lo, zr_hi;  // bit r: a sample of sample ROW r (halo column included; to the sweep's batch of rows) of one of the
+	                      // two planes equals the isovalue - only cells of the rows r - 1 and r can have such a corner, not
+	                      // the whole slice (an integer grid with an integer isovalue has such samples all along the
+	                      // surface: the CT / MRI case)
+	uint32_t zc_lo, zc_hi;  // ... and bit L: a sample that LANE L of the sweep loaded does (lane <-> columns: lane_of_column)
+	uint32_t pad_[2];
 };
+// lane of the sweep wave that loaded column c (0..255) of a row segment; S = samples per lane and load
+__host__ __device__ inline uint32_t lane_of_column(uint32_t c, uint32_t S) { return S == 1 ? (c & 63u) : S == 2 ? ((c & 127u) >> 1) : (c >> 2); }
 constexpr uint32_t SLOT_CHUNK = 512;   // slice slots per partial sum (one k_slots block)
 constexpr uint32_t SLICE_VALID = 1u, SLICE_HAS_ISO = 2u;
 // The upper 30 bits of `flags` carry the number of the extraction that wrote the record (epoch >= 1): records
@@ -296,7 +303,7 @@ __device__ __forceinline__ void store_plane_bits(const SweepLane &a, uint64_t pl
 // plane has not been written by this wave yet)
 __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slot, uint64_t slot_up, const uint64_t (&prev)[4],
                                                 const uint64_t (&cur)[4], bool write_prev, bool write_cur, uint64_t bp, uint64_t bc,
-                                                bool has_iso, const uint64_t (&act)[4], uint32_t dev = 0) {
+                                                uint64_t zrows, uint64_t zcols, const uint64_t (&act)[4], uint32_t dev = 0) {
 	const uint32_t lane = threadIdx.x & 63u;
 #ifdef MC33_DEV  // MC33_HIP_DEBUG 32: no bit-plane stores, no header; 128: the bit-plane stores alone (the later passes see nothing)
 	if (dev & 32u) { write_prev = write_cur = false; }
@@ -313,10 +320,11 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 	for (int dlt = 32; dlt; dlt >>= 1) ncell += __shfl_xor(ncell, dlt);
 	if (lane == 0) {
 		SliceHeader h;
-		h.flags = a.epoch << 2 | SLICE_VALID | (has_iso ? SLICE_HAS_ISO : 0u);
+		h.flags = a.epoch << 2 | SLICE_VALID | (zrows ? SLICE_HAS_ISO : 0u);
 		h.prevh_lo = (uint32_t)bp; h.prevh_hi = (uint32_t)(bp >> 32);
 		h.curh_lo = (uint32_t)bc; h.curh_hi = (uint32_t)(bc >> 32);
-		h.cells = ncell; h.rows = nrow; h.pad_ = 0;
+		h.cells = ncell; h.zr_lo = (uint32_t)zrows; h.zr_hi = (uint32_t)(zrows >> 32);
+		h.zc_lo = (uint32_t)zcols; h.zc_hi = (uint32_t)(zcols >> 32); h.pad_[0] = h.pad_[1] = 0;
 		a.slice_hdr[slot] = h;
 		atomicAdd(a.slot_part + slot / SLOT_CHUNK, (unsigned long long)nrow << 32 | ncell);
 	}
@@ -354,7 +362,7 @@ constexpr int SWEEP_PACK = 1;
 // unsigned shorts / 4 unsigned chars - needs rows that start on a dword boundary (the host checks), and makes a batch
 // 8 / 16 sample rows instead of 4, so that a wave keeps the same 16 x 256 bytes in flight.
 template <int S, int NI>
-__global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_sweep(const SweepArgs a) {  // (3 waves per SIMD: at most 168 VGPRs - the 4-lane form sits right at that edge)
 	constexpr int LPR = 4 / S;    // loads per sample row
 	constexpr int RB = 16 / LPR;  // sample rows per batch
 	const uint32_t lane = threadIdx.x & 63u;
@@ -396,12 +404,16 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 	// plane, and in registers they cost the kernel a third of its waves)
 	constexpr bool PREV_LDS = NI >= 4;
 	__shared__ uint64_t s_prev[PREV_LDS ? NI : 1][4][PREV_LDS ? 256 : 1];
+	__shared__ uint64_t s_prevz[PREV_LDS ? NI : 1][2][4];  // ... and its 'sample equals the isovalue' row / lane masks, per wave
+	const uint32_t wv = threadIdx.x >> 6;
 	uint64_t cur[NI][4], prev[PREV_LDS ? 1 : NI][4];
 	uint32_t c_lo[NI][4], c_hi[NI][4];
 	uint32_t cur_h[NI], prev_h[NI];
-	bool cur_z[NI], prev_z[NI];
+	uint64_t cur_zc[NI], prev_zc[PREV_LDS ? 1 : NI], zcacc[NI];  // ... and the lanes that loaded one
+	uint64_t cur_z[NI], prev_z[PREV_LDS ? 1 : NI], zacc[NI];  // sample rows of the plane that hold a sample equal to the isovalue (wave-uniform),
+	                                           // to the batch of RB rows: one compare per batch, not per row
+	real_t zmin[NI];  // min |iso - F| over the lane's samples of the batch being processed
 	bool cur_written[NI], prev_written[NI];  // the plane's bit rows are already in slice_bits
-	real_t zmin[NI];  // min |iso - F| over the lane's samples of the plane being assembled
 	real_t iso[NI];
 #pragma unroll
 	for (int q = 0; q < NI; q++) {
@@ -410,7 +422,9 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 			if constexpr (PREV_LDS) s_prev[q][k][threadIdx.x] = 0; else prev[q][k] = 0;
 			c_lo[q][k] = c_hi[q][k] = 0;
 		}
-		cur_h[q] = prev_h[q] = 0; cur_z[q] = prev_z[q] = false; cur_written[q] = prev_written[q] = false; zmin[q] = 1;
+		cur_h[q] = prev_h[q] = 0; cur_z[q] = zacc[q] = 0; cur_zc[q] = zcacc[q] = 0;
+		if constexpr (PREV_LDS) { s_prevz[q][0][wv] = 0; s_prevz[q][1][wv] = 0; } else { prev_z[q] = 0; prev_zc[q] = 0; }
+		cur_written[q] = prev_written[q] = false; zmin[q] = 1;
 		iso[q] = a.lane[q].iso;
 	}
 
@@ -492,6 +506,12 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				    : "m0");
 			}
 		}
+#pragma unroll
+		for (int q = 0; q < NI; q++) {  // a sample of these RB rows equals the isovalue: mark the rows
+			const uint64_t zb = __ballot(zmin[q] == 0);
+			if (zb) { zacc[q] |= ((1ull << RB) - 1ull) << r; zcacc[q] |= zb; }
+			zmin[q] = 1;
+		}
 		if (bi != NB - 1) return;
 		// ---- the plane is complete ----
 #pragma unroll
@@ -505,9 +525,10 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 #ifdef MC33_NAN_SAMPLES
 				cur_h[q] ^= (uint32_t)(dh != dh);
 #endif
-				if (lane < nrows) zmin[q] = real_min(zmin[q], real_abs(dh));  // lanes past the tile never loaded a halo sample
-				cur_z[q] = __ballot(zmin[q] == 0) != 0ull;  // some sample of this plane of the tile equals the isovalue
-				zmin[q] = 1;
+				const uint64_t zh = __ballot(lane < nrows && dh == 0);  // (lanes past the tile never loaded a halo sample)
+				cur_z[q] = zacc[q] | zh;
+				cur_zc[q] = zh ? ~0ull : zcacc[q];  // (a halo sample: any column)
+				zacc[q] = zcacc[q] = 0;
 			}
 			auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary (standard layout)
 				uint64_t w[4];
@@ -516,7 +537,10 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				e[0] = uint4{(uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32)};
 				e[64] = uint4{(uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32)};
 				const uint64_t bh = __ballot(cur_h[q] != 0);
-				if (lane == 0) L.edge_hdr[(uint64_t)wtile * 2u + which] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), cur_z[q] ? 1u : 0u, 0u};
+				if (lane == 0) {
+					L.edge_hdr[((uint64_t)wtile * 2u + which) * 2u] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), (uint32_t)cur_z[q], (uint32_t)(cur_z[q] >> 32)};
+					L.edge_hdr[((uint64_t)wtile * 2u + which) * 2u + 1u] = uint4{(uint32_t)cur_zc[q], (uint32_t)(cur_zc[q] >> 32), 0u, 0u};
+				}
 			};
 			if (MC33_DEBUG_BITS(a) & 2u) {
 			} else {
@@ -530,10 +554,12 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 					active_cells<S>(pq, cur[q], prev_h[q], cur_h[q], valid, rowvalid, act);
 					if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(MC33_DEBUG_BITS(a) & 16u)) {  // wave-uniform: hand the slice to k_cells
 						uint64_t ps[4], cs[4];  // (the counts only need popcounts of act: any layout)
+						uint64_t pz, pzc;
+						if constexpr (PREV_LDS) { pz = s_prevz[q][0][wv]; pzc = s_prevz[q][1][wv]; } else { pz = prev_z[q]; pzc = prev_zc[q]; }
 						to_standard<S>(pq, ps);
 						to_standard<S>(cur[q], cs);
 						hand_over_slice(L, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), ps, cs,
-						                !prev_written[q], true, __ballot(prev_h[q] != 0), __ballot(cur_h[q] != 0), prev_z[q] || cur_z[q], act,
+						                !prev_written[q], true, __ballot(prev_h[q] != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act,
 						                MC33_DEBUG_BITS(a));
 						cur_written[q] = true;
 					}
@@ -545,7 +571,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 				if constexpr (PREV_LDS) s_prev[q][k][threadIdx.x] = cur[q][k]; else prev[q][k] = cur[q][k];
 			}
 			prev_h[q] = cur_h[q];
-			prev_z[q] = cur_z[q];
+			if constexpr (PREV_LDS) { s_prevz[q][0][wv] = cur_z[q]; s_prevz[q][1][wv] = cur_zc[q]; } else { prev_z[q] = cur_z[q]; prev_zc[q] = cur_zc[q]; }
 			prev_written[q] = cur_written[q];
 			cur_written[q] = false;
 		}
@@ -590,7 +616,7 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 	const uint64_t rp = (uint64_t)b.below * 2u + 1u, rc = (uint64_t)b.above * 2u;  // top of below, bottom of above
 	const uint4 p0 = L.edge_bits[rp * 128u + lane], p1 = L.edge_bits[rp * 128u + 64u + lane];
 	const uint4 c0 = L.edge_bits[rc * 128u + lane], c1 = L.edge_bits[rc * 128u + 64u + lane];
-	const uint4 hp = L.edge_hdr[rp], hc = L.edge_hdr[rc];
+	const uint4 hp = L.edge_hdr[rp * 2u], hc = L.edge_hdr[rc * 2u], zp = L.edge_hdr[rp * 2u + 1u], zc = L.edge_hdr[rc * 2u + 1u];
 	const uint64_t prev[4] = {u64(p0.x, p0.y), u64(p0.z, p0.w), u64(p1.x, p1.y), u64(p1.z, p1.w)};
 	const uint64_t cur[4] = {u64(c0.x, c0.y), u64(c0.z, c0.w), u64(c1.x, c1.y), u64(c1.z, c1.w)};
 	const uint64_t bp = u64(hp.x, hp.y), bc = u64(hc.x, hc.y);
@@ -601,7 +627,7 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 	if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull))
 		// (the two tiles may have written these planes for slices of their own: same bytes again)
 		hand_over_slice(L, slice_slot(b.z - P.zs, b.yt, seg, a.nYT, a.nseg_pad), slice_slot(b.z + 1u - P.zs, b.yt, seg, a.nYT, a.nseg_pad), prev, cur,
-		                true, true, bp, bc, (hp.z | hc.z) != 0u, act);
+		                true, true, bp, bc, u64(hp.z, hp.w) | u64(hc.z, hc.w), u64(zp.x, zp.y) | u64(zc.x, zc.y), act);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -639,7 +665,7 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 		const bool in = s0 + k < nslots;
 		const uint4 h = in ? *(const uint4 *)((const uint32_t *)(hdr + s0 + k) + 4) : uint4{0, 0, 0, 0};  // {curh_hi, cells, rows, pad}
 		const bool valid = in && slice_valid(hdr[s0 + k].flags, epoch);
-		cells[k] = valid ? h.y : 0u; rows[k] = valid ? h.z : 0u;
+		cells[k] = valid ? h.y : 0u; rows[k] = 0u;
 		mine += (unsigned long long)rows[k] << 32 | cells[k];
 	}
 	s_red[t] = mine;
@@ -673,6 +699,8 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 // segmented scan over the 64 cells.  Records of a slice are written as one contiguous run.
 // ---------------------------------------------------------------------------------------------------
 struct CellsArgs {
+	uint32_t pack;           // samples per lane and load of the sweep that made the records (lane_of_column)
+	GridView<sample_t> G;    // (only looked at for cells of rows that may hold a sample equal to the isovalue)
 	Params P;
 	const uint4 *fast;       // per sign index: record words of a FAST cell (fast_record_table)
 	uint32_t ze, nYT, nseg_pad;
@@ -772,12 +800,15 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 
 	// rows whose cells cannot take the fast path: on the y = 0 / z = 0 faces (extra owned edges), or in a
 	// tile plane pair that holds a sample equal to the isovalue
-	const bool planeslow = z == 0 || (h.flags & SLICE_HAS_ISO);  // wave-uniform
+	const uint64_t zc = u64(h.zc_lo, h.zc_hi);  // ... and the sweep lanes that loaded one
+	const uint64_t zr = u64(h.zr_lo, h.zr_hi);  // sample rows with a sample equal to the isovalue: the cells of rows r - 1 and r
 #pragma unroll
 	for (int k = 0; k < 4; k++) { L.bits[lane][k] = prev[k]; L.bits[lane][4 + k] = cur[k]; L.act[lane][k] = act[k]; }
 	L.incl[lane] = incl;
 	L.run[lane] = 0;
-	L.slowrow[lane] = (y == 0 || planeslow) ? 1u : 0u;  // becomes 2 when a cell of the row went to the slow list
+	// bit 0: no cell of the row can take the fast path (grid faces); bit 2: a corner may equal the isovalue - the cell's
+	// own 8 samples decide; bit 1 is set when a cell of the row went to the slow list
+	L.slowrow[lane] = ((y == 0 || z == 0) ? 1u : 0u) | (((zr >> lane) & 3ull) ? 4u : 0u);
 	const uint32_t first = ebase + incl - cnt;
 	const unsigned long long t_rows = a.trace ? __builtin_amdgcn_s_memrealtime() + (first & 0u) : 0ull;
 	const uint64_t sidx0 = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y0;
@@ -816,7 +847,19 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		}
 		const uint4 f = s_fast[i];
 		const uint32_t rowflag = L.slowrow[r];
-		const bool fastcell = on && !(rowflag & 1u) && f.x != FAST_NONE && (xbase + xl) != 0;
+		bool zero_corner = false;
+		// (its row may hold such a sample, and so may one of its two columns: then the cell's own 8 samples decide)
+		const bool look = on && (rowflag & 5u) == 4u && f.x != FAST_NONE &&
+		                  (xl == 255u || ((zc >> lane_of_column(xl, a.pack)) | (zc >> lane_of_column(min(xl + 1u, 255u), a.pack))) & 1ull);
+		if (__ballot(look)) {  // wave-uniform
+			if (look) {
+				const uint32_t cx = xbase + xl, cy = y0 + r;
+#pragma unroll
+				for (uint32_t k = 0; k < 8; k++)
+					zero_corner |= iso_diff(P.iso, (real_t)a.G.at(cx + (k & 1u), cy + ((k >> 1) & 1u), z + (k >> 2))) == 0;
+			}
+		}
+		const bool fastcell = on && !(rowflag & 1u) && !zero_corner && f.x != FAST_NONE && (xbase + xl) != 0;
 		const uint32_t val = fastcell ? ((f.w & 0xFFu) | (f.w >> 8) << 16) : 0u;  // new vertices | triangles << 16
 		// offsets inside the row segment: exclusive scan over the cells of the same row
 		uint32_t sc = val;
@@ -1680,7 +1723,7 @@ static int begin_lane(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g, hipStream_t
 		(void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
 		L.edge_bits = nullptr; L.edge_hdr = nullptr; L.edge_cap = 0;
 		HIP_TRY(hipMalloc(&L.edge_bits, c->ntiles * 2 * 128 * sizeof(uint4)));
-		HIP_TRY(hipMalloc(&L.edge_hdr, c->ntiles * 2 * sizeof(uint4)));
+		HIP_TRY(hipMalloc(&L.edge_hdr, c->ntiles * 2 * 2 * sizeof(uint4)));
 		L.edge_cap = c->ntiles;
 	}
 	const uint64_t nchunks = (L.slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;  // (capacity: the halves keep their place)
@@ -1714,15 +1757,18 @@ static void set_lane(SweepArgs &a, int q, const IsoLane &L, double iso) {
 	a.lane[q] = SweepLane{L.slice_hdr, L.slice_bits, lane_part(L, false), L.edge_bits, L.edge_hdr, L.epoch, (real_t)iso};
 }
 
+// narrow samples are loaded as dwords when every row of the grid starts on a dword boundary (always true for the
+// library's own pitched copy; a caller's device buffer may have any pitch)
+static bool sweep_packed(const mc33hip_ctx *c) {
+	return SWEEP_PACK > 1 && !env_u32("MC33_HIP_NO_PACK", 0) && ((uintptr_t)c->d_grid % 4u) == 0 && (c->pitch * sizeof(sample_t)) % 4u == 0 &&
+	       (c->slice * sizeof(sample_t)) % 4u == 0;
+}
+
 // one k_sweep launch over NI = 1, 2 or 4 lanes that begin_lane has prepared
 template <int NI>
 static void launch_sweep_ni(mc33hip_ctx *c, const SweepArgs &a, hipStream_t st) {
 	const uint64_t blocks = (c->ntiles + 3) / 4;
-	// narrow samples are loaded as dwords when every row of the grid starts on a dword boundary (always true for the
-	// library's own pitched copy; a caller's device buffer may have any pitch)
-	const bool packed = SWEEP_PACK > 1 && !env_u32("MC33_HIP_NO_PACK", 0) && ((uintptr_t)c->d_grid % 4u) == 0 &&
-	                    (c->pitch * sizeof(sample_t)) % 4u == 0 && (c->slice * sizeof(sample_t)) % 4u == 0;
-	if (packed) hipLaunchKernelGGL((k_sweep<SWEEP_PACK, NI>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
+	if (sweep_packed(c)) hipLaunchKernelGGL((k_sweep<SWEEP_PACK, NI>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
 	else hipLaunchKernelGGL((k_sweep<1, NI>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
 }
 
@@ -1748,6 +1794,8 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 		hipLaunchKernelGGL(k_boundary, dim3((uint32_t)((c->nbounds + 3) / 4)), dim3(256), 0, st, a, c->d_bounds, (uint32_t)c->nbounds, 0u);
 	L.boundary_done = true;  // (its slices are in the partial sums now: a repeated tail - more room for records - must not add them again)
 	CellsArgs ca;
+	ca.pack = sweep_packed(c) ? (uint32_t)SWEEP_PACK : 1u;
+	ca.G.p = c->d_grid; ca.G.pitch = (uint32_t)c->pitch; ca.G.z0 = c->desc.plane0; ca.G.slice = c->slice;
 	ca.P = P; ca.fast = c->d_fast;
 	ca.ze = ze; ca.nYT = g.nYT; ca.nseg_pad = g.nseg;
 	ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.slot_base = c->slot_base;
@@ -1776,7 +1824,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	sa.entries_a = c->entries_a; sa.entries_b = c->entries_b; sa.entry_seg = c->entry_seg; sa.slow_list = c->slow_list;
 	sa.seg_cnt = c->seg_cnt; sa.seg_dir = c->seg_dir; sa.dirty_list = c->dirty_list;
 	sa.entry_cap = (uint32_t)c->entry_cap; sa.ctr = c->d_ctr;
-	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 256);
+	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);  // (blocks beyond the list end at once)
 	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks), dim3(256), 0, st, sa);
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
 	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
@@ -1920,7 +1968,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);
 	hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, sv, a);
 	if (fork) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
-	hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 256)), dim3(256), 0, ss, a);
+	hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, ss, a);
 	if (fork) HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
 	HIP_TRY(hipGetLastError());
 	if (fork) {
