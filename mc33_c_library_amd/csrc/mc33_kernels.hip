@@ -630,6 +630,60 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 		                true, true, bp, bc, u64(hp.z, hp.w) | u64(hc.z, hc.w), u64(zp.x, zp.y) | u64(zc.x, zc.y), act);
 }
 
+// Lists of the slow cells and of the row segments they make "dirty".  k_cells appends to them; ONE cursor for the whole
+// grid meant one atomic address that every wave with a slow cell queues at (an integer grid with an integer isovalue
+// has such cells all along the surface: the atomics alone made k_cells 1.0 ms instead of 0.2).  So the slice slots are
+// cut into at most LIST_CHUNKS groups of 2^shift consecutive slots; group g appends - with its own cursor - into the part
+// of the list that starts at the index of the group's first work record: a group cannot hold more slow cells (or dirty
+// rows) than records, so the parts cannot collide, and nothing has to be sized.  The consumers (k_slow_plan, k_seg_fix,
+// k_emit_slow) turn a flat index into (group, position) with a prefix sum of the group counts, rebuilt by every block
+// in LDS.
+constexpr uint32_t LIST_CHUNKS = 4096;
+struct ListChunks {
+	uint32_t *slow_cnt, *dirty_cnt;  // [n]
+	uint32_t n, shift;               // groups, log2 of slots per group
+};
+
+struct ChunkMap {  // per block, in LDS: exclusive prefix sums of the group counts
+	uint32_t *pre;   // [LIST_CHUNKS + 1]
+	uint32_t n, total;
+	// all threads of the block; red: 256 words of scratch
+	__device__ void build(uint32_t *lds, uint32_t *red, const uint32_t *cnt, uint32_t n_) {
+		pre = lds; n = n_;
+		constexpr uint32_t PER = LIST_CHUNKS / 256;
+		const uint32_t t = threadIdx.x, q0 = t * PER;
+		uint32_t v[PER], sum = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < PER; k++) { v[k] = q0 + k < n ? cnt[q0 + k] : 0u; sum += v[k]; }
+		red[t] = sum;
+		__syncthreads();
+		for (uint32_t d = 1; d < 256; d <<= 1) {
+			const uint32_t x = t >= d ? red[t - d] : 0u;
+			__syncthreads();
+			red[t] += x;
+			__syncthreads();
+		}
+		uint32_t run = red[t] - sum;
+#pragma unroll
+		for (uint32_t k = 0; k < PER; k++) { pre[q0 + k] = run; run += v[k]; }
+		if (t == 255) pre[LIST_CHUNKS] = run;
+		__syncthreads();
+		total = pre[LIST_CHUNKS];
+	}
+	// flat index -> group g with pre[g] <= i < pre[g + 1]
+	__device__ uint32_t group_of(uint32_t i) const {
+		uint32_t lo = 0, hi = LIST_CHUNKS;  // invariant: pre[lo] <= i < pre[hi]
+#pragma unroll
+		for (int s = 0; s < 12; s++) {
+			const uint32_t mid = (lo + hi) >> 1;
+			const bool right = pre[mid] <= i;
+			lo = right ? mid : lo;
+			hi = right ? hi : mid;
+		}
+		return lo;
+	}
+};
+
 // ---------------------------------------------------------------------------------------------------
 // k_slots: exclusive prefix sums of (cut cells, non-empty rows) over the slice slots in slot order = the
 // work-record range and the mask-record range of every slice.  The sweep has already added every slice
@@ -637,11 +691,12 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 // own chunk.  Record order is therefore a function of the grid alone (no allocation atomics).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const unsigned long long *part, unsigned long long *part_next,
-                                               uint32_t part_cap, uint32_t epoch, uint64_t nslots, uint2 *slot_base, Counters *ctr) {
+                                               uint32_t part_cap, uint32_t epoch, uint64_t nslots, uint2 *slot_base, Counters *ctr, ListChunks lc) {
 	__shared__ unsigned long long s_red[256];
 	const uint32_t c = blockIdx.x, t = threadIdx.x;
 	if (t == 0) part_next[c] = 0;  // the partial sums of the NEXT extraction live in the other half: cleared here
 	if (c == 0) for (uint32_t q = gridDim.x + t; q < part_cap; q += 256u) part_next[q] = 0;  // (a later range may be longer)
+	if (c == 0) for (uint32_t q = t; q < lc.n; q += 256u) { lc.slow_cnt[q] = 0; lc.dirty_cnt[q] = 0; }  // the list cursors of this extraction
 	if (c == 0 && t == 0) {        // ... and so are the counters the later passes of this one add to
 		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0;
 		ctr->totV = ctr->totT = ctr->ghostV = ctr->ghostT = 0;
@@ -699,6 +754,7 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 // segmented scan over the 64 cells.  Records of a slice are written as one contiguous run.
 // ---------------------------------------------------------------------------------------------------
 struct CellsArgs {
+	uint32_t dev;            // (-DMC33_DEV: MC33_HIP_CELLS_DEV experiments)
 	uint32_t pack;           // samples per lane and load of the sweep that made the records (lane_of_column)
 	GridView<sample_t> G;    // (only looked at for cells of rows that may hold a sample equal to the isovalue)
 	Params P;
@@ -713,6 +769,7 @@ struct CellsArgs {
 	EntryA *entries_a;       // work records, half A (half B only exists for slow records: k_slow_plan)
 	uint32_t *entry_seg;
 	uint32_t *slow_list, *dirty_list;
+	ListChunks lc;
 	uint32_t entry_cap;
 	Counters *ctr;
 	unsigned long long *trace;  // MC33_HIP_TRACE_CELLS: per wave {start, bits in, rows done, end}
@@ -758,12 +815,14 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 	h.flags = 0; h.cells = 0;
 	uint4 q[4] = {};
 	uint2 base = {0u, 0u};
+	uint32_t lbase = 0;
 	if (in_grid) {  // header, ranges and bit rows are fetched together (one round trip); the rows of a slice
 		// without cut cells are whatever an earlier call left there and are not looked at.  (Fetching the bit rows only
 		// once the header says the slice is cut - two thirds of the slots of a smooth field are not - saves 180 MB of
 		// reads at 1024^3 and no time: measured, round 2)
 		h = a.slice_hdr[slot];
 		base = a.slot_base[slot];
+		lbase = a.slot_base[(slot >> a.lc.shift) << a.lc.shift].x;  // where the list part of the slot's group begins
 		// bit rows of the two planes of the slice (the upper plane's record sits in the slot of the slice above)
 		const uint4 *lower = a.slice_bits + slot * 128u + lane;
 		const uint4 *upper = a.slice_bits + slice_slot(z + 1u - P.zs, yt, seg, a.nYT, a.nseg_pad) * 128u + lane;
@@ -851,7 +910,12 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		// (its row may hold such a sample, and so may one of its two columns: then the cell's own 8 samples decide)
 		const bool look = on && (rowflag & 5u) == 4u && f.x != FAST_NONE &&
 		                  (xl == 255u || ((zc >> lane_of_column(xl, a.pack)) | (zc >> lane_of_column(min(xl + 1u, 255u), a.pack))) & 1ull);
+#ifdef MC33_DEV
+		if (a.dev & 1u) zero_corner = look;  // experiment: no look at the samples (every candidate goes the slow way)
+		if (__ballot(look) && !(a.dev & 1u)) {
+#else
 		if (__ballot(look)) {  // wave-uniform
+#endif
 			if (look) {
 				const uint32_t cx = xbase + xl, cy = y0 + r;
 #pragma unroll
@@ -872,6 +936,17 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		const uint32_t before_head = __shfl(sc, head) - __shfl(val, head);
 		const uint32_t carry = kin > lane ? L.run[r] : 0u;  // the row began in an earlier batch
 		const uint32_t off = carry + (sc - val) - before_head;
+		{  // the slow cells of the batch go on the list of the slot's group, one atomic per wave
+			const bool slowlane = on && !fastcell && ebase + g < a.entry_cap;
+			const uint64_t sm = __ballot(slowlane);
+			if (sm) {
+				const uint32_t leader = (uint32_t)__builtin_ctzll(sm);
+				uint32_t at = 0;
+				if (lane == leader) at = atomicAdd(&a.lc.slow_cnt[slot >> a.lc.shift], (uint32_t)__popcll(sm));
+				at = lbase + __shfl(at, leader) + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+				if (slowlane && at < a.entry_cap) a.slow_list[at] = ebase + g;
+			}
+		}
 		if (on) {
 			const uint32_t ri = ebase + g;
 			Entry e;
@@ -879,7 +954,6 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 			else {
 				e = make_pending_entry(xl, i);
 				L.slowrow[r] = rowflag | 2u;
-				if (ri < a.entry_cap) a.slow_list[atomicAdd(&a.ctr->slow_cursor, 1u)] = ri;
 			}
 			if (ri < a.entry_cap) {
 				a.entries_a[ri] = entry_a(e);  // (half B of a fast record follows from its sign index; k_slow_plan writes the others')
@@ -902,7 +976,17 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		if (act[1]) dq[1] = uint4{(uint32_t)act[1], (uint32_t)(act[1] >> 32), first + c0, nf};
 		if (act[2]) dq[2] = uint4{(uint32_t)act[2], (uint32_t)(act[2] >> 32), first + c0 + c1, nf};
 		if (act[3]) dq[3] = uint4{(uint32_t)act[3], (uint32_t)(act[3] >> 32), first + c0 + c1 + c2, nf};
-		if (dirty && first < a.entry_cap) a.dirty_list[atomicAdd(&a.ctr->dirty_cursor, 1u)] = (uint32_t)sidx;
+	}
+	{  // rows with slow cells: the same
+		const bool dirtylane = rowvalid && cnt && (L.slowrow[lane] & 2u) && first < a.entry_cap;
+		const uint64_t dm = __ballot(dirtylane);
+		if (dm) {
+			const uint32_t leader = (uint32_t)__builtin_ctzll(dm);
+			uint32_t at = 0;
+			if (lane == leader) at = atomicAdd(&a.lc.dirty_cnt[slot >> a.lc.shift], (uint32_t)__popcll(dm));
+			at = lbase + __shfl(at, leader) + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+			if (dirtylane && at < a.entry_cap) a.dirty_list[at] = (uint32_t)sidx;
+		}
 	}
 	if (a.trace && lane == 0) {
 		unsigned long long *tr = a.trace + 4ull * slot;
@@ -926,6 +1010,8 @@ struct SlowArgs {
 	uint32_t *seg_cnt;
 	const SegDir *seg_dir;
 	const uint32_t *dirty_list;
+	ListChunks lc;
+	const uint2 *slot_base;
 	uint32_t entry_cap;
 	Counters *ctr;
 };
@@ -933,12 +1019,17 @@ struct SlowArgs {
 __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 	__shared__ real_t s_v[8][256];
 	__shared__ real_t s_w[8][256];
+	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+	ChunkMap cm;
+	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);  // (first: its loads and the one of the cursor below go out together)
 	if (a.ctr->entry_cursor > a.entry_cap) return;  // the sweep will be repeated with more room
-	const uint32_t n = a.ctr->slow_cursor;
+	const uint32_t n = cm.total;
+	if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->slow_cursor = n;  // (for the host's report)
 	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
 	const Params &P = a.P;
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
-		const uint32_t ei = a.slow_list[t];
+		const uint32_t gq = cm.group_of(t);
+		const uint32_t ei = a.slow_list[a.slot_base[(uint64_t)gq << a.lc.shift].x + (t - cm.pre[gq])];
 		const uint32_t s = a.entry_seg[ei];
 		const uint32_t xl = a.entries_a[ei].a0 & 0xFFu;
 		const SegCoord sc = segment_coord(P, s);
@@ -957,10 +1048,15 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 
 // one thread per row segment that holds slow cells: running offsets of its records, segment totals
 __global__ __launch_bounds__(256) void k_seg_fix(const SlowArgs a) {
+	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+	ChunkMap cm;
+	cm.build(s_pre, s_red, a.lc.dirty_cnt, a.lc.n);
 	if (a.ctr->entry_cursor > a.entry_cap) return;
-	const uint32_t n = a.ctr->dirty_cursor;
+	const uint32_t n = cm.total;
+	if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->dirty_cursor = n;
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
-		const uint32_t s = a.dirty_list[t];
+		const uint32_t gq = cm.group_of(t);
+		const uint32_t s = a.dirty_list[a.slot_base[(uint64_t)gq << a.lc.shift].x + (t - cm.pre[gq])];
 		const uint32_t first = a.seg_dir[s].q[0][2], cnt = a.seg_dir[s].q[0][3] & ~SEG_DIRTY;
 		uint32_t nv = 0, nt = 0;
 		for (uint32_t k = 0; k < cnt; k++) {
@@ -1076,6 +1172,8 @@ struct EmitArgs {
 	EmitCtx<sample_t> c;
 	Counters *ctr;
 	const uint32_t *slow_list;
+	ListChunks lc;
+	const uint2 *slot_base;
 	uint32_t entry_cap;
 	uint64_t capV, capT;
 	uint64_t ghost_segs;  // row segments of the ghost slice (0 without ghost)
@@ -1160,8 +1258,14 @@ __global__ __launch_bounds__(256) void k_emit_slow(const EmitArgs a) {
 	if (!emit_prepare(a, c, ctr)) return;
 	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
 	const URef ids{&s_id[0][threadIdx.x], 256};
-	const uint32_t n = ctr.slow_cursor;
-	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) emit_cell(c, a.slow_list[t], v, w, ids);
+	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+	ChunkMap cm;
+	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);
+	const uint32_t n = cm.total;
+	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+		const uint32_t gq = cm.group_of(t);
+		emit_cell(c, a.slow_list[a.slot_base[(uint64_t)gq << a.lc.shift].x + (t - cm.pre[gq])], v, w, ids);
+	}
 }
 
 // ===================================================================================================
@@ -1221,6 +1325,8 @@ struct mc33hip_ctx {
 	EntryB *entries_b;
 	EntryB *d_fast_b;
 	uint32_t *entry_seg, *slow_list, *dirty_list;
+	uint32_t *list_cnt;       // [2][LIST_CHUNKS] cursors of the slow / dirty list parts (ListChunks)
+	ListChunks lc;            // ... for the range last counted
 	uint64_t entry_cap;
 	IsoLane lanes[MC33_LANES]; // what a sweep leaves behind, per isovalue (lane 0: the single-isovalue calls)
 	uint2 *slot_base;
@@ -1346,6 +1452,7 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 		CREATE_TRY(hipMemcpy(c->d_fast_b, fb, sizeof fb, hipMemcpyHostToDevice));
 	}
 	CREATE_TRY(hipMalloc(&c->d_ctr, sizeof(Counters)));
+	CREATE_TRY(hipMalloc(&c->list_cnt, 2 * LIST_CHUNKS * sizeof(uint32_t)));
 	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
 	for (int k = 0; k < 4; k++) CREATE_TRY(hipEventCreate(&c->ev[k]));
 	for (int k = 0; k < 2; k++) CREATE_TRY(hipEventCreate(&c->ev_many[k]));
@@ -1379,7 +1486,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->slot_base);
 	(void)hipFree(c->d_bounds);
 	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
-	(void)hipFree(c->d_ctr);
+	(void)hipFree(c->d_ctr); (void)hipFree(c->list_cnt);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	if (c->aux) (void)hipStreamSynchronize(c->aux);
 	if (c->aux2) (void)hipStreamSynchronize(c->aux2);
@@ -1795,6 +1902,10 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	L.boundary_done = true;  // (its slices are in the partial sums now: a repeated tail - more room for records - must not add them again)
 	CellsArgs ca;
 	ca.pack = sweep_packed(c) ? (uint32_t)SWEEP_PACK : 1u;
+	ca.dev = 0;
+#ifdef MC33_DEV
+	ca.dev = env_u32("MC33_HIP_CELLS_DEV", 0);
+#endif
 	ca.G.p = c->d_grid; ca.G.pitch = (uint32_t)c->pitch; ca.G.z0 = c->desc.plane0; ca.G.slice = c->slice;
 	ca.P = P; ca.fast = c->d_fast;
 	ca.ze = ze; ca.nYT = g.nYT; ca.nseg_pad = g.nseg;
@@ -1814,8 +1925,14 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 		ca.trace = c->trace_cells;
 	}
 	const uint64_t nchunks = (L.slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;
+	{  // groups of slots for the slow / dirty lists: at most LIST_CHUNKS, at least 64 slots each
+		uint32_t shift = 6;
+		while (((g.nslots + (1ull << shift) - 1) >> shift) > LIST_CHUNKS) shift++;
+		c->lc = ListChunks{c->list_cnt, c->list_cnt + LIST_CHUNKS, (uint32_t)((g.nslots + (1ull << shift) - 1) >> shift), shift};
+	}
+	ca.lc = c->lc;
 	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK)), dim3(256), 0, st, L.slice_hdr, lane_part(L, false), lane_part(L, true),
-	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr);
+	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr, c->lc);
 	hipLaunchKernelGGL(k_cells, dim3((uint32_t)g.cell_blocks), dim3(256), 0, st, ca);
 	SlowArgs sa;
 	sa.G = a.G; sa.P = P;
@@ -1823,6 +1940,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	sa.z_emit = c->range.z_begin;
 	sa.entries_a = c->entries_a; sa.entries_b = c->entries_b; sa.entry_seg = c->entry_seg; sa.slow_list = c->slow_list;
 	sa.seg_cnt = c->seg_cnt; sa.seg_dir = c->seg_dir; sa.dirty_list = c->dirty_list;
+	sa.lc = c->lc; sa.slot_base = c->slot_base;
 	sa.entry_cap = (uint32_t)c->entry_cap; sa.ctr = c->d_ctr;
 	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);  // (blocks beyond the list end at once)
 	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks), dim3(256), 0, st, sa);
@@ -1943,6 +2061,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.c.z_emit = c->range.z_begin; a.c.v_skip = a.c.t_skip = a.c.id_delta = 0;
 	a.ctr = c->d_ctr;
 	a.slow_list = c->slow_list;
+	a.lc = c->lc; a.slot_base = c->slot_base;
 	a.entry_cap = (uint32_t)c->entry_cap;
 	a.capV = capV; a.capT = capT;
 	a.ghost_segs = c->ghost_segs;

@@ -15,10 +15,14 @@ import torch  # noqa: E402
 from mc33_c_library_amd import api, fields  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-grid, r0, d = fields.cos_field_cube(n, torch.device("cuda:0"))
+iso = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+if len(sys.argv) > 3 and sys.argv[3] == "u16":   # e.g. 1024 25268.0 u16: integer grid, integer isovalue (degenerate vertices)
+    grid, r0, d = fields.cos_field_u16(n, n, n, torch.device("cuda:0")), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+else:
+    grid, r0, d = fields.cos_field_cube(n, torch.device("cuda:0"))
 g = api.DeviceGrid(grid, r0=r0, d=d)
 for _ in range(3):
-    cnt = g.count(0.0)
+    cnt = g.count(iso)
 torch.cuda.synchronize()
 t = np.fromfile(out, dtype=np.uint64).reshape(-1, 4).astype(np.int64)
 print("slots", len(t), "waves that wrote records", (t[:, 3] > 0).sum())
