@@ -1016,15 +1016,33 @@ struct SlowArgs {
 	Counters *ctr;
 };
 
+// The look-up table, the id-source rules and their index (5 KB) copied into LDS: the generic per-cell path walks them
+// with dependent loads (pattern word after pattern word), each a trip to L2 when they stay in global memory.
+struct TablesLds {
+	uint16_t lut[2310];
+	uint32_t rule_words[81];
+	uint8_t rule_index[48];
+};
+__device__ __forceinline__ Tables tables_to_lds(TablesLds &L, const Tables &g) {  // all threads of the block; ends with a barrier
+	for (uint32_t q = threadIdx.x; q < 2310u; q += 256u) L.lut[q] = g.lut[q];
+	if (threadIdx.x < 81u) L.rule_words[threadIdx.x] = g.rule_words[threadIdx.x];
+	if (threadIdx.x < 48u) L.rule_index[threadIdx.x] = g.rule_index[threadIdx.x];
+	__syncthreads();
+	return Tables{L.lut, L.rule_words, L.rule_index};
+}
+
 __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 	__shared__ real_t s_v[8][256];
 	__shared__ real_t s_w[8][256];
 	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+	__shared__ TablesLds s_tab;
 	ChunkMap cm;
 	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);  // (first: its loads and the one of the cursor below go out together)
 	if (a.ctr->entry_cursor > a.entry_cap) return;  // the sweep will be repeated with more room
 	const uint32_t n = cm.total;
 	if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->slow_cursor = n;  // (for the host's report)
+	if (blockIdx.x * 256u >= n) return;             // (nothing for this block: most blocks of most calls)
+	const Tables tab = tables_to_lds(s_tab, a.tab);
 	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
 	const Params &P = a.P;
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
@@ -1036,10 +1054,10 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 		const uint32_t y = sc.y, z = sc.z, x = sc.xbase + xl;
 		const uint32_t i = load_cell(a.G, P.iso, x, y, z, v);
 		CellPlan pl;
-		plan_cell(pl, a.tab, P, a.G, x, y, z, i, v);
+		plan_cell(pl, tab, P, a.G, x, y, z, i, v);
 		// Ghost cells only lend vertex ids to the slab above; their triangle count cancels out of every
 		// offset, so the identity test (which may read one more plane below) is skipped.
-		const uint32_t nt = z < a.z_emit ? pl.ntri : count_triangles(pl, a.tab, P, a.G, x, y, z, w);
+		const uint32_t nt = z < a.z_emit ? pl.ntri : count_triangles(pl, tab, P, a.G, x, y, z, w);
 		const Entry en = make_entry(xl, i, pl, nt, 0, 0, true);
 		a.entries_a[ei] = entry_a(en);
 		a.entries_b[ei] = entry_b(en);
@@ -1259,9 +1277,12 @@ __global__ __launch_bounds__(256) void k_emit_slow(const EmitArgs a) {
 	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
 	const URef ids{&s_id[0][threadIdx.x], 256};
 	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+	__shared__ TablesLds s_tab;
 	ChunkMap cm;
 	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);
 	const uint32_t n = cm.total;
+	if (blockIdx.x * 256u >= n) return;
+	c.tab = tables_to_lds(s_tab, a.c.tab);
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
 		const uint32_t gq = cm.group_of(t);
 		emit_cell(c, a.slow_list[a.slot_base[(uint64_t)gq << a.lc.shift].x + (t - cm.pre[gq])], v, w, ids);
