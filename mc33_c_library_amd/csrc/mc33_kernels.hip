@@ -633,12 +633,12 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 // Lists of the slow cells and of the row segments they make "dirty".  k_cells appends to them; ONE cursor for the whole
 // grid meant one atomic address that every wave with a slow cell queues at (an integer grid with an integer isovalue
 // has such cells all along the surface: the atomics alone made k_cells 1.0 ms instead of 0.2).  So the slice slots are
-// cut into at most LIST_CHUNKS groups of 2^shift consecutive slots; group g appends - with its own cursor - into the part
+// cut into at most LIST_CHUNKS (1024) groups of 2^shift consecutive slots; group g appends - with its own cursor - into the part
 // of the list that starts at the index of the group's first work record: a group cannot hold more slow cells (or dirty
 // rows) than records, so the parts cannot collide, and nothing has to be sized.  The consumers (k_slow_plan, k_seg_fix,
 // k_emit_slow) turn a flat index into (group, position) with a prefix sum of the group counts, rebuilt by every block
 // in LDS.
-constexpr uint32_t LIST_CHUNKS = 4096;
+constexpr uint32_t LIST_CHUNKS = 1024;  // (measured at 1024^3 with 240 000 slow cells: 256 groups still queue, 1024 and 4096 do not)
 struct ListChunks {
 	uint32_t *slow_cnt, *dirty_cnt;  // [n]
 	uint32_t n, shift;               // groups, log2 of slots per group
@@ -647,14 +647,12 @@ struct ListChunks {
 struct ChunkMap {  // per block, in LDS: exclusive prefix sums of the group counts
 	uint32_t *pre;   // [LIST_CHUNKS + 1]
 	uint32_t n, total;
-	// all threads of the block; red: 256 words of scratch
+	// all threads of the block (256): thread t takes groups 4 t .. 4 t + 3 (one 16-byte load); red: 256 words of scratch
 	__device__ void build(uint32_t *lds, uint32_t *red, const uint32_t *cnt, uint32_t n_) {
 		pre = lds; n = n_;
-		constexpr uint32_t PER = LIST_CHUNKS / 256;
-		const uint32_t t = threadIdx.x, q0 = t * PER;
-		uint32_t v[PER], sum = 0;
-#pragma unroll
-		for (uint32_t k = 0; k < PER; k++) { v[k] = q0 + k < n ? cnt[q0 + k] : 0u; sum += v[k]; }
+		const uint32_t t = threadIdx.x;
+		uint4 v = 4u * t < n ? ((const uint4 *)cnt)[t] : uint4{0u, 0u, 0u, 0u};  // (the cursors beyond n are zero: k_slots clears them all)
+		const uint32_t sum = v.x + v.y + v.z + v.w;
 		red[t] = sum;
 		__syncthreads();
 		for (uint32_t d = 1; d < 256; d <<= 1) {
@@ -663,10 +661,9 @@ struct ChunkMap {  // per block, in LDS: exclusive prefix sums of the group coun
 			red[t] += x;
 			__syncthreads();
 		}
-		uint32_t run = red[t] - sum;
-#pragma unroll
-		for (uint32_t k = 0; k < PER; k++) { pre[q0 + k] = run; run += v[k]; }
-		if (t == 255) pre[LIST_CHUNKS] = run;
+		const uint32_t run = red[t] - sum;
+		pre[4u * t] = run; pre[4u * t + 1u] = run + v.x; pre[4u * t + 2u] = run + v.x + v.y; pre[4u * t + 3u] = run + v.x + v.y + v.z;
+		if (t == 255) pre[LIST_CHUNKS] = red[t];
 		__syncthreads();
 		total = pre[LIST_CHUNKS];
 	}
@@ -674,7 +671,7 @@ struct ChunkMap {  // per block, in LDS: exclusive prefix sums of the group coun
 	__device__ uint32_t group_of(uint32_t i) const {
 		uint32_t lo = 0, hi = LIST_CHUNKS;  // invariant: pre[lo] <= i < pre[hi]
 #pragma unroll
-		for (int s = 0; s < 12; s++) {
+		for (int s = 0; s < 10; s++) {
 			const uint32_t mid = (lo + hi) >> 1;
 			const bool right = pre[mid] <= i;
 			lo = right ? mid : lo;
@@ -696,7 +693,7 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 	const uint32_t c = blockIdx.x, t = threadIdx.x;
 	if (t == 0) part_next[c] = 0;  // the partial sums of the NEXT extraction live in the other half: cleared here
 	if (c == 0) for (uint32_t q = gridDim.x + t; q < part_cap; q += 256u) part_next[q] = 0;  // (a later range may be longer)
-	if (c == 0) for (uint32_t q = t; q < lc.n; q += 256u) { lc.slow_cnt[q] = 0; lc.dirty_cnt[q] = 0; }  // the list cursors of this extraction
+	if (c == 0) for (uint32_t q = t; q < LIST_CHUNKS; q += 256u) { lc.slow_cnt[q] = 0; lc.dirty_cnt[q] = 0; }  // the list cursors of this extraction
 	if (c == 0 && t == 0) {        // ... and so are the counters the later passes of this one add to
 		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0;
 		ctr->totV = ctr->totT = ctr->ghostV = ctr->ghostT = 0;
@@ -1016,33 +1013,17 @@ struct SlowArgs {
 	Counters *ctr;
 };
 
-// The look-up table, the id-source rules and their index (5 KB) copied into LDS: the generic per-cell path walks them
-// with dependent loads (pattern word after pattern word), each a trip to L2 when they stay in global memory.
-struct TablesLds {
-	uint16_t lut[2310];
-	uint32_t rule_words[81];
-	uint8_t rule_index[48];
-};
-__device__ __forceinline__ Tables tables_to_lds(TablesLds &L, const Tables &g) {  // all threads of the block; ends with a barrier
-	for (uint32_t q = threadIdx.x; q < 2310u; q += 256u) L.lut[q] = g.lut[q];
-	if (threadIdx.x < 81u) L.rule_words[threadIdx.x] = g.rule_words[threadIdx.x];
-	if (threadIdx.x < 48u) L.rule_index[threadIdx.x] = g.rule_index[threadIdx.x];
-	__syncthreads();
-	return Tables{L.lut, L.rule_words, L.rule_index};
-}
-
 __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 	__shared__ real_t s_v[8][256];
 	__shared__ real_t s_w[8][256];
 	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
-	__shared__ TablesLds s_tab;
 	ChunkMap cm;
 	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);  // (first: its loads and the one of the cursor below go out together)
 	if (a.ctr->entry_cursor > a.entry_cap) return;  // the sweep will be repeated with more room
 	const uint32_t n = cm.total;
 	if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->slow_cursor = n;  // (for the host's report)
 	if (blockIdx.x * 256u >= n) return;             // (nothing for this block: most blocks of most calls)
-	const Tables tab = tables_to_lds(s_tab, a.tab);
+	const Tables &tab = a.tab;  // (the tables in LDS instead: tried - flat loads tie the LDS and memory wait counters together; slower)
 	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
 	const Params &P = a.P;
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
@@ -1277,12 +1258,10 @@ __global__ __launch_bounds__(256) void k_emit_slow(const EmitArgs a) {
 	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
 	const URef ids{&s_id[0][threadIdx.x], 256};
 	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
-	__shared__ TablesLds s_tab;
 	ChunkMap cm;
 	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);
 	const uint32_t n = cm.total;
 	if (blockIdx.x * 256u >= n) return;
-	c.tab = tables_to_lds(s_tab, a.c.tab);
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
 		const uint32_t gq = cm.group_of(t);
 		emit_cell(c, a.slow_list[a.slot_base[(uint64_t)gq << a.lc.shift].x + (t - cm.pre[gq])], v, w, ids);
@@ -1946,7 +1925,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 		ca.trace = c->trace_cells;
 	}
 	const uint64_t nchunks = (L.slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;
-	{  // groups of slots for the slow / dirty lists: at most LIST_CHUNKS, at least 64 slots each
+	{  // groups of slots for the slow / dirty lists: at most LIST_CHUNKS
 		uint32_t shift = 6;
 		while (((g.nslots + (1ull << shift) - 1) >> shift) > LIST_CHUNKS) shift++;
 		c->lc = ListChunks{c->list_cnt, c->list_cnt + LIST_CHUNKS, (uint32_t)((g.nslots + (1ull << shift) - 1) >> shift), shift};

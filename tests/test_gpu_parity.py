@@ -117,6 +117,25 @@ def test_reference_example_grids(products, reflibs, name):
         assert got.nV > 5000
 
 
+@pytest.mark.parametrize("dtype", ["u16", "u8", "f32"])
+def test_smooth_integer_grid_with_integer_isovalue(products, reflibs, dtype):
+    """The CT / MRI case: a smooth field quantised to integers and an INTEGER isovalue - a thin sprinkling of samples equal
+    to the isovalue all along the surface (one in ~80 of the cut cells has such a corner).  Only those cells take the
+    generic path (the sweep hands on which sample rows and which of its lanes saw such a sample, k_cells looks at the 8
+    corners of the candidates); their neighbours stay on the fast path and look the degenerate owners up.  Wide rows (several
+    row segments), several y tiles and z tiles, ushort (2 samples per lane), uchar (4) and float (1)."""
+    if dtype == "u16":
+        data, isos = fx.cos_field_u16(600, 150, 70), (25268.0, 32768.0, 40000.0)
+    elif dtype == "u8":
+        data, isos = fx.cos_field_int(140, np.uint8, 40.0, 128.0), (128.0, 100.0)
+    else:
+        data, isos = np.rint(fx.cos_field(140)[0] * 50.0).astype(np.float32), (0.0, 25.0)
+    for iso in isos:
+        zeros = int((data == iso).sum())
+        got = check(products, reflibs, dtype, data, iso, label="%s smooth integer grid iso %g (%d samples equal)" % (dtype, iso, zeros))
+        assert zeros > 50 and got.nV > 20000
+
+
 def test_negative_zero_isovalue_is_deterministic(products, reflibs):
     """iso = -0.0 on a grid holding zeros: the reference's own result depends on what earlier slices and earlier calls
     left in its id caches, so only what IS a function of the input is pinned: the product returns one
