@@ -603,15 +603,17 @@ struct Entry {
 	uint32_t w0;  // x within the segment (8) | sign index (8) | pattern offset (12) | nnew (4)
 	uint32_t w1;  // vertex offset inside the row segment (16) | triangle offset (16)
 	uint32_t w2;  // ranks of edges 0..7  (nibbles, 0xF = the cell creates no vertex for that edge)
-	uint32_t w3;  // ranks of edges 8..11 (16) | triangles appended by the cell (4) << 16 | slow flag << 20
+	uint32_t w3;  // ranks of edges 8..11 (16) | triangles appended by the cell (4) << 16 | slow flag << 20 | tested flag << 21 |
+	              // rank of the cell-centre vertex (4) << 24
 };
-constexpr uint32_t ENTRY_SLOW = 1u << 20;
+constexpr uint32_t ENTRY_SLOW = 1u << 20;    // the generic per-cell code writes the cell (k_emit_slow)
+constexpr uint32_t ENTRY_TESTED = 1u << 21;  // planned by k_slow_plan, written by the fast emit passes (see cell_is_tested)
 MC33_HD Entry make_entry(uint32_t xl, uint32_t i, const CellPlan &p, uint32_t nt, uint32_t voff, uint32_t toff, bool slow) {
 	Entry e;
 	e.w0 = xl | i << 8 | (uint32_t)p.poff << 16 | (uint32_t)p.nnew << 28;
 	e.w1 = voff | toff << 16;
 	e.w2 = (uint32_t)p.rank;
-	e.w3 = ((uint32_t)(p.rank >> 32) & 0xFFFFu) | nt << 16 | (slow ? ENTRY_SLOW : 0u);
+	e.w3 = ((uint32_t)(p.rank >> 32) & 0xFFFFu) | nt << 16 | (slow ? ENTRY_SLOW : 0u) | plan_rank(p, 12) << 24;
 	return e;
 }
 MC33_HD uint32_t entry_rank(const Entry &e, uint32_t edge) {
@@ -619,6 +621,7 @@ MC33_HD uint32_t entry_rank(const Entry &e, uint32_t edge) {
 }
 MC33_HD uint32_t entry_nnew(const Entry &e) { return e.w0 >> 28; }
 MC33_HD uint32_t entry_ntri(const Entry &e) { return (e.w3 >> 16) & 15u; }
+MC33_HD uint32_t entry_rank_centre(const Entry &e) { return (e.w3 >> 24) & 15u; }
 
 // Fast path.  A cell is FAST when it owns exactly the three edges meeting at its far corner (x,y,z >= 1),
 // its sign index selects a pattern without tests (table word group 0: MC33 cases 1,2,5,8,9,11,14,
@@ -632,7 +635,7 @@ MC33_HD Entry make_fast_entry(uint32_t xl, uint32_t i, uint32_t f, uint32_t voff
 	e.w0 = xl | i << 8 | (f & 0xFFFu) << 16 | ((f >> 16) & 15u) << 28;
 	e.w1 = voff | toff << 16;
 	e.w2 = 0xF00FFFFFu | ((f >> 20) & 15u) << 20 | ((f >> 24) & 15u) << 24;
-	e.w3 = 0xF0FFu | ((f >> 28) & 15u) << 8 | ((f >> 12) & 15u) << 16;
+	e.w3 = 0xF0FFu | ((f >> 28) & 15u) << 8 | ((f >> 12) & 15u) << 16 | 15u << 24;  // (no pattern without tests has a centre vertex)
 	return e;
 }
 // placeholder written by the sweep for a cell the slow kernel will plan
@@ -641,29 +644,29 @@ MC33_HD Entry make_pending_entry(uint32_t xl, uint32_t i) {
 	e.w0 = xl | i << 8;
 	e.w1 = 0;
 	e.w2 = 0xFFFFFFFFu;
-	e.w3 = 0xFFFFu | ENTRY_SLOW;
+	e.w3 = 0xFFFFu | ENTRY_SLOW | 15u << 24;
 	return e;
 }
 
 // Storage of the work records.  In registers a record is an Entry; in HBM it is split in two 8-byte halves kept in two
 // arrays with the same index:
-//   A: x in the segment (8) | sign index (8) | nnew (4) | triangles (4) | slow flag (1 << 24)   ;   vertex offset (16) | triangle offset (16)
-//   B: ranks of edges 0..7   ;   ranks of edges 8..11 (16) | pattern offset (12) << 16
+//   A: x in the segment (8) | sign index (8) | nnew (4) | triangles (4) | slow flag (1 << 24) | tested flag (1 << 25)   ;   vertex offset (16) | triangle offset (16)
+//   B: ranks of edges 0..7   ;   ranks of edges 8..11 (16) | pattern offset (12) << 16 | rank of the centre vertex (4) << 28
 // Half B of a FAST record is a function of its sign index (fast_b_table): it is never written or read - a fast
 // record costs 8 bytes of HBM traffic per pass instead of 16 (writes are what the passes after the sweep pay for most).
 struct EntryA { uint32_t a0, a1; };
 struct EntryB { uint32_t b0, b1; };
-constexpr uint32_t ENTRYA_SLOW = 1u << 24;
+constexpr uint32_t ENTRYA_SLOW = 1u << 24, ENTRYA_TESTED = 1u << 25;
 MC33_HD EntryA entry_a(const Entry &e) {
-	return EntryA{(e.w0 & 0xFFFFu) | (e.w0 >> 28) << 16 | ((e.w3 >> 16) & 15u) << 20 | ((e.w3 & ENTRY_SLOW) ? ENTRYA_SLOW : 0u), e.w1};
+	return EntryA{(e.w0 & 0xFFFFu) | (e.w0 >> 28) << 16 | ((e.w3 >> 16) & 15u) << 20 | ((e.w3 >> 20) & 3u) << 24, e.w1};
 }
-MC33_HD EntryB entry_b(const Entry &e) { return EntryB{e.w2, (e.w3 & 0xFFFFu) | ((e.w0 >> 16) & 0xFFFu) << 16}; }
+MC33_HD EntryB entry_b(const Entry &e) { return EntryB{e.w2, (e.w3 & 0xFFFFu) | ((e.w0 >> 16) & 0xFFFu) << 16 | (e.w3 >> 24) << 28}; }
 MC33_HD Entry entry_join(const EntryA &a, const EntryB &b) {
 	Entry e;
-	e.w0 = (a.a0 & 0xFFFFu) | (b.b1 >> 16) << 16 | ((a.a0 >> 16) & 15u) << 28;
+	e.w0 = (a.a0 & 0xFFFFu) | ((b.b1 >> 16) & 0xFFFu) << 16 | ((a.a0 >> 16) & 15u) << 28;
 	e.w1 = a.a1;
 	e.w2 = b.b0;
-	e.w3 = (b.b1 & 0xFFFFu) | ((a.a0 >> 20) & 15u) << 16 | ((a.a0 & ENTRYA_SLOW) ? ENTRY_SLOW : 0u);
+	e.w3 = (b.b1 & 0xFFFFu) | ((a.a0 >> 20) & 15u) << 16 | ((a.a0 >> 24) & 3u) << 20 | (b.b1 >> 28) << 24;
 	return e;
 }
 MC33_HD uint32_t entrya_nnew(const EntryA &a) { return (a.a0 >> 16) & 15u; }
@@ -675,10 +678,10 @@ inline void fast_b_table(const uint32_t *fast /*[256]*/, EntryB *out /*[256]*/) 
 		if (fast[i] != FAST_NONE) out[i] = entry_b(make_fast_entry(0, i, fast[i], 0, 0));
 	}
 }
-// a record from its halves: half B from the table unless the record is slow
+// a record from its halves: half B from the table unless k_slow_plan made it
 MC33_HD Entry load_entry(const EntryA *ea, const EntryB *eb, const EntryB *fast_b, uint32_t ri) {
 	const EntryA a = ea[ri];
-	const EntryB b = (a.a0 & ENTRYA_SLOW) ? eb[ri] : fast_b[(a.a0 >> 8) & 0xFFu];
+	const EntryB b = (a.a0 & (ENTRYA_SLOW | ENTRYA_TESTED)) ? eb[ri] : fast_b[(a.a0 >> 8) & 0xFFu];
 	return entry_join(a, b);
 }
 
@@ -700,6 +703,12 @@ inline void build_fast_table(const uint16_t *lut, uint32_t *fast /*[256]*/) {
 		          plan_rank(p, 6) << 24 | plan_rank(p, 10) << 28;
 	}
 }
+
+// A TESTED cell: its sign index needs the face / interior tests (so the sweep could not finish it), but it is an interior
+// cell (it owns exactly edges 5, 6, 10 and, in some patterns, the centre vertex) and none of its corners equals the
+// isovalue - no alias, every other edge's vertex is a regular vertex of the edge's owner.  Once k_slow_plan has chosen
+// its pattern, the fast emit passes write it like a fast cell: pattern offset and ranks come from half B of the record.
+MC33_HD bool cell_is_tested(const CellPlan &p, uint32_t x, uint32_t y, uint32_t z) { return x && y && z && !p.zmask; }
 
 // Directory of the row segments.  A row segment = the cells (x in [256 s, 256 s + 256), y, z).  Records
 // are STORED in the order [z][s][y] (the 63 rows a wave handles are contiguous: coalesced writes), while
@@ -835,6 +844,7 @@ MC33_HD uint32_t edge_vertex_id(const EmitCtx<T> &c, GridEdge g, const VRef &w) 
 template <typename T>
 MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v, const VRef &w, const URef &ids) {
 	const Entry en = ctx_entry(c, entry_index);
+	if (en.w3 & ENTRY_TESTED) return;  // (on the slow list, but the fast emit passes write it)
 	const uint32_t s = c.entry_seg[entry_index];
 	const SegCoord sc = segment_coord(c.P, s);
 	const uint32_t y = sc.y, z = sc.z;
@@ -937,8 +947,8 @@ MC33_HD void fast_owned_vertex(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint
 // its order are those of vertex_on_edge (MC:990-1000, 1029-1039, 1175-1185).
 template <typename T>
 MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s) {
-	const uint32_t r5 = (en.w2 >> 20) & 15u, r6 = (en.w2 >> 24) & 15u, r10 = (en.w3 >> 8) & 15u;
-	if ((r5 & r6 & r10) == 15u) return;  // the cell creates no vertex
+	const uint32_t r5 = (en.w2 >> 20) & 15u, r6 = (en.w2 >> 24) & 15u, r10 = (en.w3 >> 8) & 15u, r12 = entry_rank_centre(en);
+	if ((r5 & r6 & r10 & r12) == 15u) return;  // the cell creates no vertex
 	const SegCoord sc = segment_coord(c.P, s);
 	const uint32_t y = sc.y, z = sc.z;
 	if (z < c.z_emit) return;
@@ -997,9 +1007,15 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 		           : (v2 - v1) * (1 - t) + (v6 - v5) * t;
 		store_vertex(P, r, c.V, c.N, vbase + r10 - c.v_skip);
 	}
+	if (r12 != 15u) {  // centre vertex of a tested cell (MC:1225-1230)
+		real_t vv[8] = {iso_diff(iso, (real_t)F[0][0]), iso_diff(iso, (real_t)F[1][0]), iso_diff(iso, (real_t)F[3][0]), iso_diff(iso, (real_t)F[2][0]),
+		                iso_diff(iso, (real_t)F[0][1]), iso_diff(iso, (real_t)F[1][1]), iso_diff(iso, (real_t)F[3][1]), iso_diff(iso, (real_t)F[2][1])};
+		vertex_centre(x, y, z, VRef{vv, 1}, r);
+		store_vertex(P, r, c.V, c.N, vbase + r12 - c.v_skip);
+	}
 }
 
-// Triangles of one FAST record.  ids: 12-slot scratch.
+// Triangles of one FAST (or TESTED) record.  ids: 13-slot scratch.
 // The other nine edges belong to six neighbours; edge k of this cell is edge k' of
 // its owner:  o0 (x-1,y,z-1): 0->6 | o1 (x-1,y,z): 1->5, 2->6 | o2 (x-1,y-1,z): 3->5 |
 //             o3 (x,y,z-1): 4->6, 9->10 | o4 (x,y-1,z): 7->5, 11->10 | o5 (x,y-1,z-1): 8->10
@@ -1070,6 +1086,7 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 	const uint32_t vbase = sb.vbase + (en.w1 & 0xFFFFu);
 	uint32_t tpos = sb.tbase + (en.w1 >> 16) - c.t_skip;
 	ids[5] = vbase + ((en.w2 >> 20) & 15u); ids[6] = vbase + ((en.w2 >> 24) & 15u); ids[10] = vbase + ((en.w3 >> 8) & 15u);
+	ids[12] = vbase + entry_rank_centre(en);
 	// winding (MC:683-691): n = 1 swaps the first two indices
 	const uint32_t n = ((c.tab.lut[(i & 0x80) ? (i ^ 0xFF) : i] >> 11) ^ (i >> 7) ^ 1u ^ (uint32_t)c.P.normal_neg) & 1u;
 	uint32_t pos = (en.w0 >> 16) & 0xFFFu, word;

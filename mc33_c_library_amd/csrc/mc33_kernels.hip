@@ -1039,7 +1039,8 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 		// Ghost cells only lend vertex ids to the slab above; their triangle count cancels out of every
 		// offset, so the identity test (which may read one more plane below) is skipped.
 		const uint32_t nt = z < a.z_emit ? pl.ntri : count_triangles(pl, tab, P, a.G, x, y, z, w);
-		const Entry en = make_entry(xl, i, pl, nt, 0, 0, true);
+		Entry en = make_entry(xl, i, pl, nt, 0, 0, true);
+		if (cell_is_tested(pl, x, y, z)) en.w3 ^= ENTRY_SLOW | ENTRY_TESTED;  // the fast emit passes can write it
 		a.entries_a[ei] = entry_a(en);
 		a.entries_b[ei] = entry_b(en);
 	}
@@ -1232,7 +1233,7 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 
 // triangles of the fast records (ids of shared edges through the owners' records)
 __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
-	__shared__ uint32_t s_id[12][256];
+	__shared__ uint32_t s_id[13][256];
 	__shared__ EntryB s_fast_b[256];
 	s_fast_b[threadIdx.x] = a.c.fast_b[threadIdx.x];
 	__syncthreads();

@@ -89,7 +89,9 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 					CellPlan p;
 					plan_cell(p, tab, P, G, x, y, z, i, v);
 					const uint32_t nt = z < z_emit ? p.ntri : count_triangles(p, tab, P, G, x, y, z, w);
-					entries.push_back(make_entry(x % SEG_CELLS, i, p, nt, voff, toff, true));
+					Entry en = make_entry(x % SEG_CELLS, i, p, nt, voff, toff, true);
+					if (force_mode != 1 && cell_is_tested(p, x, y, z)) en.w3 ^= ENTRY_SLOW | ENTRY_TESTED;  // as k_slow_plan: the fast emit writes it
+					entries.push_back(en);
 					seg_cnt[s] = seg_pack(voff + p.nnew, toff + nt);
 				}
 				entry_seg.push_back((uint32_t)s);
@@ -113,14 +115,14 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	EmitCtx<T> c;
 	c.tab = tab; c.P = P; c.G = G;
 	c.seg_base = seg_base.data(); c.seg_dir = seg_dir.data();
-	// the records as the kernels store them: half A for all, half B only for slow records (fast ones: from the table)
+	// the records as the kernels store them: half A for all, half B only for slow and tested records (fast ones: from the table)
 	std::vector<EntryA> ea(entries.size());
 	std::vector<EntryB> eb(entries.size(), EntryB{0xDEADBEEFu, 0xDEADBEEFu});
 	EntryB fast_b[256];
 	fast_b_table(fast, fast_b);
 	for (size_t k = 0; k < entries.size(); k++) {
 		ea[k] = entry_a(entries[k]);
-		if (entries[k].w3 & ENTRY_SLOW) eb[k] = entry_b(entries[k]);
+		if (entries[k].w3 & (ENTRY_SLOW | ENTRY_TESTED)) eb[k] = entry_b(entries[k]);
 		const Entry back = load_entry(ea.data(), eb.data(), fast_b, (uint32_t)k);
 		if (back.w0 != entries[k].w0 || back.w1 != entries[k].w1 || back.w2 != entries[k].w2 || back.w3 != entries[k].w3) return -7;  // split / join must be lossless
 	}
