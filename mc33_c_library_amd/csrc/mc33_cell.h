@@ -173,7 +173,21 @@ MC33_HD uint32_t load_cell(const GridView<T> &G, real_t iso, uint32_t x, uint32_
 // ---------------------------------------------------------------------------------------------------
 // Ambiguity tests (MC:347-386 face tests, MC:431-462 interior test) and case selection (MC:683-779)
 // ---------------------------------------------------------------------------------------------------
-MC33_HD bool face_less(int f, const VRef &v) {
+// The corner values come either through a VRef (any memory) or as a Corner8 (registers: every index below is static
+// except the one of corner_value, which is a chain of selects there).
+struct Corner8 {
+	real_t a[8];
+	MC33_HD real_t operator[](int k) const { return a[k]; }
+};
+MC33_HD real_t corner_value(const VRef &v, int s) { return v[s]; }
+MC33_HD real_t corner_value(const Corner8 &v, int s) {
+	real_t r = v.a[0];
+	for (int k = 1; k < 8; k++) r = s == k ? v.a[k] : r;
+	return r;
+}
+
+template <typename V>
+MC33_HD bool face_less(int f, const V &v) {
 	switch (f) {
 	case 0: return v[0] * v[5] < v[1] * v[4];
 	case 1: return v[1] * v[6] < v[2] * v[5];
@@ -188,10 +202,18 @@ MC33_HD uint32_t face_mask(int f) { return (uint32_t)(0x0FF0993366CCull >> (8 * 
 MC33_HD uint32_t face_diag_hi(int f) { return (uint32_t)(0x0AA081124284ull >> (8 * f)) & 0xFFu; }
 MC33_HD uint32_t face_diag_lo(int f) { return (uint32_t)(0x055018212448ull >> (8 * f)) & 0xFFu; }
 
-MC33_HD uint32_t face_test_one(int f, const VRef &v) { return face_less(f, v) ? face_diag_lo(f) : face_diag_hi(f); }  // MC:371-386
+template <typename V>
+MC33_HD uint32_t face_test_one(int f, const V &v) { return face_less(f, v) ? face_diag_lo(f) : face_diag_hi(f); }  // MC:371-386
 
-MC33_HD int face_tests(int *face, uint32_t ind, const VRef &v) {  // MC:347-367
-	int sum = 0;
+// results of the six face tests (-1, 0, 1 each), two bits per face so that picking one by a run-time number is a shift
+struct FaceSigns {
+	uint32_t bits;  // (r + 1) << 2 f
+	int sum;
+	MC33_HD int operator[](int f) const { return (int)((bits >> (2 * f)) & 3u) - 1; }
+};
+template <typename V>
+MC33_HD FaceSigns face_tests(uint32_t ind, const V &v) {  // MC:347-367
+	FaceSigns fs{0u, 0};
 	for (int f = 0; f < 6; f++) {
 		const uint32_t key = (f == 0 || f == 3 || f == 4) ? 0x80u : 0x02u;
 		int r = 0;
@@ -200,13 +222,14 @@ MC33_HD int face_tests(int *face, uint32_t ind, const VRef &v) {  // MC:347-367
 		} else {
 			if ((ind & face_mask(f)) == face_diag_lo(f)) r = face_less(f, v) ? 1 : -1;
 		}
-		face[f] = r;
-		sum += r;
+		fs.bits |= (uint32_t)(r + 1) << (2 * f);
+		fs.sum += r;
 	}
-	return sum;
+	return fs;
 }
 
-MC33_HD int interior_test(int s, int flag13, const VRef &v) {  // MC:431-462
+template <typename V>
+MC33_HD int interior_test(int s, int flag13, const V &v) {  // MC:431-462
 	real_t a = v[4] - v[0], b = v[5] - v[1], c = v[6] - v[2], d = v[7] - v[3];
 	real_t t = a * c - b * d;
 	if (sign_of(t)) {
@@ -218,9 +241,9 @@ MC33_HD int interior_test(int s, int flag13, const VRef &v) {  // MC:431-462
 		a = v[0] + a * t; b = v[1] + b * t; c = v[2] + c * t; d = v[3] + d * t;
 		c *= a; d *= b;
 		if (s & 1) {
-			if (c < d && !sign_of(d)) return (int)(sign_of(b) == sign_of(v[s])) + flag13;
+			if (c < d && !sign_of(d)) return (int)(sign_of(b) == sign_of(corner_value(v, s))) + flag13;
 		} else {
-			if (c > d && !sign_of(c)) return (int)(sign_of(a) == sign_of(v[s])) + flag13;
+			if (c > d && !sign_of(c)) return (int)(sign_of(a) == sign_of(corner_value(v, s))) + flag13;
 		}
 	}
 	return 0;
@@ -228,12 +251,12 @@ MC33_HD int interior_test(int s, int flag13, const VRef &v) {  // MC:431-462
 
 // table word -> offset of the triangle pattern; the walk starts at offset+1 (MC:781).
 // m,n: which of the first two triangle slots is written first (winding, MC:683-691, 1249)
-MC33_HD uint32_t pattern_offset(const uint16_t *lut, uint32_t i, const VRef &v, uint32_t &m, uint32_t &n) {
+template <typename V>
+MC33_HD uint32_t pattern_offset(const uint16_t *lut, uint32_t i, const V &v, uint32_t &m, uint32_t &n) {
 	uint32_t c;
 	if (i & 0x80) { c = lut[i ^ 0xFF]; m = (c & 0x800) == 0; n = !m; }
 	else { c = lut[i]; n = (c & 0x800) == 0; m = !n; }
 	const uint32_t k = c & 0x7FF, ci = m ? i : i ^ 0xFF;
-	int f[6];
 	switch (c >> 12) {
 	case 0: return k;                                                                    // cases 1,2,5,8,9,11,14
 	case 1: return (ci & face_test_one((int)(k >> 2), v)) ? 183 + 2 * k : 159 + k;       // case 3
@@ -241,34 +264,40 @@ MC33_HD uint32_t pattern_offset(const uint16_t *lut, uint32_t i, const VRef &v, 
 	case 3:                                                                              // case 6
 		if (ci & face_test_one((int)(k % 6), v)) return 575 + 5 * k;
 		return interior_test((int)(k / 6), 0, v) ? 407 + 7 * k : 335 + 3 * k;
-	case 4:                                                                              // case 7
-		switch (face_tests(f, ci, v)) {
+	case 4: {                                                                            // case 7
+		const FaceSigns f = face_tests(ci, v);
+		switch (f.sum) {
 		case -3: return 695 + 3 * k;
 		case -1: return (f[4] + f[5] < 0 ? (f[0] + f[2] < 0 ? 759u : 799u) : 719u) + 5 * k;
 		case 1: return (f[4] + f[5] < 0 ? 983u : (f[0] + f[2] < 0 ? 839u : 911u)) + 9 * k;
 		default: return interior_test((int)(k >> 1), 0, v) ? 1095 + 9 * k : 1055 + 5 * k;
 		}
-	case 5:                                                                              // case 10
-		switch (face_tests(f, ci, v)) {
+	}
+	case 5: {                                                                            // case 10
+		const FaceSigns f = face_tests(ci, v);
+		switch (f.sum) {
 		case -2:
 			if (k == 2 ? interior_test(0, 0, v) : (interior_test(0, 0, v) || interior_test(k ? 1 : 3, 0, v)))
 				return 1213 + 8 * k;
 			return 1189 + 4 * k;
-		case 0: return (f[2 + k] < 0 ? 1261u : 1285u) + 8 * k;
+		case 0: return (f[2 + (int)k] < 0 ? 1261u : 1285u) + 8 * k;
 		default:
 			if (k == 2 ? interior_test(1, 0, v) : (interior_test(2, 0, v) || interior_test(k ? 3 : 1, 0, v)))
 				return 1237 + 8 * k;
 			return 1201 + 4 * k;
 		}
-	case 6:                                                                              // case 12
-		switch (face_tests(f, ci, v)) {
+	}
+	case 6: {                                                                            // case 12
+		const FaceSigns f = face_tests(ci, v);
+		switch (f.sum) {
 		case -2: return interior_test((int)((0xDA010Cu >> (2 * k)) & 3), 0, v) ? 1453 + 8 * k : 1357 + 4 * k;
-		case 0: return (f[k >> 1] < 0 ? 1645u : 1741u) + 8 * k;
+		case 0: return (f[(int)(k >> 1)] < 0 ? 1645u : 1741u) + 8 * k;
 		default: return interior_test((int)((0xA7B7E5u >> (2 * k)) & 3), 0, v) ? 1549 + 8 * k : 1405 + 4 * k;
 		}
+	}
 	default: {                                                                           // case 13
-		int s = face_tests(f, 165, v);
-		if (s < 0) s = -s;
+		const FaceSigns f = face_tests(165, v);
+		const int s = f.sum < 0 ? -f.sum : f.sum;
 		if (s == 0) {
 			const int kk = ((f[1] < 0) << 1) | (f[5] < 0);
 			if (f[0] * f[1] == f[5]) return (uint32_t)(2157 + 12 * kk);
@@ -702,6 +731,39 @@ inline void build_fast_table(const uint16_t *lut, uint32_t *fast /*[256]*/) {
 		fast[i] = (uint32_t)p.poff | (uint32_t)p.ntri << 12 | (uint32_t)p.nnew << 16 | plan_rank(p, 5) << 20 |
 		          plan_rank(p, 6) << 24 | plan_rank(p, 10) << 28;
 	}
+}
+
+// What an interior cell without a corner equal to the isovalue makes of the pattern that starts at table offset p: it
+// creates the vertices of its edges 5, 6, 10 and of its centre (slot 12) in the order the pattern names them (MC:780-784)
+//   info[p] = rank of edge 5 | edge 6 << 4 | edge 10 << 8 | centre << 12 (15: not in the pattern) | triangles << 16 | new vertices << 20
+// (filled for every offset; only pattern starts are ever looked up)
+inline void build_pattern_info(const uint16_t *lut, uint32_t n, uint32_t *info) {
+	for (uint32_t p = 0; p < n; p++) {
+		uint32_t visited = 0, nnew = 0, ntri = 0, rank[13], pos = p, word = 0;
+		for (int e = 0; e < 13; e++) rank[e] = 15u;
+		do {
+			if (++pos >= n) break;
+			word = lut[pos];
+			ntri++;
+			uint32_t w = word;
+			for (int k = 0; k < 3; k++, w >>= 4) {
+				const uint32_t e = w & 15u;
+				if (e > 12u || (visited & (1u << e))) continue;
+				visited |= 1u << e;
+				if (e == 5u || e == 6u || e == 10u || e == 12u) rank[e] = nnew++;
+			}
+		} while ((word >> 12) && ntri < 15u);
+		info[p] = rank[5] | rank[6] << 4 | rank[10] << 8 | rank[12] << 12 | ntri << 16 | nnew << 20;
+	}
+}
+// record of a TESTED cell from its pattern offset and info word (same fields as make_entry fills from a CellPlan)
+MC33_HD Entry make_tested_entry(uint32_t xl, uint32_t i, uint32_t poff, uint32_t info, uint32_t voff, uint32_t toff) {
+	Entry e;
+	e.w0 = xl | i << 8 | poff << 16 | ((info >> 20) & 15u) << 28;
+	e.w1 = voff | toff << 16;
+	e.w2 = 0xF00FFFFFu | (info & 15u) << 20 | ((info >> 4) & 15u) << 24;
+	e.w3 = 0xF0FFu | ((info >> 8) & 15u) << 8 | ((info >> 16) & 15u) << 16 | ENTRY_TESTED | ((info >> 12) & 15u) << 24;
+	return e;
 }
 
 // A TESTED cell: its sign index needs the face / interior tests (so the sweep could not finish it), but it is an interior

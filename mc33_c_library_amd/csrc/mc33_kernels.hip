@@ -763,7 +763,10 @@ struct CellsArgs {
 	const uint2 *slot_base;  // [slice_slot]: {first work record, first mask record} (k_slots)
 	uint32_t *seg_cnt;
 	SegDir *seg_dir;
-	EntryA *entries_a;       // work records, half A (half B only exists for slow records: k_slow_plan)
+	EntryA *entries_a;       // work records, half A
+	EntryB *entries_b;       // ... half B: written here for TESTED cells, by k_slow_plan for slow ones, never for fast ones
+	const uint16_t *lut;     // the reference's table and what an interior cell makes of each pattern (build_pattern_info):
+	const uint32_t *pat;     // for the cells whose sign index needs the face / interior tests
 	uint32_t *entry_seg;
 	uint32_t *slow_list, *dirty_list;
 	ListChunks lc;
@@ -792,7 +795,26 @@ struct CellsLds {            // per wave
 	uint32_t incl[64], run[64], slowrow[64];
 };
 
-__global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
+// The 8 samples of one cell: {0xFFFFFFFF, 0} if one of them equals the isovalue; else, for a sign index i that needs the
+// face / interior tests (i = 0: none wanted), {offset of the pattern the tests choose, its pattern-info word}.
+__device__ __forceinline__ uint2 corner_look(const GridView<sample_t> &G, real_t iso, const uint16_t *lut, const uint32_t *pat,
+                                                        uint32_t x, uint32_t y, uint32_t z, uint32_t i) {
+	Corner8 v;
+	bool zero = false;
+#pragma unroll
+	for (uint32_t k = 0; k < 8; k++) {
+		const uint32_t cc = corner_code(k);
+		v.a[k] = iso_diff(iso, (real_t)G.at(x + (cc & 1u), y + ((cc >> 1) & 1u), z + (cc >> 2)));
+		zero |= v.a[k] == 0;
+	}
+	if (zero) return uint2{0xFFFFFFFFu, 0u};
+	if (!i) return uint2{0u, 0u};
+	uint32_t wm, wn;
+	const uint32_t poff = pattern_offset(lut, i, v, wm, wn);
+	return uint2{poff, pat[poff]};
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_cells(const CellsArgs a) {  // (4 waves per SIMD is what its LDS allows: keep the registers of the rare test code from costing one)
 	const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	__shared__ uint4 s_fast[256];
 	__shared__ CellsLds s_w[4];
@@ -907,21 +929,26 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		// (its row may hold such a sample, and so may one of its two columns: then the cell's own 8 samples decide)
 		const bool look = on && (rowflag & 5u) == 4u && f.x != FAST_NONE &&
 		                  (xl == 255u || ((zc >> lane_of_column(xl, a.pack)) | (zc >> lane_of_column(min(xl + 1u, 255u), a.pack))) & 1ull);
+		// an interior cell whose sign index needs the face / interior tests: the tests are made here on its 8 samples, and
+		// unless one of them equals the isovalue the cell is finished like a fast one (TESTED record, mc33_cell.h)
+		const bool amb = on && !(rowflag & 1u) && f.x == FAST_NONE && (xbase + xl) != 0;
+		uint32_t tpoff = 0, tinfo = 0;
 #ifdef MC33_DEV
 		if (a.dev & 1u) zero_corner = look;  // experiment: no look at the samples (every candidate goes the slow way)
-		if (__ballot(look) && !(a.dev & 1u)) {
+		if (__ballot(look || amb) && !(a.dev & 1u)) {
 #else
-		if (__ballot(look)) {  // wave-uniform
+		if (__ballot(look || amb)) {  // wave-uniform
 #endif
-			if (look) {
-				const uint32_t cx = xbase + xl, cy = y0 + r;
-#pragma unroll
-				for (uint32_t k = 0; k < 8; k++)
-					zero_corner |= iso_diff(P.iso, (real_t)a.G.at(cx + (k & 1u), cy + ((k >> 1) & 1u), z + (k >> 2))) == 0;
+			if (look || amb) {
+				const uint2 t = corner_look(a.G, P.iso, a.lut, a.pat, xbase + xl, y0 + r, z, amb ? i : 0u);
+				zero_corner = t.x == 0xFFFFFFFFu;
+				if (!zero_corner) { tpoff = t.x; tinfo = t.y; }
 			}
 		}
+		const bool tested = tinfo != 0;  // (a pattern has at least one triangle)
 		const bool fastcell = on && !(rowflag & 1u) && !zero_corner && f.x != FAST_NONE && (xbase + xl) != 0;
-		const uint32_t val = fastcell ? ((f.w & 0xFFu) | (f.w >> 8) << 16) : 0u;  // new vertices | triangles << 16
+		// new vertices | triangles << 16
+		const uint32_t val = fastcell ? ((f.w & 0xFFu) | (f.w >> 8) << 16) : tested ? (((tinfo >> 20) & 15u) | ((tinfo >> 16) & 15u) << 16) : 0u;
 		// offsets inside the row segment: exclusive scan over the cells of the same row
 		uint32_t sc = val;
 #pragma unroll
@@ -934,7 +961,7 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 		const uint32_t carry = kin > lane ? L.run[r] : 0u;  // the row began in an earlier batch
 		const uint32_t off = carry + (sc - val) - before_head;
 		{  // the slow cells of the batch go on the list of the slot's group, one atomic per wave
-			const bool slowlane = on && !fastcell && ebase + g < a.entry_cap;
+			const bool slowlane = on && !fastcell && !tested && ebase + g < a.entry_cap;
 			const uint64_t sm = __ballot(slowlane);
 			if (sm) {
 				const uint32_t leader = (uint32_t)__builtin_ctzll(sm);
@@ -948,12 +975,14 @@ __global__ __launch_bounds__(256) void k_cells(const CellsArgs a) {
 			const uint32_t ri = ebase + g;
 			Entry e;
 			if (fastcell) { e.w0 = f.x | xl; e.w1 = off; e.w2 = f.y; e.w3 = f.z; }
+			else if (tested) e = make_tested_entry(xl, i, tpoff, tinfo, off & 0xFFFFu, off >> 16);
 			else {
 				e = make_pending_entry(xl, i);
 				L.slowrow[r] = rowflag | 2u;
 			}
 			if (ri < a.entry_cap) {
-				a.entries_a[ri] = entry_a(e);  // (half B of a fast record follows from its sign index; k_slow_plan writes the others')
+				a.entries_a[ri] = entry_a(e);  // (half B of a fast record follows from its sign index; k_slow_plan writes the slow ones')
+				if (tested) a.entries_b[ri] = entry_b(e);
 				a.entry_seg[ri] = (uint32_t)(sidx0 + r);
 			}
 			if (kin + 1u == rowcnt || lane == 63u) L.run[r] = off + val;  // last cell of the row in this batch
@@ -1325,6 +1354,7 @@ struct mc33hip_ctx {
 	EntryA *entries_a;
 	EntryB *entries_b;
 	EntryB *d_fast_b;
+	uint32_t *d_pat;
 	uint32_t *entry_seg, *slow_list, *dirty_list;
 	uint32_t *list_cnt;       // [2][LIST_CHUNKS] cursors of the slow / dirty list parts (ListChunks)
 	ListChunks lc;            // ... for the range last counted
@@ -1451,6 +1481,11 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 		fast_b_table(fast, fb);
 		CREATE_TRY(hipMalloc(&c->d_fast_b, sizeof fb));
 		CREATE_TRY(hipMemcpy(c->d_fast_b, fb, sizeof fb, hipMemcpyHostToDevice));
+		constexpr uint32_t lut_n = sizeof mc33_lut / sizeof mc33_lut[0];
+		uint32_t pat[lut_n];
+		build_pattern_info(mc33_lut, lut_n, pat);
+		CREATE_TRY(hipMalloc(&c->d_pat, sizeof pat));
+		CREATE_TRY(hipMemcpy(c->d_pat, pat, sizeof pat, hipMemcpyHostToDevice));
 	}
 	CREATE_TRY(hipMalloc(&c->d_ctr, sizeof(Counters)));
 	CREATE_TRY(hipMalloc(&c->list_cnt, 2 * LIST_CHUNKS * sizeof(uint32_t)));
@@ -1478,7 +1513,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_rules); (void)hipFree(c->d_rule_index); (void)hipFree(c->d_fast);
 	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
-	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->d_fast_b); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
+	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->d_fast_b); (void)hipFree(c->d_pat); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
 	for (int k = 0; k < MC33_LANES; k++) {
 		IsoLane &L = c->lanes[k];
 		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.slot_part); (void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
@@ -1908,12 +1943,12 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	ca.dev = env_u32("MC33_HIP_CELLS_DEV", 0);
 #endif
 	ca.G.p = c->d_grid; ca.G.pitch = (uint32_t)c->pitch; ca.G.z0 = c->desc.plane0; ca.G.slice = c->slice;
-	ca.P = P; ca.fast = c->d_fast;
+	ca.P = P; ca.fast = c->d_fast; ca.lut = c->d_lut; ca.pat = c->d_pat;
 	ca.ze = ze; ca.nYT = g.nYT; ca.nseg_pad = g.nseg;
 	ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.slot_base = c->slot_base;
 	ca.epoch = L.epoch;
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir;
-	ca.entries_a = c->entries_a; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
+	ca.entries_a = c->entries_a; ca.entries_b = c->entries_b; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
 	ca.entry_cap = (uint32_t)c->entry_cap;
 	ca.ctr = c->d_ctr;
 	ca.trace = nullptr;

@@ -59,6 +59,9 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	std::vector<uint64_t> seg_mask(4 * nsegs, 0ull);
 	uint32_t fast[256];
 	build_fast_table(mc33_lut, fast);
+	constexpr uint32_t lut_n = sizeof mc33_lut / sizeof mc33_lut[0];
+	static uint32_t pat_info[lut_n];
+	build_pattern_info(mc33_lut, lut_n, pat_info);
 	const char *force = getenv("MC33_EMU_FORCE_SLOW");  // "all": no fast path; "odd": cells with odd x go slow
 	const int force_mode = !force ? 0 : (force[0] == 'a' ? 1 : 2);
 	std::vector<Entry> entries;
@@ -90,7 +93,16 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 					plan_cell(p, tab, P, G, x, y, z, i, v);
 					const uint32_t nt = z < z_emit ? p.ntri : count_triangles(p, tab, P, G, x, y, z, w);
 					Entry en = make_entry(x % SEG_CELLS, i, p, nt, voff, toff, true);
-					if (force_mode != 1 && cell_is_tested(p, x, y, z)) en.w3 ^= ENTRY_SLOW | ENTRY_TESTED;  // as k_slow_plan: the fast emit writes it
+					if (force_mode != 1 && cell_is_tested(p, x, y, z)) {  // as k_cells / k_slow_plan: the fast emit writes it
+						en.w3 ^= ENTRY_SLOW | ENTRY_TESTED;
+						// k_cells makes the same record from the pattern offset and the pattern-info table alone
+						const Entry t = make_tested_entry(x % SEG_CELLS, i, p.poff, pat_info[p.poff], voff, toff);
+						if (t.w0 != en.w0 || t.w1 != en.w1 || t.w2 != en.w2 || t.w3 != en.w3) return -8;
+						Corner8 c8;
+						for (int k = 0; k < 8; k++) c8.a[k] = v[k];
+						uint32_t m8, n8;
+						if (pattern_offset(tab.lut, i, c8, m8, n8) != p.poff) return -9;
+					}
 					entries.push_back(en);
 					seg_cnt[s] = seg_pack(voff + p.nnew, toff + nt);
 				}
