@@ -452,8 +452,10 @@ MC33_HD GridEdge tgt_edge(uint32_t t, uint32_t x, uint32_t y, uint32_t z) {
 	return g;
 }
 
-// Follow a grid edge to the cell that creates its vertex (used by the count pass, where no ids exist
-// yet, to decide the reference's zero-area test MC:1235 on vertex IDENTITY).  w: scratch for 8 values.
+// Follow a grid edge to the cell that creates its vertex by PLANNING every owner on the way (the round-1 formulation of
+// the count pass: no stored plans needed).  The kernels use chase_root / count_triangles_stored on the stored plans
+// instead; root_of, slots_differ and count_triangles are kept as the independent statement the host emulator checks
+// those against.  w: scratch for 8 values.
 struct VertexKey {
 	uint32_t x, y, z, rank;
 };
@@ -636,7 +638,8 @@ struct Entry {
 	              // rank of the cell-centre vertex (4) << 24
 };
 constexpr uint32_t ENTRY_SLOW = 1u << 20;    // the generic per-cell code writes the cell (k_emit_slow)
-constexpr uint32_t ENTRY_TESTED = 1u << 21;  // planned by k_slow_plan, written by the fast emit passes (see cell_is_tested)
+constexpr uint32_t ENTRY_TESTED = 1u << 21;  // pattern chosen by the face / interior tests, written by the fast emit passes (see cell_is_tested)
+constexpr uint32_t ENTRY_COUNT = 1u << 22;   // slow record whose triangles are still to be counted by vertex identity (k_slow_count)
 MC33_HD Entry make_entry(uint32_t xl, uint32_t i, const CellPlan &p, uint32_t nt, uint32_t voff, uint32_t toff, bool slow) {
 	Entry e;
 	e.w0 = xl | i << 8 | (uint32_t)p.poff << 16 | (uint32_t)p.nnew << 28;
@@ -679,15 +682,15 @@ MC33_HD Entry make_pending_entry(uint32_t xl, uint32_t i) {
 
 // Storage of the work records.  In registers a record is an Entry; in HBM it is split in two 8-byte halves kept in two
 // arrays with the same index:
-//   A: x in the segment (8) | sign index (8) | nnew (4) | triangles (4) | slow flag (1 << 24) | tested flag (1 << 25)   ;   vertex offset (16) | triangle offset (16)
+//   A: x in the segment (8) | sign index (8) | nnew (4) | triangles (4) | slow flag (1 << 24) | tested flag (1 << 25) | count flag (1 << 26)   ;   vertex offset (16) | triangle offset (16)
 //   B: ranks of edges 0..7   ;   ranks of edges 8..11 (16) | pattern offset (12) << 16 | rank of the centre vertex (4) << 28
 // Half B of a FAST record is a function of its sign index (fast_b_table): it is never written or read - a fast
 // record costs 8 bytes of HBM traffic per pass instead of 16 (writes are what the passes after the sweep pay for most).
 struct EntryA { uint32_t a0, a1; };
 struct EntryB { uint32_t b0, b1; };
-constexpr uint32_t ENTRYA_SLOW = 1u << 24, ENTRYA_TESTED = 1u << 25;
+constexpr uint32_t ENTRYA_SLOW = 1u << 24, ENTRYA_TESTED = 1u << 25, ENTRYA_COUNT = 1u << 26;
 MC33_HD EntryA entry_a(const Entry &e) {
-	return EntryA{(e.w0 & 0xFFFFu) | (e.w0 >> 28) << 16 | ((e.w3 >> 16) & 15u) << 20 | ((e.w3 >> 20) & 3u) << 24, e.w1};
+	return EntryA{(e.w0 & 0xFFFFu) | (e.w0 >> 28) << 16 | ((e.w3 >> 16) & 15u) << 20 | ((e.w3 >> 20) & 7u) << 24, e.w1};
 }
 MC33_HD EntryB entry_b(const Entry &e) { return EntryB{e.w2, (e.w3 & 0xFFFFu) | ((e.w0 >> 16) & 0xFFFu) << 16 | (e.w3 >> 24) << 28}; }
 MC33_HD Entry entry_join(const EntryA &a, const EntryB &b) {
@@ -695,7 +698,7 @@ MC33_HD Entry entry_join(const EntryA &a, const EntryB &b) {
 	e.w0 = (a.a0 & 0xFFFFu) | ((b.b1 >> 16) & 0xFFFu) << 16 | ((a.a0 >> 16) & 15u) << 28;
 	e.w1 = a.a1;
 	e.w2 = b.b0;
-	e.w3 = (b.b1 & 0xFFFFu) | ((a.a0 >> 20) & 15u) << 16 | ((a.a0 >> 24) & 3u) << 20 | (b.b1 >> 28) << 24;
+	e.w3 = (b.b1 & 0xFFFFu) | ((a.a0 >> 20) & 15u) << 16 | ((a.a0 >> 24) & 7u) << 20 | (b.b1 >> 28) << 24;
 	return e;
 }
 MC33_HD uint32_t entrya_nnew(const EntryA &a) { return (a.a0 >> 16) & 15u; }
@@ -712,6 +715,42 @@ MC33_HD Entry load_entry(const EntryA *ea, const EntryB *eb, const EntryB *fast_
 	const EntryA a = ea[ri];
 	const EntryB b = (a.a0 & (ENTRYA_SLOW | ENTRYA_TESTED)) ? eb[ri] : fast_b[(a.a0 >> 8) & 0xFFu];
 	return entry_join(a, b);
+}
+
+// Third part of a SLOW record (16 bytes, same index): what its plan says about the slots that take their vertex from
+// elsewhere, so that nobody has to make the plan of a cell twice - the count pass and the emit pass follow chains of
+// such references from record to record (chase_root) instead of re-planning every owner on the way.
+//   tgt[3]: byte per edge 0..11, as CellPlan::tgt   ;   masks: visited (12) | created (12) << 12 | corners equal to the isovalue (8) << 24
+//   (the centre slot 12 is visited and created exactly when it has a rank)
+struct EntryC { uint32_t tgt[3], masks; };
+MC33_HD EntryC entry_c(const CellPlan &p) {
+	return EntryC{{p.tgt[0], p.tgt[1], p.tgt[2]}, (p.visited & 0xFFFu) | (p.created & 0xFFFu) << 12 | (uint32_t)p.zmask << 24};
+}
+// the plan back from the record (all but onpoint / onb, which plan_restore_points derives from the corner values)
+MC33_HD void plan_restore(CellPlan &p, const uint16_t *lut, const Entry &en, const EntryC &c) {
+	const uint32_t i = (en.w0 >> 8) & 0xFFu, r12 = entry_rank_centre(en), has12 = r12 != 15u ? 1u << 12 : 0u;
+	p.rank = (uint64_t)en.w2 | (uint64_t)(en.w3 & 0xFFFFu) << 32 | (uint64_t)r12 << 48 | 0xFFF0000000000000ull;
+	p.visited = (c.masks & 0xFFFu) | has12;
+	p.created = ((c.masks >> 12) & 0xFFFu) | has12;
+	p.onpoint = p.onb = 0;
+	p.tgt[0] = c.tgt[0]; p.tgt[1] = c.tgt[1]; p.tgt[2] = c.tgt[2];
+	p.poff = (uint16_t)((en.w0 >> 16) & 0xFFFu);
+	p.n = (uint8_t)(((lut[(i & 0x80) ? (i ^ 0xFF) : i] >> 11) ^ (i >> 7) ^ 1u) & 1u);  // as pattern_offset
+	p.m = (uint8_t)!p.n;
+	p.nnew = (uint8_t)entry_nnew(en);
+	p.ntri = 0;
+	p.zmask = (uint8_t)(c.masks >> 24);
+}
+template <typename V>
+MC33_HD void plan_restore_points(CellPlan &p, const V &v) {  // as plan_visit sets them (MC:628: the vertex lies on a grid point)
+	for (uint32_t e = 0; e < 12; e++) {
+		if (!(p.created & (1u << e))) continue;
+		const real_t va = v[(int)edge_a(e)], vb = v[(int)edge_b(e)];
+		if (va == 0 || vb == 0) {
+			p.onpoint |= 1u << e;
+			if (va != 0) p.onb |= 1u << e;
+		}
+	}
 }
 
 inline void build_fast_table(const uint16_t *lut, uint32_t *fast /*[256]*/) {
@@ -834,6 +873,7 @@ struct EmitCtx {
 	const SegDir *seg_dir;
 	const EntryA *entries_a;    // work records, half A (all) and half B (slow records only)
 	const EntryB *entries_b;
+	const EntryC *entries_c;    // plans of the slow records
 	const EntryB *fast_b;       // [256] half B of the fast records (may point into LDS)
 	const uint32_t *entry_seg;  // row segment of each entry
 	real_t *V;
@@ -873,9 +913,16 @@ MC33_HD uint32_t find_record(const EmitCtx<T> &c, uint64_t s, uint32_t xl) {
 	return record_rank(w, xl);
 }
 
-// id of the vertex on a grid edge, through the owner's entry (emit pass).  w: scratch for 8 values.
+// The vertex a grid edge resolves to, followed from record to record: the record of the cell that creates it, the
+// vertex's rank among that cell's new vertices, and where that cell's vertices begin in its row segment.  rec == NO_ID:
+// no vertex.  Every hop is a directory word + the owner's record (+ its stored plan if it is a slow one); no samples are
+// read and no plan is made (round 1 re-planned every owner on the way: load_cell + plan_cell per hop).
+struct RootRef {
+	uint32_t rec, rank, seg, voff;
+};
 template <typename T>
-MC33_HD uint32_t edge_vertex_id(const EmitCtx<T> &c, GridEdge g, const VRef &w) {
+MC33_HD RootRef chase_root(const EmitCtx<T> &c, GridEdge g, const VRef &w) {
+	const RootRef none = {NO_ID, 15u, 0u, 0u};
 	for (int hop = 0; hop < 64; hop++) {
 		const OwnerRef o = owner_of(g.axis, g.x, g.y, g.z);
 		const uint64_t s = segment_index(c.P, o.x, o.y, o.z);
@@ -884,29 +931,72 @@ MC33_HD uint32_t edge_vertex_id(const EmitCtx<T> &c, GridEdge g, const VRef &w) 
 		// at all, and its directory entry is then whatever an earlier extraction left: do not look at it.
 		if (c.P.negzero_iso) {
 			const uint32_t oi = load_cell(c.G, c.P.iso, o.x, o.y, o.z, w);
-			if (oi == 0 || oi == 0xFF) return NO_ID;
+			if (oi == 0 || oi == 0xFF) return none;
 		}
 		const uint32_t ri = find_record(c, s, o.x % SEG_CELLS);
-		if (ri == NO_ID) return NO_ID;
-		const Entry e = ctx_entry(c, ri);
+		if (ri == NO_ID) return none;
+		const EntryA ea = c.entries_a[ri];
+		const bool stored = (ea.a0 & (ENTRYA_SLOW | ENTRYA_TESTED)) != 0;
+		const Entry e = entry_join(ea, stored ? c.entries_b[ri] : c.fast_b[(ea.a0 >> 8) & 0xFFu]);
 		const uint32_t r = entry_rank(e, o.e);
-		if (r != 15u) return c.seg_base[s].vbase + (e.w1 & 0xFFFFu) + r;
-		// the owner itself took the id from another grid edge: recompute its plan to learn which
-		const uint32_t i = load_cell(c.G, c.P.iso, o.x, o.y, o.z, w);
-		CellPlan q;
-		plan_cell(q, c.tab, c.P, c.G, o.x, o.y, o.z, i, w);
-		if (!(q.visited & (1u << o.e))) return NO_ID;
-		g = tgt_edge(plan_tgt(q, o.e), o.x, o.y, o.z);
+		if (r != 15u) return RootRef{ri, r, (uint32_t)s, ea.a1 & 0xFFFFu};
+		if (!(ea.a0 & ENTRYA_SLOW)) return none;  // a fast or tested cell creates the vertices of its cut edges itself: the edge is not in its pattern
+		const EntryC pc = c.entries_c[ri];
+		if (!(pc.masks & (1u << o.e))) return none;  // (owned edges are 0..11)
+		g = tgt_edge((pc.tgt[o.e >> 2] >> (8 * (o.e & 3))) & 0xFFu, o.x, o.y, o.z);
 	}
-	return NO_ID;
+	return none;
+}
+MC33_HD uint64_t root_key(const RootRef &r) { return r.rec == NO_ID ? ~0ull : (uint64_t)r.rec << 4 | r.rank; }
+
+// Roots of the slots of one cell, each chased at most once (count pass: a slot is compared with up to 2 x 12 others).
+// p == nullptr: nothing is remembered.
+struct RootMemo {
+	uint64_t *p;
+	int stride;
+	uint32_t have;
+};
+template <typename T>
+MC33_HD uint64_t slot_root(const EmitCtx<T> &c, const CellPlan &p, uint32_t x, uint32_t y, uint32_t z, uint32_t e, const VRef &w, RootMemo &memo) {
+	if (memo.p && (memo.have & (1u << e))) return memo.p[e * memo.stride];
+	const uint64_t k = root_key(chase_root(c, tgt_edge(plan_tgt(p, e), x, y, z), w));
+	if (memo.p) { memo.p[e * memo.stride] = k; memo.have |= 1u << e; }
+	return k;
+}
+// do pattern slots ea and eb of this cell refer to different vertices?  (slots_differ on the stored plans)
+template <typename T>
+MC33_HD bool slots_differ_stored(const EmitCtx<T> &c, const CellPlan &p, uint32_t x, uint32_t y, uint32_t z, uint32_t ea, uint32_t eb,
+                                 const VRef &w, RootMemo &memo) {
+	const uint32_t ra = plan_rank(p, ea), rb = plan_rank(p, eb);
+	if (ra != 15u && rb != 15u) return ra != rb;
+	if (ra != 15u || rb != 15u) return true;  // one created here, the other by an earlier cell
+	const uint32_t ta = plan_tgt(p, ea), tb = plan_tgt(p, eb);
+	if (ta == tb) return false;
+	// two different grid edges share a vertex only when it lies on a common end point with value 0
+	const uint32_t ca = (1u << edge_a(ea)) | (1u << edge_b(ea)), cb = (1u << edge_a(eb)) | (1u << edge_b(eb));
+	if (!(ca & cb & p.zmask)) return true;
+	return slot_root(c, p, x, y, z, ea, w, memo) != slot_root(c, p, x, y, z, eb, w, memo);
+}
+// number of triangles the cell appends (MC:1235 drops triangles with two equal vertex ids), from the stored plans
+template <typename T>
+MC33_HD uint32_t count_triangles_stored(const EmitCtx<T> &c, const CellPlan &p, uint32_t x, uint32_t y, uint32_t z, const VRef &w, RootMemo &memo) {
+	uint32_t pos = p.poff, word, nt = 0;
+	do {
+		word = c.tab.lut[++pos];
+		const uint32_t e0 = word & 15u, e1 = (word >> 4) & 15u, e2 = (word >> 8) & 15u;
+		if (!p.zmask || (slots_differ_stored(c, p, x, y, z, e0, e1, w, memo) && slots_differ_stored(c, p, x, y, z, e0, e2, w, memo) &&
+		                 slots_differ_stored(c, p, x, y, z, e1, e2, w, memo)))
+			nt++;
+	} while (word >> 12);
+	return nt;
 }
 
-// Emit pass for one active cell: writes its NEW vertices and its triangles.
-// v, w: 8-value scratch arrays; ids: 13-slot scratch.
+// Emit pass for one SLOW record: writes its NEW vertices and its triangles.  The plan comes back from the record
+// (plan_restore); v, w: 8-value scratch arrays; ids: 13-slot scratch.
 template <typename T>
 MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v, const VRef &w, const URef &ids) {
 	const Entry en = ctx_entry(c, entry_index);
-	if (en.w3 & ENTRY_TESTED) return;  // (on the slow list, but the fast emit passes write it)
+	if (!(en.w3 & ENTRY_SLOW)) return;  // (a tested cell that k_slow_plan found on the slow list: the fast emit passes write it)
 	const uint32_t s = c.entry_seg[entry_index];
 	const SegCoord sc = segment_coord(c.P, s);
 	const uint32_t y = sc.y, z = sc.z;
@@ -915,9 +1005,10 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 	const SegBase sb = c.seg_base[s];
 	const uint32_t vbase = sb.vbase + (en.w1 & 0xFFFFu);
 	uint32_t tpos = sb.tbase + (en.w1 >> 16) - c.t_skip;
-	const uint32_t i = load_cell(c.G, c.P.iso, x, y, z, v);
+	load_cell(c.G, c.P.iso, x, y, z, v);
 	CellPlan p;
-	plan_cell(p, c.tab, c.P, c.G, x, y, z, i, v);
+	plan_restore(p, c.tab.lut, en, c.entries_c[entry_index]);
+	plan_restore_points(p, v);
 	// ids of all slots of the pattern; NEW vertices are written on the way
 	for (uint32_t e = 0; e < 13; e++) {
 		if (!(p.visited & (1u << e))) continue;
@@ -934,9 +1025,12 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 					vertex_on_edge(c.P, c.G, x, y, z, e, v, g);
 				store_vertex(c.P, g, c.V, c.N, vbase + r - c.v_skip);
 			}
-		} else
-			ids[(int)e] = edge_vertex_id(c, tgt_edge(plan_tgt(p, e), x, y, z), w);
+		} else {
+			const RootRef root = chase_root(c, tgt_edge(plan_tgt(p, e), x, y, z), w);
+			ids[(int)e] = root.rec == NO_ID ? NO_ID : c.seg_base[root.seg].vbase + root.voff + root.rank;
+		}
 	}
+	RootMemo memo{nullptr, 0, 0u};
 	uint32_t pos = p.poff, word;
 	do {  // MC:780-784, 1235-1250
 		word = c.tab.lut[++pos];
@@ -945,11 +1039,11 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 		ti[2] = ids[(int)e2];
 		ti[1] = ids[(int)e1];
 		ti[0] = ids[(int)e0];
-		// MC:1235 on the ids - except for iso = -0.0, where ids may be "no vertex" (see edge_vertex_id): the triangle slots
-		// were counted by vertex identity (count_triangles), and the same test decides here, so that every counted slot is
+		// MC:1235 on the ids - except for iso = -0.0, where ids may be "no vertex" (see chase_root): the triangle slots
+		// were counted by vertex identity (count_triangles_stored), and the same test decides here, so that every counted slot is
 		// written and the output is a function of the input alone
-		const bool keep = c.P.negzero_iso ? (slots_differ(p, c.tab, c.P, c.G, x, y, z, e2, e1, w) && slots_differ(p, c.tab, c.P, c.G, x, y, z, e2, e0, w) &&
-		                                     slots_differ(p, c.tab, c.P, c.G, x, y, z, e1, e0, w))
+		const bool keep = c.P.negzero_iso ? (slots_differ_stored(c, p, x, y, z, e2, e1, w, memo) && slots_differ_stored(c, p, x, y, z, e2, e0, w, memo) &&
+		                                     slots_differ_stored(c, p, x, y, z, e1, e0, w, memo))
 		                                  : (ti[0] != ti[1] && ti[0] != ti[2] && ti[1] != ti[2]);
 		if (keep) {
 			uint32_t *t = c.Tri + 3 * (uint64_t)tpos++;

@@ -77,7 +77,7 @@ struct Counters {
 	uint32_t dirty_cursor;  // row segments whose offsets k_seg_fix has to rebuild
 	uint32_t mask_cursor;   // activity-mask records handed out
 	uint32_t emit_skipped;  // set by the emit kernels when they refused to run (capacity / overflow)
-	uint32_t pad_;
+	uint32_t count_pending; // set by k_slow_plan when a record waits for k_slow_count
 	uint64_t totV, totT;    // totals over all classified slices (ghost included)
 	uint64_t ghostV, ghostT;
 };
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 	if (c == 0) for (uint32_t q = gridDim.x + t; q < part_cap; q += 256u) part_next[q] = 0;  // (a later range may be longer)
 	if (c == 0) for (uint32_t q = t; q < LIST_CHUNKS; q += 256u) { lc.slow_cnt[q] = 0; lc.dirty_cnt[q] = 0; }  // the list cursors of this extraction
 	if (c == 0 && t == 0) {        // ... and so are the counters the later passes of this one add to
-		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0;
+		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0; ctr->count_pending = 0;
 		ctr->totV = ctr->totT = ctr->ghostV = ctr->ghostT = 0;
 	}
 	unsigned long long below = 0;
@@ -1031,6 +1031,8 @@ struct SlowArgs {
 	uint32_t z_emit;  // slices below are ghosts of a z-slab
 	EntryA *entries_a;
 	EntryB *entries_b;
+	EntryC *entries_c;       // plans of the slow records (k_slow_plan writes, k_slow_count and k_emit_slow follow them)
+	const EntryB *fast_b;
 	const uint32_t *entry_seg;
 	const uint32_t *slow_list;
 	uint32_t *seg_cnt;
@@ -1044,7 +1046,6 @@ struct SlowArgs {
 
 __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 	__shared__ real_t s_v[8][256];
-	__shared__ real_t s_w[8][256];
 	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
 	ChunkMap cm;
 	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);  // (first: its loads and the one of the cursor below go out together)
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 	if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->slow_cursor = n;  // (for the host's report)
 	if (blockIdx.x * 256u >= n) return;             // (nothing for this block: most blocks of most calls)
 	const Tables &tab = a.tab;  // (the tables in LDS instead: tried - flat loads tie the LDS and memory wait counters together; slower)
-	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
+	const VRef v{&s_v[0][threadIdx.x], 256};
 	const Params &P = a.P;
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
 		const uint32_t gq = cm.group_of(t);
@@ -1065,13 +1066,49 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 		const uint32_t i = load_cell(a.G, P.iso, x, y, z, v);
 		CellPlan pl;
 		plan_cell(pl, tab, P, a.G, x, y, z, i, v);
-		// Ghost cells only lend vertex ids to the slab above; their triangle count cancels out of every
-		// offset, so the identity test (which may read one more plane below) is skipped.
-		const uint32_t nt = z < a.z_emit ? pl.ntri : count_triangles(pl, tab, P, a.G, x, y, z, w);
-		Entry en = make_entry(xl, i, pl, nt, 0, 0, true);
+		// Triangles with two equal vertices are not appended (MC:1235): with a corner equal to the isovalue that is a question
+		// of vertex IDENTITY, answered by k_slow_count once the plans of all slow cells are stored.  Ghost cells only lend vertex
+		// ids to the slab above; their triangle count cancels out of every offset, so the identity test (which may follow a
+		// reference one more plane down) is skipped.
+		Entry en = make_entry(xl, i, pl, pl.ntri, 0, 0, true);
 		if (cell_is_tested(pl, x, y, z)) en.w3 ^= ENTRY_SLOW | ENTRY_TESTED;  // the fast emit passes can write it
+		else if (pl.zmask && z >= a.z_emit) { en.w3 |= ENTRY_COUNT; a.ctr->count_pending = 1u; }
 		a.entries_a[ei] = entry_a(en);
 		a.entries_b[ei] = entry_b(en);
+		if (en.w3 & ENTRY_SLOW) a.entries_c[ei] = entry_c(pl);
+	}
+}
+
+// the triangles of the slow cells that have a corner equal to the isovalue, counted by vertex identity on the stored plans
+__global__ __launch_bounds__(256) void k_slow_count(const SlowArgs a) {
+	__shared__ real_t s_w[8][256];
+	__shared__ uint64_t s_key[12][256];
+	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+	if (!a.ctr->count_pending) return;  // (no sample of a slow cell equals the isovalue: most calls)
+	ChunkMap cm;
+	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);
+	if (a.ctr->entry_cursor > a.entry_cap) return;
+	const uint32_t n = cm.total;
+	if (blockIdx.x * 256u >= n) return;
+	EmitCtx<sample_t> c;
+	c.tab = a.tab; c.P = a.P; c.G = a.G;
+	c.seg_base = nullptr; c.seg_dir = a.seg_dir;
+	c.entries_a = a.entries_a; c.entries_b = a.entries_b; c.entries_c = a.entries_c; c.fast_b = a.fast_b; c.entry_seg = a.entry_seg;
+	c.V = nullptr; c.N = nullptr; c.Tri = nullptr;
+	c.z_emit = a.z_emit; c.v_skip = c.t_skip = c.id_delta = 0;
+	const VRef w{&s_w[0][threadIdx.x], 256};
+	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+		const uint32_t gq = cm.group_of(t);
+		const uint32_t ei = a.slow_list[a.slot_base[(uint64_t)gq << a.lc.shift].x + (t - cm.pre[gq])];
+		const EntryA ea = a.entries_a[ei];
+		if (!(ea.a0 & ENTRYA_COUNT)) continue;
+		const Entry en = entry_join(ea, a.entries_b[ei]);
+		CellPlan pl;
+		plan_restore(pl, a.tab.lut, en, a.entries_c[ei]);
+		const SegCoord sc = segment_coord(a.P, a.entry_seg[ei]);
+		RootMemo memo{&s_key[0][threadIdx.x], 256, 0u};
+		const uint32_t nt = count_triangles_stored(c, pl, sc.xbase + (ea.a0 & 0xFFu), sc.y, sc.z, w, memo);
+		a.entries_a[ei].a0 = (ea.a0 & ~(15u << 20) & ~ENTRYA_COUNT) | nt << 20;
 	}
 }
 
@@ -1353,6 +1390,7 @@ struct mc33hip_ctx {
 	uint64_t bs_cap;
 	EntryA *entries_a;
 	EntryB *entries_b;
+	EntryC *entries_c;
 	EntryB *d_fast_b;
 	uint32_t *d_pat;
 	uint32_t *entry_seg, *slow_list, *dirty_list;
@@ -1513,7 +1551,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_rules); (void)hipFree(c->d_rule_index); (void)hipFree(c->d_fast);
 	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
-	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->d_fast_b); (void)hipFree(c->d_pat); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
+	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->entries_c); (void)hipFree(c->d_fast_b); (void)hipFree(c->d_pat); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
 	for (int k = 0; k < MC33_LANES; k++) {
 		IsoLane &L = c->lanes[k];
 		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.slot_part); (void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
@@ -1689,12 +1727,13 @@ static uint32_t env_u32(const char *name, uint32_t dflt) {
 }
 
 static int alloc_entries(mc33hip_ctx *c, uint64_t cap) {
-	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
-	c->entries_a = nullptr; c->entries_b = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr;
+	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->entries_c); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
+	c->entries_a = nullptr; c->entries_b = nullptr; c->entries_c = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr;
 	c->entry_cap = 0;
 	if (cap > 0xFFFFFF00ull) cap = 0xFFFFFF00ull;
 	HIP_TRY(hipMalloc(&c->entries_a, cap * sizeof(EntryA)));
-	HIP_TRY(hipMalloc(&c->entries_b, cap * sizeof(EntryB)));  // (touched for slow records only)
+	HIP_TRY(hipMalloc(&c->entries_b, cap * sizeof(EntryB)));  // (touched for tested and slow records only)
+	HIP_TRY(hipMalloc(&c->entries_c, cap * sizeof(EntryC)));  // (... for slow records only)
 	HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
 	HIP_TRY(hipMalloc(&c->slow_list, cap * 4));
 	HIP_TRY(hipMalloc(&c->dirty_list, cap * 4));
@@ -1974,12 +2013,13 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	sa.G = a.G; sa.P = P;
 	sa.tab.lut = c->d_lut; sa.tab.rule_words = c->d_rules; sa.tab.rule_index = c->d_rule_index;
 	sa.z_emit = c->range.z_begin;
-	sa.entries_a = c->entries_a; sa.entries_b = c->entries_b; sa.entry_seg = c->entry_seg; sa.slow_list = c->slow_list;
+	sa.entries_a = c->entries_a; sa.entries_b = c->entries_b; sa.entries_c = c->entries_c; sa.fast_b = c->d_fast_b; sa.entry_seg = c->entry_seg; sa.slow_list = c->slow_list;
 	sa.seg_cnt = c->seg_cnt; sa.seg_dir = c->seg_dir; sa.dirty_list = c->dirty_list;
 	sa.lc = c->lc; sa.slot_base = c->slot_base;
 	sa.entry_cap = (uint32_t)c->entry_cap; sa.ctr = c->d_ctr;
 	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);  // (blocks beyond the list end at once)
 	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks), dim3(256), 0, st, sa);
+	hipLaunchKernelGGL(k_slow_count, dim3(slow_blocks), dim3(256), 0, st, sa);
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
 	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
 	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT);
@@ -2092,7 +2132,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.c.P = c->P;
 	a.c.G.p = c->d_grid; a.c.G.pitch = (uint32_t)c->pitch; a.c.G.z0 = c->desc.plane0; a.c.G.slice = c->slice;
 	a.c.seg_base = c->seg_base; a.c.seg_dir = c->seg_dir;
-	a.c.entries_a = c->entries_a; a.c.entries_b = c->entries_b; a.c.fast_b = c->d_fast_b; a.c.entry_seg = c->entry_seg;
+	a.c.entries_a = c->entries_a; a.c.entries_b = c->entries_b; a.c.entries_c = c->entries_c; a.c.fast_b = c->d_fast_b; a.c.entry_seg = c->entry_seg;
 	a.c.V = (real_t *)dV; a.c.N = (float *)dN; a.c.Tri = (uint32_t *)dT;
 	a.c.z_emit = c->range.z_begin; a.c.v_skip = a.c.t_skip = a.c.id_delta = 0;
 	a.ctr = c->d_ctr;

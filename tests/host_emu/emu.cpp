@@ -64,53 +64,100 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	build_pattern_info(mc33_lut, lut_n, pat_info);
 	const char *force = getenv("MC33_EMU_FORCE_SLOW");  // "all": no fast path; "odd": cells with odd x go slow
 	const int force_mode = !force ? 0 : (force[0] == 'a' ? 1 : 2);
-	std::vector<Entry> entries;
+	// The records as the kernels keep them: half A for all, half B for tested and slow records (fast ones: from the table),
+	// part C (the stored plan) for slow ones.
+	std::vector<EntryA> ea;
+	std::vector<EntryB> eb;
+	std::vector<EntryC> ec;
 	std::vector<uint32_t> entry_seg;
+	EntryB fast_b[256];
+	fast_b_table(fast, fast_b);
 	float vbuf[8], wbuf[8];
 	uint32_t idbuf[13];
 	VRef v{vbuf, 1}, w{wbuf, 1};
 	URef ids{idbuf, 1};
-	// count pass
+	// pass 1 (k_cells + k_slow_plan): one record per cut cell, in sweep order; slow cells are planned, their plan stored
 	for (uint32_t z = P.zs; z < ze; z++)
 		for (uint32_t y = 0; y < P.ny; y++)
 			for (uint32_t x = 0; x < P.nx; x++) {
 				const uint32_t i = load_cell(G, iso, x, y, z, v);
 				if (i == 0 || i == 0xFF) continue;
 				const uint64_t s = segment_index(P, x, y, z);
-				if (seg_nent[s] == 0) seg_first[s] = (uint32_t)entries.size();
+				if (seg_nent[s] == 0) seg_first[s] = (uint32_t)ea.size();
 				seg_mask[4ull * s + ((x % SEG_CELLS) >> 6)] |= 1ull << (x & 63u);
-				const uint32_t voff = seg_cnt[s] & 0xFFFF, toff = seg_cnt[s] >> 16;
 				bool zero = false;
 				for (int k = 0; k < 8; k++) zero |= v[k] == 0;
 				bool is_fast = x && y && z && fast[i] != FAST_NONE && !zero;
 				if (force_mode == 1 || (force_mode == 2 && (x & 1))) is_fast = false;
-				if (is_fast) {  // as k_sweep: everything from the sign index
-					const uint32_t f = fast[i];
-					entries.push_back(make_fast_entry(x % SEG_CELLS, i, f, voff, toff));
-					seg_cnt[s] = seg_pack(voff + ((f >> 16) & 15u), toff + ((f >> 12) & 15u));
-				} else {        // as k_slow_plan + k_seg_fix
+				Entry en;
+				EntryC pc{{0xDEADBEEFu, 0xDEADBEEFu, 0xDEADBEEFu}, 0xDEADBEEFu};
+				if (is_fast) en = make_fast_entry(x % SEG_CELLS, i, fast[i], 0, 0);  // as k_cells: everything from the sign index
+				else {
 					CellPlan p;
 					plan_cell(p, tab, P, G, x, y, z, i, v);
-					const uint32_t nt = z < z_emit ? p.ntri : count_triangles(p, tab, P, G, x, y, z, w);
-					Entry en = make_entry(x % SEG_CELLS, i, p, nt, voff, toff, true);
+					en = make_entry(x % SEG_CELLS, i, p, p.ntri, 0, 0, true);
 					if (force_mode != 1 && cell_is_tested(p, x, y, z)) {  // as k_cells / k_slow_plan: the fast emit writes it
 						en.w3 ^= ENTRY_SLOW | ENTRY_TESTED;
 						// k_cells makes the same record from the pattern offset and the pattern-info table alone
-						const Entry t = make_tested_entry(x % SEG_CELLS, i, p.poff, pat_info[p.poff], voff, toff);
+						const Entry t = make_tested_entry(x % SEG_CELLS, i, p.poff, pat_info[p.poff], 0, 0);
 						if (t.w0 != en.w0 || t.w1 != en.w1 || t.w2 != en.w2 || t.w3 != en.w3) return -8;
 						Corner8 c8;
 						for (int k = 0; k < 8; k++) c8.a[k] = v[k];
 						uint32_t m8, n8;
 						if (pattern_offset(tab.lut, i, c8, m8, n8) != p.poff) return -9;
+					} else {
+						if (p.zmask && z >= z_emit) en.w3 |= ENTRY_COUNT;
+						pc = entry_c(p);
+						// the stored plan gives the plan back
+						CellPlan q;
+						plan_restore(q, tab.lut, en, pc);
+						plan_restore_points(q, v);
+						if (q.rank != p.rank || q.visited != p.visited || q.created != p.created || q.onpoint != p.onpoint || q.onb != p.onb ||
+						    q.tgt[0] != p.tgt[0] || q.tgt[1] != p.tgt[1] || q.tgt[2] != p.tgt[2] || q.poff != p.poff || q.m != p.m || q.n != p.n ||
+						    q.nnew != p.nnew || q.zmask != p.zmask)
+							return -10;
 					}
-					entries.push_back(en);
-					seg_cnt[s] = seg_pack(voff + p.nnew, toff + nt);
 				}
+				ea.push_back(entry_a(en));
+				eb.push_back((en.w3 & (ENTRY_SLOW | ENTRY_TESTED)) ? entry_b(en) : EntryB{0xDEADBEEFu, 0xDEADBEEFu});
+				ec.push_back(pc);
+				const Entry back = load_entry(ea.data(), eb.data(), fast_b, (uint32_t)(ea.size() - 1));
+				if (back.w0 != en.w0 || back.w1 != en.w1 || back.w2 != en.w2 || back.w3 != en.w3) return -7;  // split / join must be lossless
 				entry_seg.push_back((uint32_t)s);
 				seg_nent[s]++;
 			}
 	for (uint64_t s = 0; s < nsegs; s++)
 		if (seg_nent[s]) seg_dir[s] = make_segdir(seg_first[s], seg_nent[s], &seg_mask[4ull * s]);
+	EmitCtx<T> c;
+	c.tab = tab; c.P = P; c.G = G;
+	c.seg_base = seg_base.data(); c.seg_dir = seg_dir.data();
+	c.entries_a = ea.data(); c.entries_b = eb.data(); c.entries_c = ec.data(); c.fast_b = fast_b; c.entry_seg = entry_seg.data();
+	c.z_emit = z_emit;
+	// pass 2 (k_slow_count): triangles of the slow cells with a corner equal to the isovalue, by vertex identity on the stored
+	// plans - checked against the round-1 formulation that plans every owner on the way (count_triangles)
+	uint64_t keys[13];
+	for (size_t k = 0; k < ea.size(); k++) {
+		if (!(ea[k].a0 & ENTRYA_COUNT)) continue;
+		const Entry en = entry_join(ea[k], eb[k]);
+		CellPlan p;
+		plan_restore(p, tab.lut, en, ec[k]);
+		const SegCoord sc = segment_coord(P, entry_seg[k]);
+		const uint32_t x = sc.xbase + (ea[k].a0 & 0xFFu);
+		RootMemo memo{keys, 1, 0u};
+		const uint32_t nt = count_triangles_stored(c, p, x, sc.y, sc.z, w, memo);
+		if (nt != count_triangles(p, tab, P, G, x, sc.y, sc.z, w)) return -11;
+		ea[k].a0 = (ea[k].a0 & ~(15u << 20) & ~ENTRYA_COUNT) | nt << 20;
+	}
+	// pass 3 (the wave scan of k_cells / k_seg_fix): offsets of the records inside their row segment, segment totals
+	for (uint64_t s = 0; s < nsegs; s++) {
+		uint32_t nv = 0, nt = 0;
+		for (uint32_t k = 0; k < seg_nent[s]; k++) {
+			EntryA &e = ea[seg_first[s] + k];
+			e.a1 = nv | nt << 16;
+			nv += entrya_nnew(e); nt += entrya_ntri(e);
+		}
+		seg_cnt[s] = seg_pack(nv, nt);
+	}
 	// scan in sweep order over records stored in [z][segment][y] order
 	uint64_t nV = 0, nT = 0;
 	for (uint64_t q = 0; q < nsegs; q++) {
@@ -124,28 +171,14 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	out->nV = (uint32_t)nV; out->nT = (uint32_t)nT;
 	out->V = (float *)malloc(nV * 12 + 16); out->N = (float *)malloc(nV * 12 + 16); out->T = (uint32_t *)malloc(nT * 12 + 16);
 	memset(out->T, 0xFF, nT * 12);
-	EmitCtx<T> c;
-	c.tab = tab; c.P = P; c.G = G;
-	c.seg_base = seg_base.data(); c.seg_dir = seg_dir.data();
-	// the records as the kernels store them: half A for all, half B only for slow and tested records (fast ones: from the table)
-	std::vector<EntryA> ea(entries.size());
-	std::vector<EntryB> eb(entries.size(), EntryB{0xDEADBEEFu, 0xDEADBEEFu});
-	EntryB fast_b[256];
-	fast_b_table(fast, fast_b);
-	for (size_t k = 0; k < entries.size(); k++) {
-		ea[k] = entry_a(entries[k]);
-		if (entries[k].w3 & (ENTRY_SLOW | ENTRY_TESTED)) eb[k] = entry_b(entries[k]);
-		const Entry back = load_entry(ea.data(), eb.data(), fast_b, (uint32_t)k);
-		if (back.w0 != entries[k].w0 || back.w1 != entries[k].w1 || back.w2 != entries[k].w2 || back.w3 != entries[k].w3) return -7;  // split / join must be lossless
-	}
-	c.entries_a = ea.data(); c.entries_b = eb.data(); c.fast_b = fast_b; c.entry_seg = entry_seg.data();
 	c.V = out->V; c.N = out->N; c.Tri = out->T;
-	c.z_emit = z_emit; c.v_skip = gV; c.t_skip = gT; c.id_delta = id_base - gV;
-	for (size_t k = 0; k < entries.size(); k++) {
-		if (entries[k].w3 & ENTRY_SLOW) emit_cell(c, (uint32_t)k, v, w, ids);
+	c.v_skip = gV; c.t_skip = gT; c.id_delta = id_base - gV;
+	for (size_t k = 0; k < ea.size(); k++) {
+		if (ea[k].a0 & ENTRYA_SLOW) emit_cell(c, (uint32_t)k, v, w, ids);
 		else {
-			emit_fast_vertices(c, entries[k], entry_seg[k]);
-			emit_fast_triangles(c, entries[k], entry_seg[k], (uint32_t)k, ids);
+			const Entry en = load_entry(ea.data(), eb.data(), fast_b, (uint32_t)k);
+			emit_fast_vertices(c, en, entry_seg[k]);
+			emit_fast_triangles(c, en, entry_seg[k], (uint32_t)k, ids);
 		}
 	}
 	return 0;
