@@ -209,3 +209,56 @@ extern "C" int emu_slab_u16(const uint16_t *data, uint32_t npx, uint32_t npy, ui
 	return rc;
 }
 extern "C" unsigned long long emu_last_violations(void) { return g_violations; }
+
+// Every sign index with `per_index` random sets of corner values (no value 0): the record k_cells makes for an
+// interior cell from the pattern offset + the pattern-info table must be the one the generic plan makes, the tests on
+// register-held values (Corner8) must choose the pattern the tests on a VRef choose, and the stored plan must give the
+// plan back.  Returns the number of (index, values) pairs whose pattern needed tests, or a negative error code;
+// hist[g] counts the patterns by table group (c >> 12).
+extern "C" long emu_check_tested_records(uint32_t seed, uint32_t per_index, unsigned long long *hist /*[8]*/) {
+	Tables tab{mc33_lut, mc33_rule_words, &mc33_rule_index[0][0]};
+	constexpr uint32_t lut_n = sizeof mc33_lut / sizeof mc33_lut[0];
+	static uint32_t pat_info[lut_n];
+	build_pattern_info(mc33_lut, lut_n, pat_info);
+	uint32_t fast[256];
+	build_fast_table(mc33_lut, fast);
+	Params P{};
+	P.nx = P.ny = P.nz = 1u << 20;
+	GridView<float> G{nullptr, 0, 0, 0};
+	uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1;
+	auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 32); };
+	long tested = 0;
+	for (uint32_t i = 1; i < 255; i++)
+		for (uint32_t r = 0; r < per_index; r++) {
+			float vb[8];
+			Corner8 c8;
+			for (int k = 0; k < 8; k++) {
+				// magnitudes over several decades, now and then equal ones (ties in the face tests)
+				const uint32_t q = rnd();
+				float mag = (q & 7u) == 0 ? 1.0f : (float)((q >> 8) % 1000u + 1u) * ((q & 8u) ? 0.001f : 1.0f);
+				vb[k] = ((i >> (7 - k)) & 1) ? -mag : mag;
+				c8.a[k] = vb[k];
+			}
+			CellPlan p;
+			plan_cell(p, tab, P, G, 5, 6, 7, i, VRef{vb, 1});
+			if (!cell_is_tested(p, 5, 6, 7)) return -1;
+			uint32_t m, n;
+			if (pattern_offset(mc33_lut, i, c8, m, n) != p.poff || m != p.m || n != p.n) return -2;
+			const Entry want = make_entry(37, i, p, p.ntri, 11, 13, false), got = make_tested_entry(37, i, p.poff, pat_info[p.poff], 11, 13);
+			if (got.w0 != want.w0 || got.w1 != want.w1 || got.w2 != want.w2 || got.w3 != (want.w3 | ENTRY_TESTED)) return -3;
+			if (fast[i] != FAST_NONE) {
+				const Entry f = make_fast_entry(37, i, fast[i], 11, 13);
+				if (f.w0 != want.w0 || f.w1 != want.w1 || f.w2 != want.w2 || f.w3 != want.w3) return -4;
+			} else
+				tested++;
+			CellPlan q;
+			const Entry slow = make_entry(37, i, p, p.ntri, 11, 13, true);
+			plan_restore(q, mc33_lut, slow, entry_c(p));
+			plan_restore_points(q, VRef{vb, 1});
+			if (q.rank != p.rank || q.visited != p.visited || q.created != p.created || q.onpoint != p.onpoint || q.onb != p.onb || q.tgt[0] != p.tgt[0] ||
+			    q.tgt[1] != p.tgt[1] || q.tgt[2] != p.tgt[2] || q.poff != p.poff || q.m != p.m || q.n != p.n || q.nnew != p.nnew || q.zmask != p.zmask)
+				return -5;
+			hist[mc33_lut[(i & 0x80) ? (i ^ 0xFF) : i] >> 12]++;
+		}
+	return tested;
+}

@@ -70,3 +70,19 @@ def test_z_slabs_reproduce_whole_volume_and_stay_in_window(emus, case, cuts):
         base += s.nV
     assert np.array_equal(np.concatenate(Ts), whole.T)
     assert bits_equal(np.concatenate(Vs), whole.V) and bits_equal(np.concatenate(Ns), whole.N)
+
+
+def test_tested_records_for_every_sign_index(emus):
+    """254 sign indices x 3000 random corner-value sets (ties included): the record `k_cells` builds for an ambiguous
+    interior cell from the pattern offset and the pattern-info table equals the one the generic plan builds; the face /
+    interior tests on register-held values choose the same pattern; fast records equal the plan's; a stored plan
+    (record parts B + C) gives the plan back.  All eight table groups (MC33 cases 3, 4, 6, 7, 10, 12, 13 and the
+    unambiguous ones) are hit."""
+    import ctypes as C
+    lib = emus["f32"].lib
+    lib.emu_check_tested_records.restype = C.c_long
+    lib.emu_check_tested_records.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong)]
+    hist = (C.c_ulonglong * 8)()
+    n = lib.emu_check_tested_records(7, 3000, hist)
+    assert n > 0, "check failed with code %d" % n
+    assert all(h > 0 for h in hist), list(hist)
