@@ -177,6 +177,22 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
 	return u64(__builtin_amdgcn_readlane((uint32_t)v, l), __builtin_amdgcn_readlane((uint32_t)(v >> 32), l));
 }
 
+// Inclusive prefix sum / running maximum over the 64 lanes of a wave by DPP (no LDS round trips): Hillis-Steele inside
+// the rows of 16 lanes (row_shr 1, 2, 4, 8: lanes without a source add 0), then lane 15 of rows 0 and 2 into rows 1 and 3
+// (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31).
+#define MC33_DPP(x, ctrl, rows) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, false)
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
+	x += MC33_DPP(x, 0x111, 0xf); x += MC33_DPP(x, 0x112, 0xf); x += MC33_DPP(x, 0x114, 0xf); x += MC33_DPP(x, 0x118, 0xf);
+	x += MC33_DPP(x, 0x142, 0xa); x += MC33_DPP(x, 0x143, 0xc);
+	return x;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
+	x = max(x, MC33_DPP(x, 0x111, 0xf)); x = max(x, MC33_DPP(x, 0x112, 0xf)); x = max(x, MC33_DPP(x, 0x114, 0xf)); x = max(x, MC33_DPP(x, 0x118, 0xf));
+	x = max(x, MC33_DPP(x, 0x142, 0xa)); x = max(x, MC33_DPP(x, 0x143, 0xc));
+	return x;
+}
+#undef MC33_DPP
+
 // Bit-row layouts.  A wave keeps the sign bits of a sample row of its tile in four 64-bit words (in lane r for row r).
 // With one sample per lane and load (S = 1) bit j of word k is sample x = 64 k + j: the STANDARD layout, the one every
 // other pass and every record in HBM uses.  Narrow samples are loaded several to a dword (S = 2 unsigned short, S = 4
@@ -793,6 +809,7 @@ struct CellsLds {            // per wave
 	uint64_t bits[64][9];    // row r: prev[0..3], cur[0..3] (row 63 of the tile is only ever the row above); the
 	uint64_t act[64][5];     // odd row pitches keep neighbouring rows on different LDS banks
 	uint32_t incl[64], run[64], slowrow[64];
+	uint32_t rowof[64];      // per batch of 64 cells: row + 1 at the position of the row's first cell, 0 elsewhere
 };
 
 // The 8 samples of one cell: {0xFFFFFFFF, 0} if one of them equals the isovalue; else, for a sign index i that needs the
@@ -866,12 +883,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 	}
 	const uint32_t c0 = __popcll(act[0]), c1 = __popcll(act[1]), c2 = __popcll(act[2]);
 	const uint32_t cnt = c0 + c1 + c2 + __popcll(act[3]);
-	uint32_t incl = cnt;  // inclusive prefix of the per-row counts over the lanes
-#pragma unroll
-	for (int dlt = 1; dlt < 64; dlt <<= 1) {
-		const uint32_t t = __shfl_up(incl, dlt);
-		if ((int)lane >= dlt) incl += t;
-	}
+	const uint32_t incl = wave_scan_add(cnt);  // inclusive prefix of the per-row counts over the lanes
 	const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
 	const unsigned long long t_bits = a.trace ? __builtin_amdgcn_s_memrealtime() + (total & 0u) : 0ull;
 	const uint32_t ebase = base.x;
@@ -891,19 +903,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 	const unsigned long long t_rows = a.trace ? __builtin_amdgcn_s_memrealtime() + (first & 0u) : 0ull;
 	const uint64_t sidx0 = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y0;
 
+	uint32_t carry_row = 0;
 	for (uint32_t g0 = 0; g0 < total; g0 += 64u) {  // wave-uniform
 		const uint32_t g = g0 + lane;
 		const bool on = g < total;
-		// row: the first r with incl[r] > g
-		uint32_t lo = 0, hi = 63;
-#pragma unroll
-		for (int step = 0; step < 6; step++) {
-			const uint32_t mid = (lo + hi) >> 1;
-			const bool right = L.incl[mid] <= g;
-			lo = right ? mid + 1 : lo;
-			hi = right ? hi : mid;
-		}
-		const uint32_t r = on ? lo : 62u;  // (row 63 of a tile is never a cell row)
+		// the row of cell g: the rows that begin inside this batch mark the position of their first cell, the cells after
+		// it follow by a running maximum over the lanes (rows come in rising order), and the cells before the first mark
+		// belong to the row the previous batch ended in.  (Round 1: a binary search in the prefix sums, six dependent LDS reads)
+		L.rowof[lane] = 0u;
+		if (cnt && incl - cnt >= g0 && incl - cnt < g0 + 64u) L.rowof[incl - cnt - g0] = lane + 1u;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the marks of the other lanes: not a value this thread could know)
+		const uint32_t mark = wave_scan_max(L.rowof[lane]);
+		const uint32_t r = on ? (mark ? mark - 1u : carry_row) : 62u;  // (row 63 of a tile is never a cell row)
+		carry_row = __builtin_amdgcn_readlane(r, 63);
 		const uint64_t a0 = L.act[r][0], a1 = L.act[r][1], a2 = L.act[r][2], a3 = L.act[r][3];
 		const uint32_t p0 = __popcll(a0), p1 = p0 + __popcll(a1), p2 = p1 + __popcll(a2), rowcnt = p2 + __popcll(a3);
 		const uint32_t kin = on ? g - (L.incl[r] - rowcnt) : 0u;  // position of the cell among the cells of its row
@@ -950,14 +962,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 		// new vertices | triangles << 16
 		const uint32_t val = fastcell ? ((f.w & 0xFFu) | (f.w >> 8) << 16) : tested ? (((tinfo >> 20) & 15u) | ((tinfo >> 16) & 15u) << 16) : 0u;
 		// offsets inside the row segment: exclusive scan over the cells of the same row
-		uint32_t sc = val;
-#pragma unroll
-		for (int dlt = 1; dlt < 64; dlt <<= 1) {
-			const uint32_t t = __shfl_up(sc, dlt);
-			if ((int)lane >= dlt) sc += t;
-		}
-		const uint32_t head = lane - min(lane, kin);  // lane of the first cell of my row inside this batch
-		const uint32_t before_head = __shfl(sc, head) - __shfl(val, head);
+		const uint32_t sc = wave_scan_add(val);
+		// ... minus the scan value before the first cell of my row inside this batch: both halves of the packed sums only
+		// grow along the lanes, so that is the running maximum of the values at the row heads (0 when my row began earlier)
+		const uint32_t before_head = wave_scan_max(on && kin == 0u ? sc - val : 0u);
 		const uint32_t carry = kin > lane ? L.run[r] : 0u;  // the row began in an earlier batch
 		const uint32_t off = carry + (sc - val) - before_head;
 		{  // the slow cells of the batch go on the list of the slot's group, one atomic per wave
