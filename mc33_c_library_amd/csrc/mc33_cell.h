@@ -181,9 +181,12 @@ struct Corner8 {
 };
 MC33_HD real_t corner_value(const VRef &v, int s) { return v[s]; }
 MC33_HD real_t corner_value(const Corner8 &v, int s) {
-	real_t r = v.a[0];
-	for (int k = 1; k < 8; k++) r = s == k ? v.a[k] : r;
-	return r;
+	// (copies first: `c ? v.a[3] : v.a[2]` selects between two lvalues, i.e. between two ADDRESSES, and the load through the
+	// selected address is what keeps the values out of registers)
+	const real_t a0 = v.a[0], a1 = v.a[1], a2 = v.a[2], a3 = v.a[3], a4 = v.a[4], a5 = v.a[5], a6 = v.a[6], a7 = v.a[7];
+	const real_t lo = (s & 2) ? ((s & 1) ? a3 : a2) : ((s & 1) ? a1 : a0);
+	const real_t hi = (s & 2) ? ((s & 1) ? a7 : a6) : ((s & 1) ? a5 : a4);
+	return (s & 4) ? hi : lo;
 }
 
 template <typename V>
@@ -196,6 +199,14 @@ MC33_HD bool face_less(int f, const V &v) {
 	case 4: return v[0] * v[2] < v[1] * v[3];
 	default: return v[4] * v[6] < v[5] * v[7];
 	}
+}
+// (register-held values: all six comparisons with static indices, the face picks its bit - a run-time face number must not
+// become an index into the values, which would move them to scratch memory)
+MC33_HD bool face_less(int f, const Corner8 &v) {
+	const uint32_t bits = (uint32_t)(v.a[0] * v.a[5] < v.a[1] * v.a[4]) | (uint32_t)(v.a[1] * v.a[6] < v.a[2] * v.a[5]) << 1 |
+	                      (uint32_t)(v.a[3] * v.a[6] < v.a[2] * v.a[7]) << 2 | (uint32_t)(v.a[0] * v.a[7] < v.a[3] * v.a[4]) << 3 |
+	                      (uint32_t)(v.a[0] * v.a[2] < v.a[1] * v.a[3]) << 4 | (uint32_t)(v.a[4] * v.a[6] < v.a[5] * v.a[7]) << 5;
+	return (bits >> f) & 1u;
 }
 // per face f (byte f): index mask, the diagonal through v0 (faces 0,3,4) / v6 (faces 1,2,5), the other one
 MC33_HD uint32_t face_mask(int f) { return (uint32_t)(0x0FF0993366CCull >> (8 * f)) & 0xFFu; }
@@ -342,9 +353,17 @@ MC33_HD uint32_t plan_rank(const CellPlan &p, uint32_t e) { return (uint32_t)(p.
 MC33_HD void plan_set_rank(CellPlan &p, uint32_t e, uint32_t r) {
 	p.rank = (p.rank & ~(15ull << (4 * e))) | ((uint64_t)r << (4 * e));
 }
-MC33_HD uint32_t plan_tgt(const CellPlan &p, uint32_t e) { return (p.tgt[e >> 2] >> (8 * (e & 3))) & 0xFFu; }
+// (the word is picked by selects, not by an index: a run-time index into the three words would put the plan in scratch memory)
+MC33_HD uint32_t tgt_byte(const uint32_t *tgt /*[3]*/, uint32_t e) {
+	const uint32_t w = e < 4u ? tgt[0] : e < 8u ? tgt[1] : tgt[2];
+	return (w >> (8 * (e & 3))) & 0xFFu;
+}
+MC33_HD uint32_t plan_tgt(const CellPlan &p, uint32_t e) { return tgt_byte(p.tgt, e); }
 MC33_HD void plan_set_tgt(CellPlan &p, uint32_t e, uint32_t t) {
-	p.tgt[e >> 2] = (p.tgt[e >> 2] & ~(0xFFu << (8 * (e & 3)))) | (t << (8 * (e & 3)));
+	const uint32_t sh = 8 * (e & 3), keep = ~(0xFFu << sh), put = t << sh;
+	p.tgt[0] = e < 4u ? (p.tgt[0] & keep) | put : p.tgt[0];
+	p.tgt[1] = (e >= 4u && e < 8u) ? (p.tgt[1] & keep) | put : p.tgt[1];
+	p.tgt[2] = e >= 8u ? (p.tgt[2] & keep) | put : p.tgt[2];
 }
 MC33_HD uint32_t make_tgt(uint32_t axis, int dx, int dy, int dz) {
 	return axis | (uint32_t)(dx + 1) << 2 | (uint32_t)(dy + 1) << 4 | (uint32_t)(dz + 1) << 6;
@@ -943,7 +962,7 @@ MC33_HD RootRef chase_root(const EmitCtx<T> &c, GridEdge g, const VRef &w) {
 		if (!(ea.a0 & ENTRYA_SLOW)) return none;  // a fast or tested cell creates the vertices of its cut edges itself: the edge is not in its pattern
 		const EntryC pc = c.entries_c[ri];
 		if (!(pc.masks & (1u << o.e))) return none;  // (owned edges are 0..11)
-		g = tgt_edge((pc.tgt[o.e >> 2] >> (8 * (o.e & 3))) & 0xFFu, o.x, o.y, o.z);
+		g = tgt_edge(tgt_byte(pc.tgt, o.e), o.x, o.y, o.z);
 	}
 	return none;
 }
