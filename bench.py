@@ -13,7 +13,8 @@ resident in HBM, outputs left in HBM.
   --config c3 (default; BASELINE.json configs[2] / configs[3]): `cos x + cos y + cos z` float grid, iso 0.
         N = 1: 1024^3 points (4 GiB).  N > 1: weak scaling, 1024 x 1024 x (1024 N) points, one 1024^3-point z-slab
         per GPU (+ ghost planes); per step every rank extracts its slab, the ranks exchange their counts, rebase the
-        ids and exchange the surface arrays over RCCL (--gather).
+        ids and exchange the surface arrays over RCCL (--gather).  --strong: the ONE 1024^3 grid in N z-slabs instead
+        (configs[3] read literally: 128 slices per GPU at N = 8, the exchange then outweighs the extraction).
   --config c5 (BASELINE.json configs[4]): 2048 x 2048 x 1024 unsigned short grid (8 GiB), ONE resident grid,
         a step = the sweep over the 8 isovalues 15268.5 + 5000 k; z-slabs over the N GPUs (strong scaling: the grid
         is fixed).
@@ -42,6 +43,8 @@ def parse():
     ap.add_argument("--config", choices=("c3", "c5"), default=os.environ.get("MC33_BENCH_CONFIG", "c3"))
     ap.add_argument("--points", type=int, default=int(os.environ.get("MC33_BENCH_POINTS", "0")),
                     help="points per axis of a GPU's slab (c3, default 1024) / points along z of the whole grid, x and y twice that (c5, default 1024)")
+    ap.add_argument("--strong", action="store_true", default=os.environ.get("MC33_BENCH_STRONG", "0") == "1",
+                    help="c3 with N > 1: strong scaling (the one 1024^3 grid in N z-slabs) instead of one 1024^3 slab per GPU")
     ap.add_argument("--gather", choices=("allgather", "pairs", "root"), default=os.environ.get("MC33_BENCH_GATHER", "allgather"),
                     help="how the ranks exchange the surface arrays (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true", default=os.environ.get("MC33_BENCH_NO_CPU", "0") == "1")
@@ -191,12 +194,17 @@ def main():
         lo, h = -4.0, 8.0 / (n - 1)
         r0, dd = (lo, lo, lo), (h, h, h)
         npx = npy = n
-        nz_total = n * world - 1                  # cell slices of the whole volume: weak scaling, n planes per rank
-        slab = Slab(rank, world, nz_total, per=n)
+        if args.strong and world > 1:             # configs[3] read literally: ONE n^3 grid cut into `world` z-slabs
+            nz_total = n - 1
+            slab = Slab(rank, world, nz_total)
+            scaling, nzp_all = "strong", n
+        else:                                     # default: weak scaling, n planes per rank (the per-GPU work of the N = 1 line)
+            nz_total = n * world - 1              # cell slices of the whole volume
+            slab = Slab(rank, world, nz_total, per=n)
+            scaling, nzp_all = "weak", n * world
         field = cos_field_slab(n, slab.planes, h, lo, dev, z_first=slab.p_lo)
-        scaling = "weak"
         workload = ("%dx%dx%d-point float grid cos x+cos y+cos z on h=8/%d, iso=0.0, calculate_isosurface (sweep+scan+emit), "
-                    "grid and outputs resident in HBM" % (n, n, n * world, n - 1))
+                    "grid and outputs resident in HBM" % (n, n, nzp_all, n - 1))
     else:
         nzp = args.points or 1024
         dtype, sample_bytes = "u16", 2

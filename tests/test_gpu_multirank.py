@@ -65,6 +65,21 @@ def test_bench_self_launch_c3_rehearsal(launcher, reflibs, tmp_path, gather):
     assert np.array_equal(got["N"].view(np.uint32), ref.N.view(np.uint32))
 
 
+def test_bench_self_launch_c3_strong_scaling(launcher, reflibs, tmp_path):
+    """`--strong`: BASELINE configs[3] read literally - ONE n^3 grid cut into z-slabs over the ranks (here 3 ranks, 26 / 27 / 26
+    slices) - against oracle/_ref on the whole grid."""
+    dump = str(tmp_path / "surf.npz")
+    n = 80
+    res, out = bench(launcher, ["--gpus", "3", "--steps", "2", "--warmup", "1", "--points", str(n), "--gather", "root", "--strong"], {"MC33_BENCH_DUMP": dump})
+    assert res["n_gpus"] == 3 and res["scaling"] == "strong" and "equals whole-volume result: True" in out["stderr"]
+    data, r0, d = fx.cos_field(n)
+    ref = reflibs["f32"].isosurface(data, 0.0, r0, d)
+    got = np.load(dump)
+    assert res["config"]["vertices"] == ref.nV and res["config"]["triangles"] == ref.nT
+    assert np.array_equal(got["T"], ref.T) and np.array_equal(got["V"].view(np.uint32), ref.V.view(np.uint32))
+    assert np.array_equal(got["N"].view(np.uint32), ref.N.view(np.uint32))
+
+
 def test_bench_self_launch_c5_rehearsal(launcher, reflibs, tmp_path):
     """The ushort / 8-isovalue config on 3 rank processes (strong scaling: one grid cut into z-slabs)."""
     dump = str(tmp_path / "surf.npz")
