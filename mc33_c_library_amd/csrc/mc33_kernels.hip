@@ -34,6 +34,8 @@
 #include <cstring>
 #include <mutex>
 #include <algorithm>
+#include <cmath>
+#include <limits>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -44,6 +46,8 @@
 #endif
 #if !defined(MC33_GRD_U8) && !defined(MC33_GRD_U16) && !defined(MC33_GRD_U32)
 #define MC33_NAN_SAMPLES 1  // float / double grids may hold NaN samples
+#else
+#define MC33_INT_SAMPLES 1  // unsigned integer samples: no NaN, no signed zero (k_sweep's ZM)
 #endif
 #include "mc33_cell.h"
 #include "mc33_lut_data.h"
@@ -377,7 +381,13 @@ constexpr int SWEEP_PACK = 1;
 // S: samples per lane and load.  S = 1: every lane loads single samples (all types); S = SWEEP_PACK > 1: dwords of 2
 // unsigned shorts / 4 unsigned chars - needs rows that start on a dword boundary (the host checks), and makes a batch
 // 8 / 16 sample rows instead of 4, so that a wave keeps the same 16 x 256 bytes in flight.
-template <int S, int NI>
+// ZM: how a sample is classified.  0: d = iso - F, its sign bit and d == 0, exactly as the reference writes it (float and
+// double samples - NaN samples, signed zeros - and the isovalue -0.0).  Integer samples (MC33_INT_SAMPLES) otherwise: the
+// sign bit of iso - F is F > iso and iso - F == 0 is F == iso (both converted to MC33_real as the reference does), so the
+// subtraction, the |d| and the running minimum go: 1: one compare for the sign, one for "equals the isovalue"; 2: no
+// isovalue of the pass is an integer of the sample type's range - nothing can equal it, one compare per sample and isovalue
+// (the 4-isovalue pass over ushort samples is bound by its instructions: 94 -> 58 per sample row).
+template <int S, int NI, int ZM = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_sweep(const SweepArgs a) {  // (3 waves per SIMD: at most 168 VGPRs - the 4-lane form sits right at that edge)
 	constexpr int LPR = 4 / S;    // loads per sample row
 	constexpr int RB = 16 / LPR;  // sample rows per batch
@@ -428,7 +438,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	uint64_t cur_zc[NI], prev_zc[PREV_LDS ? 1 : NI], zcacc[NI];  // ... and the lanes that loaded one
 	uint64_t cur_z[NI], prev_z[PREV_LDS ? 1 : NI], zacc[NI];  // sample rows of the plane that hold a sample equal to the isovalue (wave-uniform),
 	                                           // to the batch of RB rows: one compare per batch, not per row
-	real_t zmin[NI];  // min |iso - F| over the lane's samples of the batch being processed
+	real_t zmin[NI];  // min |iso - F| over the lane's samples of the batch being processed (ZM = 0)
+	uint64_t zeq[NI]; // lanes that loaded a sample equal to the isovalue in the batch being processed (ZM = 1; wave-uniform)
 	bool cur_written[NI], prev_written[NI];  // the plane's bit rows are already in slice_bits
 	real_t iso[NI];
 #pragma unroll
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 		}
 		cur_h[q] = prev_h[q] = 0; cur_z[q] = zacc[q] = 0; cur_zc[q] = zcacc[q] = 0;
 		if constexpr (PREV_LDS) { s_prevz[q][0][wv] = 0; s_prevz[q][1][wv] = 0; } else { prev_z[q] = 0; prev_zc[q] = 0; }
-		cur_written[q] = prev_written[q] = false; zmin[q] = 1;
+		cur_written[q] = prev_written[q] = false; zmin[q] = 1; zeq[q] = 0;
 		iso[q] = a.lane[q].iso;
 	}
 
@@ -511,13 +522,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 				uint32_t m[8];
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
-					const real_t d = iso[q] - f[k];                           // MC:1852-1855
-					uint64_t bb = __ballot(sign_of(d) != 0);                  // MC:1856-1859 (sign bit)
+					uint64_t bb;
+					if constexpr (ZM == 0) {
+						const real_t d = iso[q] - f[k];                       // MC:1852-1855
+						bb = __ballot(sign_of(d) != 0);                       // MC:1856-1859 (sign bit)
 #ifdef MC33_NAN_SAMPLES
-					bb ^= __ballot(d != d);  // NaN sample: the sign the reference sees is the NaN's own (see iso_diff)
+						bb ^= __ballot(d != d);  // NaN sample: the sign the reference sees is the NaN's own (see iso_diff)
 #endif
+						zmin[q] = real_min(zmin[q], real_abs(d));
+					} else {
+						bb = __ballot(f[k] > iso[q]);                         // = the sign bit of iso - F for an integer sample
+						if constexpr (ZM == 1) zeq[q] |= __ballot(f[k] == iso[q]);
+					}
 					m[2 * k] = (uint32_t)bb; m[2 * k + 1] = (uint32_t)(bb >> 32);
-					zmin[q] = real_min(zmin[q], real_abs(d));
 				}
 				// park the bit row of sample row r+rr in lane r+rr: v_writelane takes its lane select from M0
 				// when the data operand is an SGPR too (one SGPR per VOP3 on gfx9-class encodings)
@@ -534,9 +551,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 		}
 #pragma unroll
 		for (int q = 0; q < NI; q++) {  // a sample of these RB rows equals the isovalue: mark the rows
-			const uint64_t zb = __ballot(zmin[q] == 0);
+			if constexpr (ZM == 2) continue;
+			const uint64_t zb = ZM == 0 ? __ballot(zmin[q] == 0) : zeq[q];
 			if (zb) { zacc[q] |= ((1ull << RB) - 1ull) << r; zcacc[q] |= zb; }
-			zmin[q] = 1;
+			zmin[q] = 1; zeq[q] = 0;
 		}
 		if (bi != NB - 1) return;
 		// ---- the plane is complete ----
@@ -1965,11 +1983,29 @@ static bool sweep_packed(const mc33hip_ctx *c) {
 }
 
 // one k_sweep launch over NI = 1, 2 or 4 lanes that begin_lane has prepared
+template <int NI, int ZM>
+static void launch_sweep_zm(mc33hip_ctx *c, const SweepArgs &a, hipStream_t st) {
+	const uint64_t blocks = (c->ntiles + 3) / 4;
+	if (sweep_packed(c)) hipLaunchKernelGGL((k_sweep<SWEEP_PACK, NI, ZM>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
+	else hipLaunchKernelGGL((k_sweep<1, NI, ZM>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
+}
 template <int NI>
 static void launch_sweep_ni(mc33hip_ctx *c, const SweepArgs &a, hipStream_t st) {
-	const uint64_t blocks = (c->ntiles + 3) / 4;
-	if (sweep_packed(c)) hipLaunchKernelGGL((k_sweep<SWEEP_PACK, NI>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
-	else hipLaunchKernelGGL((k_sweep<1, NI>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
+#ifdef MC33_INT_SAMPLES
+	// which classification the isovalues of this pass allow (k_sweep's ZM)
+	bool negzero = false, can_equal = false;
+	for (int q = 0; q < NI; q++) {
+		const real_t iso = a.lane[q].iso;
+		negzero |= iso == 0 && sign_of(iso);
+		can_equal |= iso >= 0 && iso <= (real_t)std::numeric_limits<sample_t>::max() && iso == std::floor(iso);
+	}
+	if (!negzero && !env_u32("MC33_HIP_SWEEP_SUBTRACT", 0)) {
+		if (can_equal) launch_sweep_zm<NI, 1>(c, a, st);
+		else launch_sweep_zm<NI, 2>(c, a, st);
+		return;
+	}
+#endif
+	launch_sweep_zm<NI, 0>(c, a, st);
 }
 
 // everything after the sweep for the slices lane L holds: tile boundaries, record ranges, cell records, slow-cell
