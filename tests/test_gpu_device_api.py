@@ -129,7 +129,7 @@ def test_one_context_many_extractions_of_different_extent(reflibs):
             g2.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "u16", "u8"])
+@pytest.mark.parametrize("dtype", ["f32", "u16", "u16mix", "u8"])
 def test_sweep_many_equals_single_sweeps(reflibs, dtype):
     """mc33hip_sweep_many classifies up to 8 isovalues per pass over the grid (4 per kernel launch); the extractions
     that follow must be exactly what they are without it - and the reference's.  Odd counts (4 + 2 + 1 lanes), a slab with
@@ -138,8 +138,10 @@ def test_sweep_many_equals_single_sweeps(reflibs, dtype):
     from mc33_c_library_amd import DeviceGrid, Range
     if dtype == "f32":
         data, isos = fx.noise_quant(0, 3, shape=(40, 70, 300)), [0.0, 1.0, -1.0, 0.5, 1.5, -0.5, 2.0]
-    elif dtype == "u16":
+    elif dtype == "u16":   # half-integer isovalues: no sample can equal one (k_sweep classifies with one compare per sample)
         data, isos = fx.cos_field_u16(300, 130, 50), [15268.5 + 5000.0 * k for k in range(8)]
+    elif dtype == "u16mix":  # integer isovalues (samples equal to them), half-integer ones, one above and one below the type's range
+        data, isos, dtype = fx.cos_field_u16(300, 130, 50), [25268.0, 15268.5, 32768.0, 70000.0, -5.0, 40000.0], "u16"
     else:
         data, isos = fx.noise_u8(0, 4, 5, shape=(30, 66, 258)), [2.0, 1.5, 3.0]
     t = torch.from_numpy(data).cuda()

@@ -159,6 +159,20 @@ def test_noisy_smooth_field(products, reflibs, dtype):
         assert got.nT > 100000
 
 
+def test_negative_zero_isovalue_on_integer_grid(products, reflibs):
+    """iso = -0.0 on an unsigned grid holding zeros: `iso - F` is -0.0 at F = 0 (sign bit set, like every F > 0) although
+    F > iso is false there - the reference finds NO cut cell, a sweep that classified by the compare would draw a surface
+    around the zeros.  The sweep falls back from its compare form to the subtraction for this isovalue (k_sweep's ZM = 0)."""
+    data = fx.noise_u8(0, 4, 5, shape=(30, 66, 258))
+    data = (data - data.min()).astype(np.uint8)
+    assert (data == 0).sum() > 1000
+    for dtype, arr in (("u8", data), ("u16", data.astype(np.uint16) * 257)):
+        want = reflibs[dtype].isosurface(arr, -0.0)
+        got = products[dtype].isosurface(arr, -0.0)
+        assert (want.nV, want.nT) == (0, 0) and (got.nV, got.nT) == (0, 0), dtype
+        assert check(products, reflibs, dtype, arr, 0.0, label=dtype + " +0.0").nV > 1000
+
+
 def test_negative_zero_isovalue_is_deterministic(products, reflibs):
     """iso = -0.0 on a grid holding zeros: the reference's own result depends on what earlier slices and earlier calls
     left in its id caches, so only what IS a function of the input is pinned: the product returns one
