@@ -821,13 +821,17 @@ struct CellsArgs {
 
 // n-th (0-based) set bit of w; n < popcount(w)
 __device__ __forceinline__ uint32_t nth_set_bit(uint64_t w, uint32_t n) {
-	uint32_t pos = 0;
+	// the half first, then five halving steps on 32 bits
+	const uint32_t lo = (uint32_t)w, clo = (uint32_t)__popc(lo);
+	const bool hi = n >= clo;
+	n -= hi ? clo : 0u;
+	uint32_t v = hi ? (uint32_t)(w >> 32) : lo, pos = hi ? 32u : 0u;
 #pragma unroll
-	for (int width = 32; width; width >>= 1) {
-		const uint32_t c = (uint32_t)__popcll(w & ((1ull << width) - 1ull));
+	for (int width = 16; width; width >>= 1) {
+		const uint32_t c = (uint32_t)__popc(v & ((1u << width) - 1u));
 		const bool up = n >= c;
 		n -= up ? c : 0u;
-		w = up ? w >> width : w;
+		v = up ? v >> width : v;
 		pos += up ? (uint32_t)width : 0u;
 	}
 	return pos;
@@ -922,6 +926,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 	const uint64_t zr = u64(h.zr_lo, h.zr_hi);  // sample rows with a sample equal to the isovalue: the cells of rows r - 1 and r
 #pragma unroll
 	for (int k = 0; k < 4; k++) { L.bits[lane][k] = prev[k]; L.bits[lane][4 + k] = cur[k]; L.act[lane][k] = act[k]; }
+	L.bits[lane][8] = (bc >> lane) & 1ull;  // the halo-column bit of the upper plane's row: the bit after its last word
 	L.incl[lane] = incl;
 	L.run[lane] = 0;
 	// bit 0: no cell of the row can take the fast path (grid faces); bit 2: a corner may equal the isovalue - the cell's
@@ -951,17 +956,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 		const uint64_t aw = wsel == 0 ? a0 : wsel == 1 ? a1 : wsel == 2 ? a2 : a3;
 		const uint32_t xl = 64u * wsel + (on ? nth_set_bit(aw, kin - (wsel == 0 ? 0u : wsel == 1 ? p0 : wsel == 2 ? p1 : p2)) : 0u);
 		// the 8 corner bits: sample x and x+1 of rows r, r+1 on the two planes
-		const uint32_t w0 = xl >> 6, b0 = xl & 63u, w1 = min(w0 + 1u, 3u);
-		const bool wrap = b0 == 63u;  // x+1 is bit 0 of the next word, or the halo column after the last word
+		// (the bit rows as dwords: dword 2 w + h of a plane's row holds the bits 32 h .. 32 h + 31 of word w; the two bits are
+		// taken from the 64-bit window that begins at the dword of x - the dword after the prev plane's last one is replaced
+		// by the halo bit, the one after the cur plane's last one IS the halo bit: bits[r][8], set above)
+		const uint32_t didx = xl >> 5, bit = xl & 31u;
 		uint32_t i = 0;
 #pragma unroll
 		for (int c = 0; c < 4; c++) {  // c: 0 = (row r, prev) 1 = (row r+1, prev) 2 = (row r+1, cur) 3 = (row r, cur): corners 0..3, MC:1846-1859
 			const uint32_t rr = r + ((c == 1 || c == 2) ? 1u : 0u), pl = (c >= 2) ? 4u : 0u;
-			const uint64_t W = L.bits[rr][pl + w0], Wn = L.bits[rr][pl + w1];
-			const uint32_t halo = (uint32_t)(((pl ? bc : bp) >> rr) & 1ull);
-			const uint32_t here = (uint32_t)(W >> b0) & 1u;
-			const uint32_t next = wrap ? (w0 < 3u ? (uint32_t)Wn & 1u : halo) : (uint32_t)(W >> (b0 + 1u)) & 1u;
-			i |= here << (7 - c) | next << (3 - c);
+			const uint32_t *rowp = (const uint32_t *)&L.bits[rr][pl];
+			const uint32_t w32 = rowp[didx];
+			uint32_t n32 = rowp[didx + 1u];
+			if (c < 2) n32 = didx == 7u ? (uint32_t)(bp >> rr) & 1u : n32;
+			const uint32_t t = __builtin_amdgcn_alignbit(n32, w32, bit);
+			i |= (t & 1u) << (7 - c) | ((t >> 1) & 1u) << (3 - c);
 		}
 		const uint4 f = s_fast[i];
 		const uint32_t rowflag = L.slowrow[r];
