@@ -131,6 +131,7 @@ struct SweepLane {
 	                         // rows.  A plane is written once, by the first slice with cut cells that touches it: writes are
 	                         // what the sweep pays for (100 MB of them cost as much as 600 MB of reads), and consecutive slices
 	                         // share a plane
+	uint8_t *plane_fmt;      // [slice_slot of the PLANE]: PLANE_COMPACT / PLANE_RAW - how its record in slice_bits is written (store_plane)
 	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: rows << 32 | cells of the slices of that chunk
 	uint4 *edge_bits;        // [tile * 2 + (0 bottom | 1 top)][2][lane]: bit rows of the tile's first / last plane
 	uint4 *edge_hdr;         // ... their halo-column bits and "a sample equals the isovalue" flag
@@ -313,14 +314,62 @@ __device__ __forceinline__ void valid_masks(uint32_t xbase, uint32_t nx, uint64_
 // A slice with cut cells is handed to k_cells: its bit rows (4 KiB), the halo-column bits, flags and counts; the
 // counts also go into the partial sum of the slot's chunk (k_slots).  prev / cur: bit rows of planes z / z+1, lane =
 // sample row; bp / bc: ballots of the halo-column bits.  Wave-uniform call.
-__device__ __forceinline__ void store_plane_bits(const SweepLane &a, uint64_t plane_slot, const uint64_t (&w)[4]) {
-	uint4 *bits = a.slice_bits + plane_slot * 128u + (threadIdx.x & 63u);
-	bits[0] = uint4{(uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32)};
-	bits[64] = uint4{(uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32)};
+// The record of a plane in slice_bits.  A bit row of a smooth field changes its value once or twice along its 256
+// samples: a row with at most two changes is ONE dword - bit 0: the first sample's bit, bits 1-2: number of changes,
+// bytes 1-2: their positions p (bits p and p + 1 differ) - and when all 64 rows of a plane are such rows the record is
+// 256 bytes (dword r = row r) instead of 2 KiB (PLANE_COMPACT; k_cells rebuilds the words).  The hand-over is what the sweep
+// pays for beyond its reads, by the byte: 68 MB at C3, 1.08 GB per 4-isovalue pass at C5 before this.
+constexpr uint32_t PLANE_RAW = 0u, PLANE_COMPACT = 1u;
+__device__ __forceinline__ void decode_row(uint32_t desc, uint64_t (&w)[4]) {
+	const uint64_t base = (desc & 1u) ? ~0ull : 0ull;
+	const uint32_t n = (desc >> 1) & 3u;
+#pragma unroll
+	for (int k = 0; k < 4; k++) w[k] = base;
+#pragma unroll
+	for (int j = 0; j < 2; j++) {
+		const int p = (int)((desc >> (8 + 8 * j)) & 0xFFu);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {  // every bit after position p changes sides
+			const int first = p + 1 - 64 * k;
+			const uint64_t m = first <= 0 ? ~0ull : first >= 64 ? 0ull : ~0ull << first;
+			w[k] ^= (uint32_t)j < n ? m : 0ull;
+		}
+	}
+}
+// (w: the plane's bit rows in layout S, lane = sample row; wave-uniform call.  The changes of a row are found in the layout
+// the sweep works in - bit j of word m is sample x = 64 m + j | 128 (m >> 1) + 2 j + (m & 1) | 4 j + m for S = 1 | 2 | 4 - so a
+// compact plane is never converted to the standard layout at all)
+template <int S>
+__device__ __forceinline__ void store_plane(const SweepLane &a, uint64_t plane_slot, const uint64_t (&w)[4]) {
+	const uint32_t lane = threadIdx.x & 63u;
+	uint64_t nx[4], t[4];
+	succ_words<S>(w, w[3] >> 63, nx);  // (the sample after the last one: itself - no change there)
+#pragma unroll
+	for (int k = 0; k < 4; k++) t[k] = w[k] ^ nx[k];
+	const uint32_t n = (uint32_t)(__popcll(t[0]) + __popcll(t[1]) + __popcll(t[2]) + __popcll(t[3]));
+	const bool compact = __ballot(n > 2u) == 0ull;
+	if (compact) {
+		// at most two changes: the lowest bit of the first word that has one and the highest bit of the last such word
+		const uint32_t m1 = t[0] ? 0u : t[1] ? 1u : t[2] ? 2u : 3u, m2 = t[3] ? 3u : t[2] ? 2u : t[1] ? 1u : 0u;
+		const uint64_t t1 = t[0] ? t[0] : t[1] ? t[1] : t[2] ? t[2] : t[3], t2 = t[3] ? t[3] : t[2] ? t[2] : t[1] ? t[1] : t[0];
+		const uint32_t b1 = t1 ? (uint32_t)__builtin_ctzll(t1) : 0u, b2 = t2 ? 63u - (uint32_t)__builtin_clzll(t2) : 0u;
+		const uint32_t p1 = S == 1 ? 64u * m1 + b1 : S == 2 ? 128u * (m1 >> 1) + 2u * b1 + (m1 & 1u) : 4u * b1 + m1;
+		const uint32_t p2 = S == 1 ? 64u * m2 + b2 : S == 2 ? 128u * (m2 >> 1) + 2u * b2 + (m2 & 1u) : 4u * b2 + m2;
+		const uint32_t desc = (uint32_t)(w[0] & 1ull) | n << 1 | p1 << 8 | p2 << 16;
+		((uint32_t *)(a.slice_bits + plane_slot * 128u))[lane] = desc;
+	} else {
+		uint64_t o[4];
+		to_standard<S>(w, o);
+		uint4 *bits = a.slice_bits + plane_slot * 128u + lane;
+		bits[0] = uint4{(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)};
+		bits[64] = uint4{(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)};
+	}
+	if (lane == 0) a.plane_fmt[plane_slot] = (uint8_t)(compact ? PLANE_COMPACT : PLANE_RAW);
 }
 
 // (slot: of the slice; slot_up: of the slice above = the slot of the upper plane; write_prev / write_cur: the
 // plane has not been written by this wave yet)
+template <int S>
 __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slot, uint64_t slot_up, const uint64_t (&prev)[4],
                                                 const uint64_t (&cur)[4], bool write_prev, bool write_cur, uint64_t bp, uint64_t bc,
                                                 uint64_t zrows, uint64_t zcols, const uint64_t (&act)[4], uint32_t dev = 0) {
@@ -328,8 +377,8 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 #ifdef MC33_DEV  // MC33_HIP_DEBUG 32: no bit-plane stores, no header; 128: the bit-plane stores alone (the later passes see nothing)
 	if (dev & 32u) { write_prev = write_cur = false; }
 #endif
-	if (write_prev) store_plane_bits(a, slot, prev);
-	if (write_cur) store_plane_bits(a, slot_up, cur);
+	if (write_prev) store_plane<S>(a, slot, prev);  // (prev, cur: layout S)
+	if (write_cur) store_plane<S>(a, slot_up, cur);
 #ifdef MC33_DEV
 	if (dev & (32u | 128u)) return;
 #endif
@@ -597,14 +646,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 					}
 					active_cells<S>(pq, cur[q], prev_h[q], cur_h[q], valid, rowvalid, act);
 					if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(MC33_DEBUG_BITS(a) & 16u)) {  // wave-uniform: hand the slice to k_cells
-						uint64_t ps[4], cs[4];  // (the counts only need popcounts of act: any layout)
 						uint64_t pz, pzc;
 						if constexpr (PREV_LDS) { pz = s_prevz[q][0][wv]; pzc = s_prevz[q][1][wv]; } else { pz = prev_z[q]; pzc = prev_zc[q]; }
-						to_standard<S>(pq, ps);
-						to_standard<S>(cur[q], cs);
-						hand_over_slice(L, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), ps, cs,
-						                !prev_written[q], true, __ballot(prev_h[q] != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act,
-						                MC33_DEBUG_BITS(a));
+						hand_over_slice<S>(L, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), pq, cur[q],
+						                   !prev_written[q], true, __ballot(prev_h[q] != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act,
+						                   MC33_DEBUG_BITS(a));
 						cur_written[q] = true;
 					}
 				}
@@ -670,7 +716,7 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 	active_cells(prev, cur, (uint32_t)((bp >> lane) & 1ull), (uint32_t)((bc >> lane) & 1ull), valid, rowvalid, act);
 	if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull))
 		// (the two tiles may have written these planes for slices of their own: same bytes again)
-		hand_over_slice(L, slice_slot(b.z - P.zs, b.yt, seg, a.nYT, a.nseg_pad), slice_slot(b.z + 1u - P.zs, b.yt, seg, a.nYT, a.nseg_pad), prev, cur,
+		hand_over_slice<1>(L, slice_slot(b.z - P.zs, b.yt, seg, a.nYT, a.nseg_pad), slice_slot(b.z + 1u - P.zs, b.yt, seg, a.nYT, a.nseg_pad), prev, cur,
 		                true, true, bp, bc, u64(hp.z, hp.w) | u64(hc.z, hc.w), u64(zp.x, zp.y) | u64(zc.x, zc.y), act);
 }
 
@@ -803,6 +849,7 @@ struct CellsArgs {
 	uint32_t ze, nYT, nseg_pad;
 	const SliceHeader *slice_hdr;
 	const uint4 *slice_bits;
+	const uint8_t *plane_fmt;
 	uint32_t epoch;          // number of this extraction: headers written by earlier ones are not valid
 	const uint2 *slot_base;  // [slice_slot]: {first work record, first mask record} (k_slots)
 	uint32_t *seg_cnt;
@@ -881,7 +928,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 	const bool in_grid = seg < P.nseg && z < a.ze;
 	SliceHeader h;
 	h.flags = 0; h.cells = 0;
-	uint4 q[4] = {};
+	uint32_t dl = 0, du = 0, fmt_l = PLANE_COMPACT, fmt_u = PLANE_COMPACT;
+	uint64_t slot_up = 0;
 	uint2 base = {0u, 0u};
 	uint32_t lbase = 0;
 	if (in_grid) {  // header, ranges and bit rows are fetched together (one round trip); the rows of a slice
@@ -891,10 +939,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 		h = a.slice_hdr[slot];
 		base = a.slot_base[slot];
 		lbase = a.slot_base[(slot >> a.lc.shift) << a.lc.shift].x;  // where the list part of the slot's group begins
-		// bit rows of the two planes of the slice (the upper plane's record sits in the slot of the slice above)
-		const uint4 *lower = a.slice_bits + slot * 128u + lane;
-		const uint4 *upper = a.slice_bits + slice_slot(z + 1u - P.zs, yt, seg, a.nYT, a.nseg_pad) * 128u + lane;
-		q[0] = lower[0]; q[1] = lower[64]; q[2] = upper[0]; q[3] = upper[64];
+		// the records of the two planes of the slice (the upper plane's sits in the slot of the slice above): their compact
+		// form, one dword per row, and how they are written; a plane in raw form (a row with more than two changes) costs
+		// a second round trip below
+		slot_up = slice_slot(z + 1u - P.zs, yt, seg, a.nYT, a.nseg_pad);
+		dl = ((const uint32_t *)(a.slice_bits + slot * 128u))[lane];
+		du = ((const uint32_t *)(a.slice_bits + slot_up * 128u))[lane];
+		fmt_l = a.plane_fmt[slot]; fmt_u = a.plane_fmt[slot_up];
 	}
 	__syncthreads();  // s_fast
 	const bool live = in_grid && slice_valid(h.flags, a.epoch);  // wave-uniform
@@ -905,8 +956,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 		return;
 	}
 	uint64_t prev[4], cur[4], act[4];
-	prev[0] = u64(q[0].x, q[0].y); prev[1] = u64(q[0].z, q[0].w); prev[2] = u64(q[1].x, q[1].y); prev[3] = u64(q[1].z, q[1].w);
-	cur[0] = u64(q[2].x, q[2].y); cur[1] = u64(q[2].z, q[2].w); cur[2] = u64(q[3].x, q[3].y); cur[3] = u64(q[3].z, q[3].w);
+	{
+		const bool raw_l = __builtin_amdgcn_readfirstlane((int)fmt_l) != (int)PLANE_COMPACT, raw_u = __builtin_amdgcn_readfirstlane((int)fmt_u) != (int)PLANE_COMPACT;
+		uint4 q[4] = {};
+		if (raw_l) { const uint4 *lower = a.slice_bits + slot * 128u + lane; q[0] = lower[0]; q[1] = lower[64]; }
+		if (raw_u) { const uint4 *upper = a.slice_bits + slot_up * 128u + lane; q[2] = upper[0]; q[3] = upper[64]; }
+		if (raw_l) { prev[0] = u64(q[0].x, q[0].y); prev[1] = u64(q[0].z, q[0].w); prev[2] = u64(q[1].x, q[1].y); prev[3] = u64(q[1].z, q[1].w); }
+		else decode_row(dl, prev);
+		if (raw_u) { cur[0] = u64(q[2].x, q[2].y); cur[1] = u64(q[2].z, q[2].w); cur[2] = u64(q[3].x, q[3].y); cur[3] = u64(q[3].z, q[3].w); }
+		else decode_row(du, cur);
+	}
 	const uint64_t bp = u64(h.prevh_lo, h.prevh_hi), bc = u64(h.curh_lo, h.curh_hi);  // halo-column bits of the rows
 	{
 		uint64_t valid[4];
@@ -1404,6 +1463,7 @@ constexpr int MC33_LANES = 8;
 struct IsoLane {
 	SliceHeader *slice_hdr;   // one record per (wave tile, cell slice) of the sweep
 	uint4 *slice_bits;
+	uint8_t *plane_fmt;
 	unsigned long long *slot_part;
 	uint4 *edge_bits, *edge_hdr;
 	uint64_t slice_cap, edge_cap;
@@ -1598,7 +1658,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->entries_c); (void)hipFree(c->d_fast_b); (void)hipFree(c->d_pat); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
 	for (int k = 0; k < MC33_LANES; k++) {
 		IsoLane &L = c->lanes[k];
-		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.slot_part); (void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
+		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.plane_fmt); (void)hipFree(L.slot_part); (void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
 	}
 	(void)hipFree(c->d_tiles);
 	(void)hipFree(c->slot_base);
@@ -1934,10 +1994,11 @@ static int slot_geometry(mc33hip_ctx *c, SlotGeom &g) {
 // buffers of one isovalue lane for the current range and tile plan; a new extraction number (epoch)
 static int begin_lane(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g, hipStream_t st) {
 	if (L.slice_cap < g.nslots) {
-		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.slot_part);
-		L.slice_hdr = nullptr; L.slice_bits = nullptr; L.slot_part = nullptr; L.slice_cap = 0;
+		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.plane_fmt); (void)hipFree(L.slot_part);
+		L.slice_hdr = nullptr; L.slice_bits = nullptr; L.plane_fmt = nullptr; L.slot_part = nullptr; L.slice_cap = 0;
 		HIP_TRY(hipMalloc(&L.slice_hdr, g.nslots * sizeof(SliceHeader)));
 		HIP_TRY(hipMalloc(&L.slice_bits, (g.nslots + 4ull * g.nYT * g.nseg) * 2048));  // planes: one more than slices
+		HIP_TRY(hipMalloc(&L.plane_fmt, g.nslots + 4ull * g.nYT * g.nseg));
 		const uint64_t part_bytes = ((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK) * 8;
 		HIP_TRY(hipMalloc(&L.slot_part, 2 * part_bytes));  // two halves, used by alternate extractions
 		HIP_TRY(hipMemsetAsync(L.slice_hdr, 0, g.nslots * sizeof(SliceHeader), st));
@@ -1977,10 +2038,10 @@ static void sweep_args(mc33hip_ctx *c, const SlotGeom &g, SweepArgs &a) {
 	a.z_end = c->range.z_end;
 	a.trace = nullptr;
 	a.debug = 0;
-	for (int q = 0; q < SWEEP_MAXNI; q++) a.lane[q] = SweepLane{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, (real_t)0};
+	for (int q = 0; q < SWEEP_MAXNI; q++) a.lane[q] = SweepLane{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, (real_t)0};
 }
 static void set_lane(SweepArgs &a, int q, const IsoLane &L, double iso) {
-	a.lane[q] = SweepLane{L.slice_hdr, L.slice_bits, lane_part(L, false), L.edge_bits, L.edge_hdr, L.epoch, (real_t)iso};
+	a.lane[q] = SweepLane{L.slice_hdr, L.slice_bits, L.plane_fmt, lane_part(L, false), L.edge_bits, L.edge_hdr, L.epoch, (real_t)iso};
 }
 
 // narrow samples are loaded as dwords when every row of the grid starts on a dword boundary (always true for the
@@ -2046,7 +2107,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	ca.G.p = c->d_grid; ca.G.pitch = (uint32_t)c->pitch; ca.G.z0 = c->desc.plane0; ca.G.slice = c->slice;
 	ca.P = P; ca.fast = c->d_fast; ca.lut = c->d_lut; ca.pat = c->d_pat;
 	ca.ze = ze; ca.nYT = g.nYT; ca.nseg_pad = g.nseg;
-	ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.slot_base = c->slot_base;
+	ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.plane_fmt = L.plane_fmt; ca.slot_base = c->slot_base;
 	ca.epoch = L.epoch;
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir;
 	ca.entries_a = c->entries_a; ca.entries_b = c->entries_b; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
