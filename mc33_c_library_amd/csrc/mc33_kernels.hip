@@ -340,31 +340,42 @@ __device__ __forceinline__ void decode_row(uint32_t desc, uint64_t (&w)[4]) {
 // the sweep works in - bit j of word m is sample x = 64 m + j | 128 (m >> 1) + 2 j + (m & 1) | 4 j + m for S = 1 | 2 | 4 - so a
 // compact plane is never converted to the standard layout at all)
 template <int S>
-__device__ __forceinline__ void store_plane(const SweepLane &a, uint64_t plane_slot, const uint64_t (&w)[4]) {
-	const uint32_t lane = threadIdx.x & 63u;
+__device__ __forceinline__ bool encode_plane(const uint64_t (&w)[4], uint32_t &desc) {  // true (wave-uniform): every row of the plane fits its dword
 	uint64_t nx[4], t[4];
 	succ_words<S>(w, w[3] >> 63, nx);  // (the sample after the last one: itself - no change there)
 #pragma unroll
 	for (int k = 0; k < 4; k++) t[k] = w[k] ^ nx[k];
 	const uint32_t n = (uint32_t)(__popcll(t[0]) + __popcll(t[1]) + __popcll(t[2]) + __popcll(t[3]));
-	const bool compact = __ballot(n > 2u) == 0ull;
-	if (compact) {
-		// at most two changes: the lowest bit of the first word that has one and the highest bit of the last such word
-		const uint32_t m1 = t[0] ? 0u : t[1] ? 1u : t[2] ? 2u : 3u, m2 = t[3] ? 3u : t[2] ? 2u : t[1] ? 1u : 0u;
-		const uint64_t t1 = t[0] ? t[0] : t[1] ? t[1] : t[2] ? t[2] : t[3], t2 = t[3] ? t[3] : t[2] ? t[2] : t[1] ? t[1] : t[0];
-		const uint32_t b1 = t1 ? (uint32_t)__builtin_ctzll(t1) : 0u, b2 = t2 ? 63u - (uint32_t)__builtin_clzll(t2) : 0u;
-		const uint32_t p1 = S == 1 ? 64u * m1 + b1 : S == 2 ? 128u * (m1 >> 1) + 2u * b1 + (m1 & 1u) : 4u * b1 + m1;
-		const uint32_t p2 = S == 1 ? 64u * m2 + b2 : S == 2 ? 128u * (m2 >> 1) + 2u * b2 + (m2 & 1u) : 4u * b2 + m2;
-		const uint32_t desc = (uint32_t)(w[0] & 1ull) | n << 1 | p1 << 8 | p2 << 16;
-		((uint32_t *)(a.slice_bits + plane_slot * 128u))[lane] = desc;
-	} else {
-		uint64_t o[4];
-		to_standard<S>(w, o);
-		uint4 *bits = a.slice_bits + plane_slot * 128u + lane;
-		bits[0] = uint4{(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)};
-		bits[64] = uint4{(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)};
+	desc = 0;
+	if (__ballot(n > 2u) != 0ull) return false;
+	// at most two changes: the lowest bit of the first word that has one and the highest bit of the last such word
+	const uint32_t m1 = t[0] ? 0u : t[1] ? 1u : t[2] ? 2u : 3u, m2 = t[3] ? 3u : t[2] ? 2u : t[1] ? 1u : 0u;
+	const uint64_t t1 = t[0] ? t[0] : t[1] ? t[1] : t[2] ? t[2] : t[3], t2 = t[3] ? t[3] : t[2] ? t[2] : t[1] ? t[1] : t[0];
+	const uint32_t b1 = t1 ? (uint32_t)__builtin_ctzll(t1) : 0u, b2 = t2 ? 63u - (uint32_t)__builtin_clzll(t2) : 0u;
+	const uint32_t p1 = S == 1 ? 64u * m1 + b1 : S == 2 ? 128u * (m1 >> 1) + 2u * b1 + (m1 & 1u) : 4u * b1 + m1;
+	const uint32_t p2 = S == 1 ? 64u * m2 + b2 : S == 2 ? 128u * (m2 >> 1) + 2u * b2 + (m2 & 1u) : 4u * b2 + m2;
+	desc = (uint32_t)(w[0] & 1ull) | n << 1 | p1 << 8 | p2 << 16;
+	return true;
+}
+// writes the record at `rec` (2 KiB reserved) in the form that fits; returns the form
+template <int S>
+__device__ __forceinline__ uint32_t store_plane_record(uint4 *rec, const uint64_t (&w)[4]) {
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t desc;
+	if (encode_plane<S>(w, desc)) {
+		((uint32_t *)rec)[lane] = desc;
+		return PLANE_COMPACT;
 	}
-	if (lane == 0) a.plane_fmt[plane_slot] = (uint8_t)(compact ? PLANE_COMPACT : PLANE_RAW);
+	uint64_t o[4];
+	to_standard<S>(w, o);
+	rec[lane] = uint4{(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)};
+	rec[64 + lane] = uint4{(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)};
+	return PLANE_RAW;
+}
+template <int S>
+__device__ __forceinline__ void store_plane(const SweepLane &a, uint64_t plane_slot, const uint64_t (&w)[4]) {
+	const uint32_t fmt = store_plane_record<S>(a.slice_bits + plane_slot * 128u, w);
+	if ((threadIdx.x & 63u) == 0) a.plane_fmt[plane_slot] = (uint8_t)fmt;
 }
 
 // (slot: of the slice; slot_up: of the slice above = the slot of the upper plane; write_prev / write_cur: the
@@ -623,16 +634,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 				cur_zc[q] = zh ? ~0ull : zcacc[q];  // (a halo sample: any column)
 				zacc[q] = zcacc[q] = 0;
 			}
-			auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary (standard layout)
-				uint64_t w[4];
-				to_standard<S>(cur[q], w);
-				uint4 *e = L.edge_bits + ((uint64_t)wtile * 2u + which) * 128u + lane;
-				e[0] = uint4{(uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32)};
-				e[64] = uint4{(uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32)};
+			auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary (a plane record like those of slice_bits)
+				// (in compact form where it fits only in the passes over several isovalues, which are bound by what they write:
+				// 2.26 -> 2.19 ms per 4-isovalue pass at C5; the single-isovalue pass lost with it - 0.789 -> 0.818 ms at C3,
+				// eight processes each way - and keeps the raw form)
+				uint32_t fmt = PLANE_RAW;
+				uint4 *rec = L.edge_bits + ((uint64_t)wtile * 2u + which) * 128u;
+				if constexpr (NI >= 2) fmt = store_plane_record<S>(rec, cur[q]);
+				else {
+					uint64_t o[4];
+					to_standard<S>(cur[q], o);
+					rec[lane] = uint4{(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)};
+					rec[64 + lane] = uint4{(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)};
+				}
 				const uint64_t bh = __ballot(cur_h[q] != 0);
 				if (lane == 0) {
 					L.edge_hdr[((uint64_t)wtile * 2u + which) * 2u] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), (uint32_t)cur_z[q], (uint32_t)(cur_z[q] >> 32)};
-					L.edge_hdr[((uint64_t)wtile * 2u + which) * 2u + 1u] = uint4{(uint32_t)cur_zc[q], (uint32_t)(cur_zc[q] >> 32), 0u, 0u};
+					L.edge_hdr[((uint64_t)wtile * 2u + which) * 2u + 1u] = uint4{(uint32_t)cur_zc[q], (uint32_t)(cur_zc[q] >> 32), fmt, 0u};
 				}
 			};
 			if (MC33_DEBUG_BITS(a) & 2u) {
@@ -707,8 +725,12 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 	const uint4 p0 = L.edge_bits[rp * 128u + lane], p1 = L.edge_bits[rp * 128u + 64u + lane];
 	const uint4 c0 = L.edge_bits[rc * 128u + lane], c1 = L.edge_bits[rc * 128u + 64u + lane];
 	const uint4 hp = L.edge_hdr[rp * 2u], hc = L.edge_hdr[rc * 2u], zp = L.edge_hdr[rp * 2u + 1u], zc = L.edge_hdr[rc * 2u + 1u];
-	const uint64_t prev[4] = {u64(p0.x, p0.y), u64(p0.z, p0.w), u64(p1.x, p1.y), u64(p1.z, p1.w)};
-	const uint64_t cur[4] = {u64(c0.x, c0.y), u64(c0.z, c0.w), u64(c1.x, c1.y), u64(c1.z, c1.w)};
+	// (both forms of both records are asked for at once - which one a plane has stands in its header, zp.z / zc.z)
+	const uint32_t dp = ((const uint32_t *)(L.edge_bits + rp * 128u))[lane], dc = ((const uint32_t *)(L.edge_bits + rc * 128u))[lane];
+	uint64_t prev[4] = {u64(p0.x, p0.y), u64(p0.z, p0.w), u64(p1.x, p1.y), u64(p1.z, p1.w)};
+	uint64_t cur[4] = {u64(c0.x, c0.y), u64(c0.z, c0.w), u64(c1.x, c1.y), u64(c1.z, c1.w)};
+	if (zp.z == PLANE_COMPACT) decode_row(dp, prev);
+	if (zc.z == PLANE_COMPACT) decode_row(dc, cur);
 	const uint64_t bp = u64(hp.x, hp.y), bc = u64(hc.x, hc.y);
 	uint64_t valid[4], act[4];
 	valid_masks(seg * SEG_CELLS, P.nx, valid);
