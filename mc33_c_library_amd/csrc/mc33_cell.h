@@ -837,9 +837,7 @@ struct alignas(64) SegDir {
 	// One cache line per row segment, laid out so that ONE 16-byte read answers "which record is cell x": for each of
 	// the four 64-cell words k of the segment
 	//   q[k] = { activity mask of the word (lo, hi), index of the first work record of the word's cells, nent }
-	// nent = number of records of the whole segment (bit 31: the sweep left cells for the slow kernel) UNTIL the prefix sums
-	// are known: k_scan_apply then puts the segment's first vertex id (SegBase::vbase) there - the triangle pass, which
-	// fetches this word for each of the three neighbouring row segments, gets their bases with it.  Written only
+	// nent = number of records of the whole segment (bit 31: the sweep left cells for the slow kernel).  Written only
 	// for segments that hold records; nobody looks at the others.
 	uint32_t q[4][4];
 };
@@ -915,7 +913,7 @@ MC33_HD uint32_t seg_pack(uint32_t nv, uint32_t nt) { return nv | nt << 16; }
 // work record of the active cell (x,y,z), through the directory (no search: the activity mask of the cell's word
 // gives the rank of the cell among the word's records); w = the directory word q[xl >> 6] of the cell's row segment
 struct DirWord {
-	uint32_t mlo, mhi, first, vbase;  // (vbase: the fourth field in the emit passes, see SegDir)
+	uint32_t mlo, mhi, first, nent;
 };
 template <typename T>
 MC33_HD DirWord dir_word(const EmitCtx<T> &c, uint64_t s, uint32_t xl) {
@@ -1227,7 +1225,7 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 		for (int g = 0; g < 3; g++) {  // round trip 1: one 16-byte directory word per segment
 			const uint64_t gs = needseg[g] ? segment_index(c.P, x, y - sdy[g], z - sdz[g]) : (uint64_t)s;
 			sd[g] = dir_word(c, gs, xl);
-			svb[g] = sd[g].vbase;
+			svb[g] = c.seg_base[gs].vbase;
 		}
 		const Entry prev = ctx_entry(c, need[1] ? self_index - 1 : self_index);  // o1: the cell x-1 is active whenever needed
 		uint32_t below[3];
@@ -1248,7 +1246,7 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 			const uint64_t os = need[o] ? segment_index(c.P, ox, y - ody[o], z - odz[o]) : (uint64_t)s;
 			const uint32_t oxl = need[o] ? ox % SEG_CELLS : xl;
 			const DirWord d = dir_word(c, os, oxl);
-			ovb[o] = d.vbase;
+			ovb[o] = c.seg_base[os].vbase;
 			oe[o] = ctx_entry(c, need[o] ? record_rank(d, oxl) : self_index);
 		}
 	}

@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, ui
 // L2; cheaper than a separate one-block scan kernel between the two passes), then scans its chunk.  The last block
 // also knows the totals.
 __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uint64_t n, Params P, const uint64_t *bsV, const uint64_t *bsT,
-                                                    SegBase *seg_base, SegDir *seg_dir, uint64_t ghost_segs, Counters *ctr) {
+                                                    SegBase *seg_base, uint64_t ghost_segs, Counters *ctr) {
 	__shared__ uint32_t sv[4], st[4];
 	__shared__ uint64_t s_bv[4], s_bt[4];
 	uint64_t bv = 0, bt = 0;  // vertices / triangles of all chunks before this one
@@ -1348,11 +1348,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uin
 #pragma unroll
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
 		if (q0 + k < n) {
-			if (cv[k] | ct[k]) {  // (nobody asks for the base of a row segment that holds nothing)
-				seg_base[st_idx[k]] = SegBase{ev, et};
-				uint32_t *dq = (uint32_t *)seg_dir[st_idx[k]].q;  // ... and into the four words of its directory line (SegDir)
-				dq[3] = ev; dq[7] = ev; dq[11] = ev; dq[15] = ev;
-			}
+			if (cv[k] | ct[k]) seg_base[st_idx[k]] = SegBase{ev, et};  // (nobody asks for the base of a row segment that holds nothing)
 			if (q0 + k == ghost_segs) { ctr->ghostV = ev; ctr->ghostT = et; }  // first segment of the emitted range
 		}
 		ev += cv[k]; et += ct[k];
@@ -2172,7 +2168,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
 	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
 	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT);
-	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, c->seg_base, c->seg_dir,
+	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, c->seg_base,
 	                   c->ghost_segs, c->d_ctr);
 	HIP_TRY(hipGetLastError());
 	return 0;

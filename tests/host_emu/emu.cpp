@@ -163,7 +163,6 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	for (uint64_t q = 0; q < nsegs; q++) {
 		const uint64_t s = segment_sweep_to_store(P, q);
 		seg_base[s].vbase = (uint32_t)nV; seg_base[s].tbase = (uint32_t)nT;
-		for (int k = 0; k < 4; k++) seg_dir[s].q[k][3] = (uint32_t)nV;  // as k_scan_apply: the base rides in the directory words
 		nV += seg_cnt[s] & 0xFFFF; nT += seg_cnt[s] >> 16;
 	}
 	const uint64_t gseg = (uint64_t)(z_emit - P.zs) * P.ny * P.nseg;  // first segment of the emitted range (same index in both orders)
