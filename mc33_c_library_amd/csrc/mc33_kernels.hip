@@ -2090,7 +2090,11 @@ static void launch_sweep_ni(mc33hip_ctx *c, const SweepArgs &a, hipStream_t st) 
 		negzero |= iso == 0 && sign_of(iso);
 		can_equal |= iso >= 0 && iso <= (real_t)std::numeric_limits<sample_t>::max() && iso == std::floor(iso);
 	}
-	if (!negzero && !env_u32("MC33_HIP_SWEEP_SUBTRACT", 0)) {
+	bool subtract = negzero;
+#ifdef MC33_DEV
+	subtract |= env_u32("MC33_HIP_SWEEP_SUBTRACT", 0) != 0;  // (A/B of the two forms; same results)
+#endif
+	if (!subtract) {
 		if (can_equal) launch_sweep_zm<NI, 1>(c, a, st);
 		else launch_sweep_zm<NI, 2>(c, a, st);
 		return;
