@@ -1139,7 +1139,8 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 		const SamplePair<T> q = G.pair(x, yy, zz);
 		F[r][0] = q.a;
 		F[r][1] = q.b;
-		F[r][2] = xin ? G.at(x + 2, yy, zz) : q.b;
+		F[r][2] = G.at(xin ? x + 2 : x + 1, yy, zz);  // (x + 1 again on the last column: the same value as q.b, and a load without a branch -
+		                                             // a conditional load made the compiler wait for each row's pair before asking for the next row)
 	}
 	// rows outside the cell: Y2[p][col] = (y+2, z+p), Z2[q][col] = (y+q, z+2); col = x, x+1
 	T Y2[2][2], Z2[2][2];
@@ -1148,6 +1149,15 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 		Y2[q][0] = yq.a; Y2[q][1] = yq.b;
 		Z2[q][0] = zq.a; Z2[q][1] = zq.b;
 	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	{  // every sample fetched above is needed HERE: without a use outside the per-vertex branches the compiler moves the loads
+		// a branch alone uses (half a pair, even) into that branch - a round trip of their own for the records that take it
+		uint32_t acc = 0;
+		for (int r = 0; r < 4; r++) acc += (uint32_t)F[r][0] + (uint32_t)F[r][1] + (uint32_t)F[r][2];
+		for (int q = 0; q < 2; q++) acc += (uint32_t)Y2[q][0] + (uint32_t)Y2[q][1] + (uint32_t)Z2[q][0] + (uint32_t)Z2[q][1];
+		asm volatile("" ::"v"(acc));
+	}
+#endif
 	const real_t iso = P.iso;
 	const real_t v1 = iso - (real_t)F[1][0], v2 = iso - (real_t)F[3][0], v3 = iso - (real_t)F[2][0];
 	const real_t v4 = iso - (real_t)F[0][1], v5 = iso - (real_t)F[1][1], v6 = iso - (real_t)F[3][1], v7 = iso - (real_t)F[2][1];
@@ -1217,26 +1227,32 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 	Entry oe[6];
 	uint32_t ovb[6];
 	if (xl != 0) {
-		// segments A, B, C (index 0..2); x-1 lies in the same segments as x
+		// segments A = (y, z-1), B = (y-1, z), C = (y-1, z-1) (index 0..2); x-1 lies in the same segments as x.  Everything is
+		// written so that the loads of a round trip are asked for together: addresses by selects, never by branches (the
+		// compiler waits at a branch for what it depends on), halves A of all records before any half B.
 		const bool needseg[3] = {need[0] || need[3], need[2] || need[4], need[5]};
-		const uint32_t sdy[3] = {0, 1, 1}, sdz[3] = {1, 0, 1};
+		const uint64_t dz = (uint64_t)c.P.nseg * c.P.ny;  // segment index: ((z - zs) nseg + seg) ny + y
+		const uint64_t gs[3] = {(uint64_t)s - (needseg[0] ? dz : 0ull), (uint64_t)s - (needseg[1] ? 1ull : 0ull), (uint64_t)s - (needseg[2] ? dz + 1ull : 0ull)};
 		DirWord sd[3];
 		uint32_t svb[3];
-		for (int g = 0; g < 3; g++) {  // round trip 1: one 16-byte directory word per segment
-			const uint64_t gs = needseg[g] ? segment_index(c.P, x, y - sdy[g], z - sdz[g]) : (uint64_t)s;
-			sd[g] = dir_word(c, gs, xl);
-			svb[g] = c.seg_base[gs].vbase;
+		for (int g = 0; g < 3; g++) {  // round trip 1: one 16-byte directory word and the base per segment ...
+			sd[g] = dir_word(c, gs[g], xl);
+			svb[g] = c.seg_base[gs[g]].vbase;
 		}
-		const Entry prev = ctx_entry(c, need[1] ? self_index - 1 : self_index);  // o1: the cell x-1 is active whenever needed
+		EntryA oa[6];
+		uint32_t oi[6];
+		oi[1] = need[1] ? self_index - 1 : self_index;  // o1: the cell x-1 is active whenever needed
+		oa[1] = c.entries_a[oi[1]];                     // ... and the record before this one
 		uint32_t below[3];
 		for (int g = 0; g < 3; g++) below[g] = record_rank(sd[g], xl);  // the record of x in that segment (or where it would be)
-		// round trip 2: the records (x-1 is the record before x's position, it is active whenever needed)
-		oe[3] = ctx_entry(c, need[3] ? below[0] : self_index);
-		oe[0] = ctx_entry(c, need[0] ? below[0] - 1 : self_index);
-		oe[4] = ctx_entry(c, need[4] ? below[1] : self_index);
-		oe[2] = ctx_entry(c, need[2] ? below[1] - 1 : self_index);
-		oe[5] = ctx_entry(c, need[5] ? below[2] : self_index);
-		oe[1] = prev;
+		// round trip 2: halves A of the records (x-1 is the record before x's position, it is active whenever needed)
+		oi[3] = need[3] ? below[0] : self_index; oi[0] = need[0] ? below[0] - 1 : self_index;
+		oi[4] = need[4] ? below[1] : self_index; oi[2] = need[2] ? below[1] - 1 : self_index;
+		oi[5] = need[5] ? below[2] : self_index;
+		oa[3] = c.entries_a[oi[3]]; oa[0] = c.entries_a[oi[0]]; oa[4] = c.entries_a[oi[4]]; oa[2] = c.entries_a[oi[2]]; oa[5] = c.entries_a[oi[5]];
+		// halves B: from the table for fast records; a third round trip only for neighbours that are tested or slow cells
+		for (int o = 0; o < 6; o++)
+			oe[o] = entry_join(oa[o], (oa[o].a0 & (ENTRYA_SLOW | ENTRYA_TESTED)) ? c.entries_b[oi[o]] : c.fast_b[(oa[o].a0 >> 8) & 0xFFu]);
 		ovb[0] = ovb[3] = svb[0]; ovb[2] = ovb[4] = svb[1]; ovb[5] = svb[2]; ovb[1] = sb.vbase;
 	} else {
 		// first cell of a row segment: the x-1 neighbours live in the previous segment - six plain lookups

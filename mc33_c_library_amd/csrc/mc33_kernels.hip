@@ -1417,8 +1417,9 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 	if (!emit_prepare(a, c, ctr)) return;
 	const XcdWalk w(ctr.entry_cursor);
 	for (uint32_t e = w.first; e < w.end; e += w.stride) {
+		const uint32_t seg = c.entry_seg[e];  // (asked for together with the record, not after its flags are known)
 		const Entry en = ctx_entry(c, e);
-		if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, c.entry_seg[e]);
+		if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, seg);
 	}
 }
 
@@ -1435,8 +1436,9 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	const URef ids{&s_id[0][threadIdx.x], 256};
 	const XcdWalk w(ctr.entry_cursor);
 	for (uint32_t e = w.first; e < w.end; e += w.stride) {
+		const uint32_t seg = c.entry_seg[e];
 		const Entry en = ctx_entry(c, e);
-		if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, c.entry_seg[e], e, ids);
+		if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, seg, e, ids);
 	}
 }
 
