@@ -893,7 +893,8 @@ struct EmitCtx {
 	const EntryA *entries_a;    // work records, half A (all) and half B (slow records only)
 	const EntryB *entries_b;
 	const EntryC *entries_c;    // plans of the slow records
-	const EntryB *fast_b;       // [256] half B of the fast records (may point into LDS)
+	const EntryB *fast_b;       // [256] half B of the fast records
+	bool fast_b_in_lds;         // ... the table is a copy in LDS (the fast emit kernels): read as such, see fast_half_b
 	const uint32_t *entry_seg;  // row segment of each entry
 	real_t *V;
 	float *N;
@@ -904,8 +905,32 @@ struct EmitCtx {
 	uint32_t z_emit, v_skip, t_skip, id_delta;
 };
 
+// Half B of a fast record from the table.  When the table sits in LDS it must be READ as LDS: through the generic pointer
+// it is a flat load, which counts on both wait counters - every wait for it is a wait for all global loads in flight - and a
+// `stored ? entries_b[i] : fast_b[k]` becomes ONE flat load through a selected pointer.  An LDS read and a global load
+// behind a branch cannot be merged.
 template <typename T>
-MC33_HD Entry ctx_entry(const EmitCtx<T> &c, uint32_t ri) { return load_entry(c.entries_a, c.entries_b, c.fast_b, ri); }
+MC33_HD EntryB fast_half_b(const EmitCtx<T> &c, uint32_t sign_index) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (c.fast_b_in_lds) {
+		typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
+		lds_u32 p = (lds_u32)(const uint32_t *)c.fast_b + 2u * sign_index;
+		return EntryB{p[0], p[1]};
+	}
+#endif
+	return c.fast_b[sign_index];
+}
+template <typename T>
+MC33_HD EntryB ctx_half_b(const EmitCtx<T> &c, const EntryA &a, uint32_t ri) {
+	EntryB b = fast_half_b(c, (a.a0 >> 8) & 0xFFu);
+	if (a.a0 & (ENTRYA_SLOW | ENTRYA_TESTED)) b = c.entries_b[ri];
+	return b;
+}
+template <typename T>
+MC33_HD Entry ctx_entry(const EmitCtx<T> &c, uint32_t ri) {
+	const EntryA a = c.entries_a[ri];
+	return entry_join(a, ctx_half_b(c, a, ri));
+}
 
 // per-segment counts packed in one word: vertices (<= 13*256) | triangles (<= 12*256) << 16
 MC33_HD uint32_t seg_pack(uint32_t nv, uint32_t nt) { return nv | nt << 16; }
@@ -955,8 +980,7 @@ MC33_HD RootRef chase_root(const EmitCtx<T> &c, GridEdge g, const VRef &w) {
 		const uint32_t ri = find_record(c, s, o.x % SEG_CELLS);
 		if (ri == NO_ID) return none;
 		const EntryA ea = c.entries_a[ri];
-		const bool stored = (ea.a0 & (ENTRYA_SLOW | ENTRYA_TESTED)) != 0;
-		const Entry e = entry_join(ea, stored ? c.entries_b[ri] : c.fast_b[(ea.a0 >> 8) & 0xFFu]);
+		const Entry e = entry_join(ea, ctx_half_b(c, ea, ri));
 		const uint32_t r = entry_rank(e, o.e);
 		if (r != 15u) return RootRef{ri, r, (uint32_t)s, ea.a1 & 0xFFFFu};
 		if (!(ea.a0 & ENTRYA_SLOW)) return none;  // a fast or tested cell creates the vertices of its cut edges itself: the edge is not in its pattern
@@ -1252,7 +1276,7 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 		oa[3] = c.entries_a[oi[3]]; oa[0] = c.entries_a[oi[0]]; oa[4] = c.entries_a[oi[4]]; oa[2] = c.entries_a[oi[2]]; oa[5] = c.entries_a[oi[5]];
 		// halves B: from the table for fast records; a third round trip only for neighbours that are tested or slow cells
 		for (int o = 0; o < 6; o++)
-			oe[o] = entry_join(oa[o], (oa[o].a0 & (ENTRYA_SLOW | ENTRYA_TESTED)) ? c.entries_b[oi[o]] : c.fast_b[(oa[o].a0 >> 8) & 0xFFu]);
+			oe[o] = entry_join(oa[o], ctx_half_b(c, oa[o], oi[o]));
 		ovb[0] = ovb[3] = svb[0]; ovb[2] = ovb[4] = svb[1]; ovb[5] = svb[2]; ovb[1] = sb.vbase;
 	} else {
 		// first cell of a row segment: the x-1 neighbours live in the previous segment - six plain lookups

@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(256) void k_slow_count(const SlowArgs a) {
 	EmitCtx<sample_t> c;
 	c.tab = a.tab; c.P = a.P; c.G = a.G;
 	c.seg_base = nullptr; c.seg_dir = a.seg_dir;
-	c.entries_a = a.entries_a; c.entries_b = a.entries_b; c.entries_c = a.entries_c; c.fast_b = a.fast_b; c.entry_seg = a.entry_seg;
+	c.entries_a = a.entries_a; c.entries_b = a.entries_b; c.entries_c = a.entries_c; c.fast_b = a.fast_b; c.fast_b_in_lds = false; c.entry_seg = a.entry_seg;
 	c.V = nullptr; c.N = nullptr; c.Tri = nullptr;
 	c.z_emit = a.z_emit; c.v_skip = c.t_skip = c.id_delta = 0;
 	const VRef w{&s_w[0][threadIdx.x], 256};
@@ -1413,12 +1413,14 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 	__syncthreads();
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
-	c.fast_b = s_fast_b;
+	c.fast_b = s_fast_b; c.fast_b_in_lds = true;
 	if (!emit_prepare(a, c, ctr)) return;
 	const XcdWalk w(ctr.entry_cursor);
 	for (uint32_t e = w.first; e < w.end; e += w.stride) {
 		const uint32_t seg = c.entry_seg[e];  // (asked for together with the record, not after its flags are known)
-		const Entry en = ctx_entry(c, e);
+		const EntryA ea = c.entries_a[e];
+		asm volatile("" ::"v"(seg), "v"(ea.a0));  // (both wanted here: the compiler would move the segment's load behind the flag test)
+		const Entry en = entry_join(ea, ctx_half_b(c, ea, e));
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, seg);
 	}
 }
@@ -1431,13 +1433,15 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	__syncthreads();
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
-	c.fast_b = s_fast_b;
+	c.fast_b = s_fast_b; c.fast_b_in_lds = true;
 	if (!emit_prepare(a, c, ctr)) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
 	const XcdWalk w(ctr.entry_cursor);
 	for (uint32_t e = w.first; e < w.end; e += w.stride) {
 		const uint32_t seg = c.entry_seg[e];
-		const Entry en = ctx_entry(c, e);
+		const EntryA ea = c.entries_a[e];
+		asm volatile("" ::"v"(seg), "v"(ea.a0));
+		const Entry en = entry_join(ea, ctx_half_b(c, ea, e));
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, seg, e, ids);
 	}
 }
@@ -2283,7 +2287,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.c.P = c->P;
 	a.c.G.p = c->d_grid; a.c.G.pitch = (uint32_t)c->pitch; a.c.G.z0 = c->desc.plane0; a.c.G.slice = c->slice;
 	a.c.seg_base = c->seg_base; a.c.seg_dir = c->seg_dir;
-	a.c.entries_a = c->entries_a; a.c.entries_b = c->entries_b; a.c.entries_c = c->entries_c; a.c.fast_b = c->d_fast_b; a.c.entry_seg = c->entry_seg;
+	a.c.entries_a = c->entries_a; a.c.entries_b = c->entries_b; a.c.entries_c = c->entries_c; a.c.fast_b = c->d_fast_b; a.c.fast_b_in_lds = false; a.c.entry_seg = c->entry_seg;
 	a.c.V = (real_t *)dV; a.c.N = (float *)dN; a.c.Tri = (uint32_t *)dT;
 	a.c.z_emit = c->range.z_begin; a.c.v_skip = a.c.t_skip = a.c.id_delta = 0;
 	a.ctr = c->d_ctr;

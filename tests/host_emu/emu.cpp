@@ -131,7 +131,7 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	EmitCtx<T> c;
 	c.tab = tab; c.P = P; c.G = G;
 	c.seg_base = seg_base.data(); c.seg_dir = seg_dir.data();
-	c.entries_a = ea.data(); c.entries_b = eb.data(); c.entries_c = ec.data(); c.fast_b = fast_b; c.entry_seg = entry_seg.data();
+	c.entries_a = ea.data(); c.entries_b = eb.data(); c.entries_c = ec.data(); c.fast_b = fast_b; c.fast_b_in_lds = false; c.entry_seg = entry_seg.data();
 	c.z_emit = z_emit;
 	// pass 2 (k_slow_count): triangles of the slow cells with a corner equal to the isovalue, by vertex identity on the stored
 	// plans - checked against the round-1 formulation that plans every owner on the way (count_triangles)
