@@ -1236,10 +1236,8 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 // are edges of a fast cell), so their owners created regular vertices: no alias to follow.
 template <typename T>
 MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t s, uint32_t self_index, const URef &ids) {
-	const SegCoord sc = segment_coord(c.P, s);
-	const uint32_t y = sc.y, z = sc.z;
-	if (z < c.z_emit) return;
-	const uint32_t xl = en.w0 & 0xFFu, x = sc.xbase + xl;
+	if (segment_coord(c.P, s).z < c.z_emit) return;
+	const uint32_t xl = en.w0 & 0xFFu;
 	const uint32_t i = (en.w0 >> 8) & 0xFFu;
 #define MC33_SIDE(k) ((i >> (7 - (k))) & 1u)
 	const bool cut0 = MC33_SIDE(0) != MC33_SIDE(1), cut1 = MC33_SIDE(1) != MC33_SIDE(2), cut2 = MC33_SIDE(3) != MC33_SIDE(2);
@@ -1279,16 +1277,25 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 			oe[o] = entry_join(oa[o], ctx_half_b(c, oa[o], oi[o]));
 		ovb[0] = ovb[3] = svb[0]; ovb[2] = ovb[4] = svb[1]; ovb[5] = svb[2]; ovb[1] = sb.vbase;
 	} else {
-		// first cell of a row segment: the x-1 neighbours live in the previous segment - six plain lookups
+		// first cell of a row segment: the x-1 neighbours are the last cells of the previous segment (ny row segments back) -
+		// six lookups, again in rounds: directory words and bases, then halves A, then halves B
 		const uint32_t odx[6] = {1, 1, 1, 0, 0, 0}, ody[6] = {0, 0, 1, 0, 1, 1}, odz[6] = {1, 0, 0, 1, 0, 1};
+		const uint64_t dz = (uint64_t)c.P.nseg * c.P.ny;
+		uint64_t os[6];
+		uint32_t oxl[6], oi[6];
+		DirWord d[6];
+		EntryA oa[6];
 		for (int o = 0; o < 6; o++) {
-			const uint32_t ox = x - odx[o];
-			const uint64_t os = need[o] ? segment_index(c.P, ox, y - ody[o], z - odz[o]) : (uint64_t)s;
-			const uint32_t oxl = need[o] ? ox % SEG_CELLS : xl;
-			const DirWord d = dir_word(c, os, oxl);
-			ovb[o] = c.seg_base[os].vbase;
-			oe[o] = ctx_entry(c, need[o] ? record_rank(d, oxl) : self_index);
+			os[o] = (uint64_t)s - (need[o] ? odz[o] * dz + ody[o] + (odx[o] ? (uint64_t)c.P.ny : 0ull) : 0ull);
+			oxl[o] = (need[o] && odx[o]) ? SEG_CELLS - 1u : xl;
+			d[o] = dir_word(c, os[o], oxl[o]);
+			ovb[o] = c.seg_base[os[o]].vbase;
 		}
+		for (int o = 0; o < 6; o++) {
+			oi[o] = need[o] ? record_rank(d[o], oxl[o]) : self_index;
+			oa[o] = c.entries_a[oi[o]];
+		}
+		for (int o = 0; o < 6; o++) oe[o] = entry_join(oa[o], ctx_half_b(c, oa[o], oi[o]));
 	}
 	uint32_t ob[6];
 	for (int o = 0; o < 6; o++) ob[o] = ovb[o] + (oe[o].w1 & 0xFFFFu);
