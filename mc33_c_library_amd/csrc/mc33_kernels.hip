@@ -2298,15 +2298,13 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
 	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 64u);
-	// The three emit passes are independent (V/N vs T, fast vs slow records) and each is bound by the
-	// latency of scattered reads, not by bandwidth: the vertex pass runs on a second stream beside the
-	// two triangle passes and joins before the end-of-call event.
-	// Side by side pays from about 700^3 cells up (0.15 instead of 0.18 ms at 768^3); below that the events between
-	// the streams cost more than the overlap gains (64^3: 0.19 -> 0.14 ms per call without them).  MC33_HIP_NO_FORK:
-	// 1 = never, 0 = always, unset = by size.
-	const uint64_t range_cells = (uint64_t)c->P.nx * c->P.ny * (c->range.z_end - c->P.zs);
+	// The three emit passes are independent (V/N vs T, fast vs slow records).  While each of them waited through a chain of
+	// dependent loads (rounds 1 and most of 2) running them side by side on three streams paid on large grids (0.15 instead
+	// of 0.18 ms at 768^3); with the loads of a round trip asked for together they keep the GPU busy by themselves and
+	// one after the other is as fast or faster (C3 tail 0.401 against 0.404 - 0.409 ms, C5 step 15.97 against 16.18 ms), without
+	// the events between the streams.  MC33_HIP_NO_FORK=0 still runs them side by side.
 	const char *fork_env = getenv("MC33_HIP_NO_FORK");
-	const bool fork = fork_env ? !atoi(fork_env) : range_cells >= 300000000ull;
+	const bool fork = fork_env ? !atoi(fork_env) : false;
 	hipStream_t sv = fork ? c->aux : c->stream, ss = fork ? c->aux2 : c->stream;
 	if (fork) {
 		HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
