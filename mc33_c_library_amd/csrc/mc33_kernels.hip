@@ -1149,6 +1149,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 // k_slow_plan: cells the sweep could not finish from the sign index (ambiguous MC33 cases: face and
 // interior tests MC:347-462; cells on the x/y/z = 0 faces; corners equal to the isovalue MC:788-1224)
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_sum(uint64_t x) {
+#pragma unroll
+	for (int d = 32; d; d >>= 1) x += __shfl_xor(x, d);
+	return x;
+}
+
 struct SlowArgs {
 	GridView<sample_t> G;
 	Params P;
@@ -1176,7 +1182,15 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);  // (first: its loads and the one of the cursor below go out together)
 	if (a.ctr->entry_cursor > a.entry_cap) return;  // the sweep will be repeated with more room
 	const uint32_t n = cm.total;
-	if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->slow_cursor = n;  // (for the host's report)
+	if (blockIdx.x == 0) {  // the totals of both lists, for the kernels that follow: their blocks beyond the lists leave at once
+		uint32_t d = 0;
+		for (uint32_t k = threadIdx.x; k < a.lc.n; k += 256u) d += a.lc.dirty_cnt[k];
+		d = (uint32_t)wave_sum((uint64_t)d);
+		__shared__ uint32_t s_dirty[4];
+		if ((threadIdx.x & 63u) == 0) s_dirty[threadIdx.x >> 6] = d;
+		__syncthreads();
+		if (threadIdx.x == 0) { a.ctr->slow_cursor = n; a.ctr->dirty_cursor = s_dirty[0] + s_dirty[1] + s_dirty[2] + s_dirty[3]; }
+	}
 	if (blockIdx.x * 256u >= n) return;             // (nothing for this block: most blocks of most calls)
 	const Tables &tab = a.tab;  // (the tables in LDS instead: tried - flat loads tie the LDS and memory wait counters together; slower)
 	const VRef v{&s_v[0][threadIdx.x], 256};
@@ -1240,11 +1254,11 @@ __global__ __launch_bounds__(256) void k_slow_count(const SlowArgs a) {
 // one thread per row segment that holds slow cells: running offsets of its records, segment totals
 __global__ __launch_bounds__(256) void k_seg_fix(const SlowArgs a) {
 	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+	if (blockIdx.x * 256u >= a.ctr->dirty_cursor) return;  // (k_slow_plan left the total there)
 	ChunkMap cm;
 	cm.build(s_pre, s_red, a.lc.dirty_cnt, a.lc.n);
 	if (a.ctr->entry_cursor > a.entry_cap) return;
 	const uint32_t n = cm.total;
-	if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->dirty_cursor = n;
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
 		const uint32_t gq = cm.group_of(t);
 		const uint32_t s = a.dirty_list[a.slot_base[(uint64_t)gq << a.lc.shift].x + (t - cm.pre[gq])];
@@ -1265,11 +1279,6 @@ __global__ __launch_bounds__(256) void k_seg_fix(const SlowArgs a) {
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t SCAN_PER_THREAD = 8, SCAN_CHUNK = 256 * SCAN_PER_THREAD;
 
-__device__ __forceinline__ uint64_t wave_sum(uint64_t x) {
-#pragma unroll
-	for (int d = 32; d; d >>= 1) x += __shfl_xor(x, d);
-	return x;
-}
 
 // position in sweep order -> storage index, advanced incrementally (one division per thread, not per element)
 struct SweepWalk {
@@ -1456,10 +1465,10 @@ __global__ __launch_bounds__(256) void k_emit_slow(const EmitArgs a) {
 	const VRef v{&s_v[0][threadIdx.x], 256}, w{&s_w[0][threadIdx.x], 256};
 	const URef ids{&s_id[0][threadIdx.x], 256};
 	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+	if (blockIdx.x * 256u >= ctr.slow_cursor) return;  // (k_slow_plan left the total there: most blocks of most calls)
 	ChunkMap cm;
 	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);
 	const uint32_t n = cm.total;
-	if (blockIdx.x * 256u >= n) return;
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
 		const uint32_t gq = cm.group_of(t);
 		emit_cell(c, a.slow_list[a.slot_base[(uint64_t)gq << a.lc.shift].x + (t - cm.pre[gq])], v, w, ids);
