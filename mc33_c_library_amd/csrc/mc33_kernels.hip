@@ -2312,26 +2312,30 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	// of 0.18 ms at 768^3); with the loads of a round trip asked for together they keep the GPU busy by themselves and
 	// one after the other is as fast or faster (C3 tail 0.401 against 0.404 - 0.409 ms, C5 step 15.97 against 16.18 ms), without
 	// the events between the streams.  MC33_HIP_NO_FORK=0 still runs them side by side.
+	// MC33_HIP_NO_FORK: 0 = all three side by side, 1 = all in sequence, unset = the two fast passes in sequence and, on
+	// large grids, the slow one beside them on a second stream: its few blocks wait through long chains of dependent lookups
+	// (34 us for 8 800 cells at C3) and fill nothing - in sequence that is 34 us added to the call, beside the others none.
 	const char *fork_env = getenv("MC33_HIP_NO_FORK");
-	const bool fork = fork_env ? !atoi(fork_env) : false;
-	hipStream_t sv = fork ? c->aux : c->stream, ss = fork ? c->aux2 : c->stream;
-	if (fork) {
+	const uint64_t range_cells = (uint64_t)c->P.nx * c->P.ny * (c->range.z_end - c->P.zs);
+	const bool fork_all = fork_env && !atoi(fork_env);
+	const bool fork_slow = fork_all || (!fork_env && range_cells >= 300000000ull);  // (small grids: the events cost more than they gain)
+	hipStream_t sv = fork_all ? c->aux : c->stream, ss = fork_slow ? c->aux2 : c->stream;
+	if (fork_slow) {
 		HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-		HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+		if (fork_all) HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
 		HIP_TRY(hipStreamWaitEvent(c->aux2, c->ev_fork, 0));
 	}
-	// the vertex pass is the longest of the three: it goes on the context's own stream (first), so that the
-	// end-of-call event follows it directly and the two joins find their streams already idle
+	if (fork_slow) {  // (first: it is the one with the long chains)
+		hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, ss, a);
+		HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
+	}
 	hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);
 	hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, sv, a);
-	if (fork) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
-	hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, ss, a);
-	if (fork) HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
+	if (fork_all) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
+	if (!fork_slow) hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, ss, a);
 	HIP_TRY(hipGetLastError());
-	if (fork) {
-		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
-	}
+	if (fork_all) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+	if (fork_slow) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
 	if (c->timing_level > 0) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
 	c->emit_pending = true;
 	return 0;
