@@ -263,10 +263,16 @@ MC33_HD int interior_test(int s, int flag13, const V &v) {  // MC:431-462
 // table word -> offset of the triangle pattern; the walk starts at offset+1 (MC:781).
 // m,n: which of the first two triangle slots is written first (winding, MC:683-691, 1249)
 template <typename V>
+MC33_HD uint32_t pattern_offset_word(uint32_t c, uint32_t i, const V &v, uint32_t &m, uint32_t &n);
+template <typename V>
 MC33_HD uint32_t pattern_offset(const uint16_t *lut, uint32_t i, const V &v, uint32_t &m, uint32_t &n) {
-	uint32_t c;
-	if (i & 0x80) { c = lut[i ^ 0xFF]; m = (c & 0x800) == 0; n = !m; }
-	else { c = lut[i]; n = (c & 0x800) == 0; m = !n; }
+	return pattern_offset_word(lut[(i & 0x80) ? (i ^ 0xFF) : i], i, v, m, n);
+}
+// (c: the table word of the sign index, tables[i] or tables[i ^ 0xFF] for i >= 128)
+template <typename V>
+MC33_HD uint32_t pattern_offset_word(uint32_t c, uint32_t i, const V &v, uint32_t &m, uint32_t &n) {
+	if (i & 0x80) { m = (c & 0x800) == 0; n = !m; }
+	else { n = (c & 0x800) == 0; m = !n; }
 	const uint32_t k = c & 0x7FF, ci = m ? i : i ^ 0xFF;
 	switch (c >> 12) {
 	case 0: return k;                                                                    // cases 1,2,5,8,9,11,14

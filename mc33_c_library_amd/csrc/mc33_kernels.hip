@@ -163,7 +163,7 @@ struct SweepArgs {
 static void fast_record_table(const uint32_t *fast, uint4 *out) {
 	for (uint32_t i = 0; i < 256; i++) {
 		const uint32_t f = fast[i];
-		if (f == FAST_NONE) { out[i] = uint4{FAST_NONE, 0, 0, 0}; continue; }
+		if (f == FAST_NONE) { out[i] = uint4{FAST_NONE, mc33_lut[(i & 0x80) ? (i ^ 0xFF) : i], 0, 0}; continue; }  // (y: its table word, for corner_look)
 		const Entry e = make_fast_entry(0, i, f, 0, 0);
 		out[i] = uint4{e.w0, e.w2, e.w3, ((f >> 16) & 15u) | ((f >> 12) & 15u) << 8};
 	}
@@ -878,8 +878,8 @@ struct CellsArgs {
 	SegDir *seg_dir;
 	EntryA *entries_a;       // work records, half A
 	EntryB *entries_b;       // ... half B: written here for TESTED cells, by k_slow_plan for slow ones, never for fast ones
-	const uint16_t *lut;     // the reference's table and what an interior cell makes of each pattern (build_pattern_info):
-	const uint32_t *pat;     // for the cells whose sign index needs the face / interior tests
+	const uint32_t *pat;     // what an interior cell makes of each pattern of the reference's table (build_pattern_info): for the
+	                         // cells whose sign index needs the face / interior tests (their table word rides in `fast`)
 	uint32_t *entry_seg;
 	uint32_t *slow_list, *dirty_list;
 	ListChunks lc;
@@ -915,7 +915,7 @@ struct CellsLds {            // per wave
 
 // The 8 samples of one cell: {0xFFFFFFFF, 0} if one of them equals the isovalue; else, for a sign index i that needs the
 // face / interior tests (i = 0: none wanted), {offset of the pattern the tests choose, its pattern-info word}.
-__device__ __forceinline__ uint2 corner_look(const GridView<sample_t> &G, real_t iso, const uint16_t *lut, const uint32_t *pat,
+__device__ __forceinline__ uint2 corner_look(const GridView<sample_t> &G, real_t iso, uint32_t lut_word, const uint32_t *pat,
                                                         uint32_t x, uint32_t y, uint32_t z, uint32_t i) {
 	Corner8 v;
 	bool zero = false;
@@ -928,7 +928,7 @@ __device__ __forceinline__ uint2 corner_look(const GridView<sample_t> &G, real_t
 	if (zero) return uint2{0xFFFFFFFFu, 0u};
 	if (!i) return uint2{0u, 0u};
 	uint32_t wm, wn;
-	const uint32_t poff = pattern_offset(lut, i, v, wm, wn);
+	const uint32_t poff = pattern_offset_word(lut_word, i, v, wm, wn);  // (the word came with the LDS table entry: no load of its own)
 	return uint2{poff, pat[poff]};
 }
 
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 		if (__ballot(look || amb)) {  // wave-uniform
 #endif
 			if (look || amb) {
-				const uint2 t = corner_look(a.G, P.iso, a.lut, a.pat, xbase + xl, y0 + r, z, amb ? i : 0u);
+				const uint2 t = corner_look(a.G, P.iso, f.y, a.pat, xbase + xl, y0 + r, z, amb ? i : 0u);
 				zero_corner = t.x == 0xFFFFFFFFu;
 				if (!zero_corner) { tpoff = t.x; tinfo = t.y; }
 			}
@@ -2146,7 +2146,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	ca.dev = env_u32("MC33_HIP_CELLS_DEV", 0);
 #endif
 	ca.G.p = c->d_grid; ca.G.pitch = (uint32_t)c->pitch; ca.G.z0 = c->desc.plane0; ca.G.slice = c->slice;
-	ca.P = P; ca.fast = c->d_fast; ca.lut = c->d_lut; ca.pat = c->d_pat;
+	ca.P = P; ca.fast = c->d_fast; ca.pat = c->d_pat;
 	ca.ze = ze; ca.nYT = g.nYT; ca.nseg_pad = g.nseg;
 	ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.plane_fmt = L.plane_fmt; ca.slot_base = c->slot_base;
 	ca.epoch = L.epoch;
