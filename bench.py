@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", default=os.environ.get("MC33_BENCH_NO_CPU", "0") == "1")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("MC33_BENCH_CPU_N", "0")),
                     help="planes (c5) / points per axis (c3) of the sub-grid the CPU reference is timed on")
+    ap.add_argument("--rank-timeout", type=int, default=int(os.environ.get("MC33_BENCH_RANK_TIMEOUT", "1500")),
+                    help="self-launched N > 1 runs: seconds after which the parent kills ranks that have not finished and exits non-zero")
     return ap.parse_args()
 
 
@@ -57,23 +59,58 @@ def parse():
 # parent of a self-launched multi-GPU run: no torch import, no GPU call
 # ---------------------------------------------------------------------------------------------------------
 def launch_ranks(args):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
+    """Starts the N rank processes (fresh children: this parent never touches the GPU and never re-execs), forwards rank 0's
+    JSON line.  Every rank writes its stdout / stderr to a log file of its own (MC33_BENCH_LOG_DIR, default a temporary
+    directory; the tail of a failed or stuck rank's log is printed), and the whole run has a time limit (--rank-timeout)
+    after which the ranks' process groups are killed and the parent exits non-zero: a rank stuck in a collective must
+    not hold the lease until somebody else kills it."""
+    import signal
+    import tempfile
+    # The rendezvous port: bound here with SO_REUSEADDR and kept bound until the children have been started, so that no other
+    # process on a shared box is handed the same port in between; rank 0's TCPStore sets SO_REUSEADDR too and binds it
+    # the moment this socket closes.
+    sock = socket.socket()
+    sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    logdir = os.environ.get("MC33_BENCH_LOG_DIR") or tempfile.mkdtemp(prefix="mc33_bench_ranks_")
+    os.makedirs(logdir, exist_ok=True)
+    procs, logs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # (this pool's host driver supports only dmabuf IPC: without this RCCL's and torch's cross-process device-memory
+        # handles fail with "hipIpcGetMemHandle: invalid argument" - it is exported in the image already, DESIGN.md 6)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = None
+        out = open(os.path.join(logdir, "rank%d.out" % r), "w+")
+        err = open(os.path.join(logdir, "rank%d.err" % r), "w+")
+        logs.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err,
+                                      start_new_session=True))
+    sock.close()
+
+    def tail(f, n=3000):
+        f.flush()
+        f.seek(0, os.SEEK_END)
+        size = f.tell()
+        f.seek(max(0, size - n))
+        return f.read()
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+        for p in procs:
+            p.wait()
+
+    deadline = time.monotonic() + args.rank_timeout
     failed = None
     alive = list(range(args.gpus))
     while alive and failed is None:
         for r in list(alive):
-            if r == 0 and out0 is None and procs[0].poll() is not None:
-                out0 = procs[0].stdout.read()
             rc = procs[r].poll()
             if rc is None:
                 continue
@@ -82,18 +119,28 @@ def launch_ranks(args):
                 failed = (r, rc)
                 break
         if alive and failed is None:
+            if time.monotonic() > deadline:
+                failed = (alive[0], None)
+                break
             time.sleep(0.05)
-    if failed is not None:  # a rank died: the others would wait in a collective for ever
-        for r in alive:
-            procs[r].kill()
-        for p in procs:
-            p.wait()
-        sys.stderr.write("bench.py: rank %d exited with code %d\n" % failed)
+    if failed is not None:  # a rank died or the run is stuck: the others would wait in a collective for ever
+        kill_all()
+        if failed[1] is None:
+            sys.stderr.write("bench.py: no result after --rank-timeout %d s, ranks %s still running: killed (logs in %s)\n" % (args.rank_timeout, alive, logdir))
+        else:
+            sys.stderr.write("bench.py: rank %d exited with code %d (logs in %s)\n" % (failed[0], failed[1], logdir))
+        for r in sorted(set([failed[0]] + alive))[:4]:
+            sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (r, tail(logs[r][1])))
         return 1
-    if out0 is None:
-        out0 = procs[0].stdout.read()
+    logs[0][0].flush()
+    logs[0][0].seek(0)
+    out0 = logs[0][0].read()
     sys.stdout.write(out0)
     sys.stdout.flush()
+    for r in range(args.gpus):  # what the ranks said on stderr (verification lines, warnings) goes to the parent's stderr
+        logs[r][1].flush()
+        logs[r][1].seek(0)
+        sys.stderr.write(logs[r][1].read())
     return 0 if any(line.startswith("{") for line in out0.splitlines()) else 1
 
 

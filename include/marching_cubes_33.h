@@ -146,6 +146,12 @@ void adjustvectorlenght_s(surface *s);                           /* shrink the a
  * Returns the number of surfaces produced. */
 unsigned calculate_isosurfaces(MC33 *extractor, const MC33_real *isovalues, unsigned count, surface **out);
 
+/* extension (not in the reference): the caller has rewritten samples of the grid `extractor` was created from.  The
+ * reference reads G->F anew on every call (source/marching_cubes_33.c:1792, 1832-1868); this library keeps a copy in
+ * HBM, and uploads G->F again before the next extraction after this call.  (MC33_HIP_REUPLOAD=1 in the environment does
+ * that before EVERY extraction, for callers that cannot be changed.) */
+void MC33_grid_changed(MC33 *extractor);
+
 /* ---- inclined grids (reference header :186-191) ---------------------------------------------------------
  * c = A b (transposed == 0) or A^T b for a 3x3 matrix; _multTSA_bf assumes an upper triangular A.  A caller may
  * point mult_Abf at either; calculate_isosurface looks at the pointer when it is called and runs the matching

@@ -119,6 +119,10 @@ int mc33hip_extract(mc33hip_ctx *c, double iso, const mc33hip_range *range, void
  * or 2 (per pass) in the environment - the event records cost about 20 us per call.  Waits for a pending mc33hip_emit. */
 int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t);
 
+/* Switches the hipEvent timing of the context at run time (0, 1, 2 as MC33_HIP_TIMING, which only sets the level a context
+ * starts with).  bench.py times its steps at level 2 - the events are recorded, never waited for - and once more at 0. */
+int mc33hip_set_timing(mc33hip_ctx *c, int level);
+
 /* Waits until everything enqueued on the context's stream (mc33hip_emit in particular) has finished.  Needed before
  * the output buffers are read by anything that is not ordered after that stream - mc33hip_download_concurrent, another
  * stream, another process. */

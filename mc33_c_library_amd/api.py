@@ -35,12 +35,12 @@ class Timing(C.Structure):
 HIP_API = ["mc33hip_set_id_base", "mc33hip_create", "mc33hip_destroy", "mc33hip_last_error", "mc33hip_upload_rows",
            "mc33hip_upload_contiguous", "mc33hip_adopt_device", "mc33hip_set_stream", "mc33hip_count",
            "mc33hip_emit", "mc33hip_extract", "mc33hip_last_timing", "mc33hip_download",
-           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many", "mc33hip_set_normal_neg", "mc33hip_sweep_many"]
+           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many", "mc33hip_set_normal_neg", "mc33hip_sweep_many", "mc33hip_set_timing"]
 REFERENCE_API = ["create_MC33", "calculate_isosurface", "size_of_isosurface", "free_MC33", "free_surface_memory",
                  "adjustvectorlenght_s", "DefaultColorMC", "free_memory_grd", "alloc_F", "grid_from_data_pointer",
                  "generate_grid_from_fn", "_multTSA_bf", "_multA_bf", "mult_Abf",
                  "write_bin_s", "read_bin_s", "write_txt_s", "write_obj_s", "write_ply_s",
-                 "read_grd", "read_grd_binary", "read_scanfiles", "read_raw_file", "read_dat_file", "calculate_isosurfaces"]
+                 "read_grd", "read_grd_binary", "read_scanfiles", "read_raw_file", "read_dat_file", "calculate_isosurfaces", "MC33_grid_changed"]
 
 
 class MC33Error(RuntimeError):
@@ -90,6 +90,7 @@ def load_library(dtype="f32"):
     lib.mc33hip_set_inclined.argtypes = [V, V, V, C.c_int]
     lib.mc33hip_set_normal_neg.argtypes = [V, C.c_int]
     lib.mc33hip_sweep_many.argtypes = [V, P(C.c_double), C.c_int, P(Range)]
+    lib.mc33hip_set_timing.argtypes = [V, C.c_int]
     _libs[dtype] = lib
     return lib
 
@@ -126,12 +127,19 @@ class DeviceGrid:
         desc = GridDesc(npx, npy, npz, plane0, (nz_total if nz_total is not None else npz - 1),
                         (C.c_double * 3)(*r0), (C.c_double * 3)(*d), sb, tensor.device.index)
         self.desc = desc
-        os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvent timing for timing(); off by default in the library
         self.ctx = C.c_void_p()
         _check(self.lib, self.lib.mc33hip_create(C.byref(self.ctx), C.byref(desc)))
+        # per-pass hipEvent timing for timing(): events are recorded on the stream, never waited for (off by default in
+        # the library; MC33_HIP_TIMING in the environment overrides)
+        if "MC33_HIP_TIMING" not in os.environ:
+            self.set_timing(2)
         _check(self.lib, self.lib.mc33hip_adopt_device(self.ctx, C.c_void_p(tensor.data_ptr()), pitch, tensor.stride(0)))
         self.device = tensor.device
         self.use_stream(torch.cuda.current_stream(self.device))
+
+    def set_timing(self, level):
+        """0: no events (the production path), 1: whole call, 2: per pass (timing() then reports sweep / scan / emit)."""
+        _check(self.lib, self.lib.mc33hip_set_timing(self.ctx, int(level)))
 
     def use_stream(self, stream):
         self.stream = stream

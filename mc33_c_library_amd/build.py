@@ -3,7 +3,8 @@
     mc33_c_library_amd/libMC33_<type>.so        <type> = f32 (float), f64 (double, -DGRD_TYPE_SIZE=8), u8 / u16 / u32
                                                 (-DINTEGER_GRD -DGRD_TYPE_SIZE=1 / 2 / 4)
     mc33_c_library_amd/libMC33_<type>_ortho.so  the same kernels, host layer compiled with -DGRD_ORTHOGONAL
-    mc33_c_library_amd/libMC33_<type>_nneg.so   ... with -DMC33_NORMAL_NEG=1 (front and back exchanged; f32 and u16)
+    mc33_c_library_amd/libMC33_<type>_nneg.so   ... with -DMC33_NORMAL_NEG=1 (front and back exchanged), every type;
+    mc33_c_library_amd/libMC33_<type>_ortho_nneg.so  both switches
 
 One library per grid sample type and per compile-time switch of the reference's header, like the reference's
 one-type-per-compile model (reference include/marching_cubes_33.h:57-88, source/libMC33.c:17-28).  hipcc cross-compiles
@@ -38,12 +39,14 @@ VARIANTS = {
 }
 
 
-def lib_path(dtype, ortho=False, nneg=False):
+def lib_path(dtype, ortho=False, nneg=False):  # (both: libMC33_<type>_ortho_nneg.so)
     """ortho: the GRD_ORTHOGONAL flavour of the C API (structs without the inclined-grid members); nneg: MC33_NORMAL_NEG."""
     return os.path.join(PKG, "libMC33_%s%s%s.so" % (dtype, "_ortho" if ortho else "", "_nneg" if nneg else ""))
 
 
-NNEG_TYPES = ("f32", "u16")
+# The reference's switch applies to every GRD_data_type (reference source/libMC33.c:20-22, marching_cubes_33.c:509-513,
+# 1246-1250): every type has the flavour, alone and together with GRD_ORTHOGONAL.
+NNEG_TYPES = ("f32", "u16", "u8", "u32", "f64")
 
 
 def _newer(target, deps):
@@ -96,17 +99,18 @@ def build(dtype, force=False, verbose_resources=False):
     oout = lib_path(dtype, ortho=True)
     if relink or _newer(oout, oobjs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + oobjs + ["-o", oout])
-    if dtype in NNEG_TYPES:  # MC33_NORMAL_NEG flavour: only mc33_capi.c looks at the switch
-        nobjs, relink = list(objs), force
-        src = os.path.join(CSRC, "mc33_capi.c")
-        obj = os.path.join(BUILD, "mc33_capi_%s_nneg.o" % dtype)
-        if force or _newer(obj, [src] + incs):
-            _run([GCC] + C_FLAGS + var["c"] + ["-DMC33_NORMAL_NEG=1", "-c", src, "-o", obj])
-            relink = True
-        nobjs[1 + C_SOURCES.index("mc33_capi.c")] = obj
-        nout = lib_path(dtype, nneg=True)
-        if relink or _newer(nout, nobjs):
-            _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + nobjs + ["-o", nout])
+    if dtype in NNEG_TYPES:  # MC33_NORMAL_NEG flavours: only mc33_capi.c looks at the switch
+        for ortho, base in ((False, objs), (True, oobjs)):
+            nobjs, relink = list(base), force
+            src = os.path.join(CSRC, "mc33_capi.c")
+            obj = os.path.join(BUILD, "mc33_capi_%s%s_nneg.o" % (dtype, "_ortho" if ortho else ""))
+            if force or _newer(obj, [src] + incs):
+                _run([GCC] + C_FLAGS + var["c"] + (["-DGRD_ORTHOGONAL"] if ortho else []) + ["-DMC33_NORMAL_NEG=1", "-c", src, "-o", obj])
+                relink = True
+            nobjs[1 + C_SOURCES.index("mc33_capi.c")] = obj
+            nout = lib_path(dtype, ortho=ortho, nneg=True)
+            if relink or _newer(nout, nobjs):
+                _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + nobjs + ["-o", nout])
     return out
 
 

@@ -64,6 +64,7 @@ typedef struct {
 		unsigned long long capV, capT;
 	} set[2];
 	int reupload;
+	int grid_dirty;      /* MC33_grid_changed: the caller rewrote samples of G->F, upload them before the next extraction */
 	int inclined;        /* G->nonortho at create time: the MC33_spnC store */
 	double grd_A[9], grd_Ai[9];
 } mc33_private;
@@ -171,9 +172,19 @@ static int refresh_grid(mc33_private *p) {
 		if (mc33hip_set_inclined(p->ctx, p->grd_A, p->grd_Ai, mult_Abf == _multTSA_bf) != MC33HIP_OK)
 			return MC33HIP_EINVAL;
 	}
-	if (!p->reupload)
+	if (!p->reupload && !p->grid_dirty)
 		return 0;
+	p->grid_dirty = 0;
 	return mc33hip_upload_rows(p->ctx, (const void *const *const *)p->grid->F);
+}
+
+/* Extension (not in the reference, which reads G->F anew on every call, MC:1792, 1832-1868): tells the extractor that
+ * samples of the grid it was created from have been rewritten.  The next size_of_isosurface / calculate_isosurface(s)
+ * uploads G->F again first.  The _GRD and its rows must still be alive then, as for the reference's own M->F. */
+void MC33_grid_changed(MC33 *M) {
+	mc33_private *p = priv(M);
+	if (p)
+		p->grid_dirty = 1;
 }
 
 unsigned long long size_of_isosurface(MC33 *M, MC33_real iso, unsigned int *nV, unsigned int *nT) {
@@ -431,7 +442,7 @@ unsigned int calculate_isosurfaces(MC33 *M, const MC33_real *iso, unsigned int n
 			mc33hip_range r;
 			r.z_begin = 0; r.z_end = M->nz; r.ghost_below = 0; r.id_base = 0;
 			for (unsigned int q = 0; q != m; q++) many[q] = iso[k + q];
-			if (!p->reupload)
+			if (!p->reupload) /* (the re-upload of every call would drop the sweeps made ahead) */
 				(void)mc33hip_sweep_many(p->ctx, many, (int)m, &r); /* (on failure the single calls sweep for themselves) */
 		}
 		/* surface k is computed into set k&1 while the helper thread copies surface k-1 out of the other set */

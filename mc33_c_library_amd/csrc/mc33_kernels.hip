@@ -1497,6 +1497,7 @@ static void set_err(const char *fmt, ...) {
 
 // Per-isovalue output of the sweep (SweepLane) and its bookkeeping on the host
 constexpr int MC33_LANES = 8;
+constexpr int MC33_MANY_PASSES = 4;  // passes of one mc33hip_sweep_many call: 8 isovalues = 4 + 4, 7 = 4 + 2 + 1
 struct IsoLane {
 	SliceHeader *slice_hdr;   // one record per (wave tile, cell slice) of the sweep
 	uint4 *slice_bits;
@@ -1507,9 +1508,10 @@ struct IsoLane {
 	uint32_t epoch;           // extractions since the slice headers were last cleared
 	// a sweep made ahead of time by mc33hip_sweep_many, waiting for the count / extract call of its isovalue
 	bool swept, boundary_done;
+	bool tail_pending;        // a sweep has added this lane's slices into slot_part and no tail (k_slots) has consumed them yet
 	double iso;
 	mc33hip_range range;
-	float sweep_ms;           // its share of the sweep's time
+	int many_pass, many_ni;   // which pass of mc33hip_sweep_many filled it (its events), and how many isovalues that pass classified
 };
 
 struct mc33hip_ctx {
@@ -1551,7 +1553,7 @@ struct mc33hip_ctx {
 	uint32_t resident_blocks; // k_sweep blocks the device holds at once
 	Counters *d_ctr, *h_ctr;
 	hipEvent_t ev[4];
-	hipEvent_t ev_many[2];    // mc33hip_sweep_many's pass timing
+	hipEvent_t ev_many[MC33_MANY_PASSES][2];  // mc33hip_sweep_many's passes: recorded around each, read in read_timing (nobody waits)
 	hipStream_t aux, aux2;    // the triangle pass and the slow-record pass run beside the vertex pass
 	hipStream_t copy;         // mc33hip_download_concurrent
 	hipEvent_t ev_fork, ev_join, ev_join2;
@@ -1670,7 +1672,7 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	CREATE_TRY(hipMalloc(&c->list_cnt, 2 * LIST_CHUNKS * sizeof(uint32_t)));
 	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
 	for (int k = 0; k < 4; k++) CREATE_TRY(hipEventCreate(&c->ev[k]));
-	for (int k = 0; k < 2; k++) CREATE_TRY(hipEventCreate(&c->ev_many[k]));
+	for (int k = 0; k < MC33_MANY_PASSES; k++) { CREATE_TRY(hipEventCreate(&c->ev_many[k][0])); CREATE_TRY(hipEventCreate(&c->ev_many[k][1])); }
 	CREATE_TRY(pool_take(c->device, &c->aux));
 	CREATE_TRY(pool_take(c->device, &c->aux2));
 	CREATE_TRY(pool_take(c->device, &c->copy));
@@ -1707,7 +1709,8 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	if (c->aux2) (void)hipStreamSynchronize(c->aux2);
 	if (c->copy) (void)hipStreamSynchronize(c->copy);
 	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
-	for (int k = 0; k < 2; k++) if (c->ev_many[k]) (void)hipEventDestroy(c->ev_many[k]);
+	for (int k = 0; k < MC33_MANY_PASSES; k++)
+		for (int j = 0; j < 2; j++) if (c->ev_many[k][j]) (void)hipEventDestroy(c->ev_many[k][j]);
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
@@ -1990,6 +1993,9 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 			below[planned[b].col] = b;
 		}
 	}
+	// A sweep made ahead by mc33hip_sweep_many may still be reading the old plan: the copies below go through the null stream,
+	// which a non-blocking stream (any torch.cuda.Stream) is not ordered with
+	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (c->tiles_cap < tiles.size()) {
 		(void)hipFree(c->d_tiles);
 		c->d_tiles = nullptr; c->tiles_cap = 0;
@@ -2041,6 +2047,7 @@ static int begin_lane(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g, hipStream_t
 		HIP_TRY(hipMemsetAsync(L.slice_hdr, 0, g.nslots * sizeof(SliceHeader), st));
 		HIP_TRY(hipMemsetAsync(L.slot_part, 0, 2 * part_bytes, st));
 		L.epoch = 0;
+		L.tail_pending = false;
 		L.slice_cap = g.nslots;
 	}
 	if (L.edge_cap < c->ntiles) {
@@ -2056,6 +2063,14 @@ static int begin_lane(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g, hipStream_t
 		HIP_TRY(hipMemsetAsync(L.slice_hdr, 0, L.slice_cap * sizeof(SliceHeader), st));
 		HIP_TRY(hipMemsetAsync(L.slot_part, 0, 2 * nchunks * 8, st));
 		L.epoch = 1;
+	}
+	if (L.tail_pending) {
+		// The sweep before this one added its slices into the half its epoch selected, and no k_slots ever consumed them and
+		// cleared the other half for this epoch (a sweep made ahead by mc33hip_sweep_many whose isovalue was never asked for,
+		// the grid was re-uploaded, a call failed in between): the half this epoch accumulates into still holds the sums of
+		// two extractions ago.  Start from clean sums.
+		HIP_TRY(hipMemsetAsync(L.slot_part, 0, 2 * nchunks * 8, st));
+		L.tail_pending = false;
 	}
 	L.swept = false;
 	L.boundary_done = false;
@@ -2172,6 +2187,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	ca.lc = c->lc;
 	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK)), dim3(256), 0, st, L.slice_hdr, lane_part(L, false), lane_part(L, true),
 	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr, c->lc);
+	L.tail_pending = false;  // k_slots has read this epoch's partial sums and cleared the half of the next one
 	hipLaunchKernelGGL(k_cells, dim3((uint32_t)g.cell_blocks), dim3(256), 0, st, ca);
 	SlowArgs sa;
 	sa.G = a.G; sa.P = P;
@@ -2193,6 +2209,9 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	return 0;
 }
 
+// the isovalue a lane was swept for, compared by bit pattern: +0.0 and -0.0 compare equal but classify samples equal to
+// them differently (v = iso - F = -0 is "zero AND negative", Params::negzero_iso), and a NaN is the same NaN
+static bool same_bits(real_t a, real_t b) { return memcmp(&a, &b, sizeof a) == 0; }
 static bool same_range(const mc33hip_range &x, const mc33hip_range &y) {
 	return x.z_begin == y.z_begin && x.z_end == y.z_end && (x.ghost_below != 0) == (y.ghost_below != 0);
 }
@@ -2209,7 +2228,7 @@ static int enqueue_count(mc33hip_ctx *c, bool rerun = false) {
 	if (rerun && c->cur_lane && c->lane_presweeped) L = c->cur_lane;  // same call, more room for records: the sweep's result stands
 	else
 		for (int k = 0; k < MC33_LANES && !L; k++)
-			if (c->lanes[k].swept && (real_t)c->lanes[k].iso == P.iso && same_range(c->lanes[k].range, c->range) &&
+			if (c->lanes[k].swept && same_bits((real_t)c->lanes[k].iso, P.iso) && same_range(c->lanes[k].range, c->range) &&
 			    c->lanes[k].slice_cap >= g.nslots && c->lanes[k].edge_cap >= c->ntiles)
 				L = &c->lanes[k];
 	if (c->timing_level > 0) HIP_TRY(hipEventRecord(c->ev[0], st));
@@ -2243,6 +2262,7 @@ static int enqueue_count(mc33hip_ctx *c, bool rerun = false) {
 		// nothing is cleared between extractions: headers carry the epoch, k_slots resets the counters and the
 		// partial sums of the next call, k_cells writes every row segment count of the range
 		launch_sweep_ni<1>(c, a, st);
+		L->tail_pending = true;
 		HIP_TRY(hipGetLastError());
 	}
 	c->cur_lane = L;
@@ -2259,7 +2279,7 @@ static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n) {
 	if (int rc = plan_sweep(c, c->P.zs, c->range.z_end)) return rc;
 	SlotGeom g;
 	if (int rc = slot_geometry(c, g)) return rc;
-	int k = 0;
+	int k = 0, pass = 0;
 	while (k < n) {
 		const int ni = (n - k >= 4) ? 4 : (n - k >= 2) ? 2 : 1;
 		SweepArgs a;
@@ -2269,23 +2289,21 @@ static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n) {
 			if (int rc = begin_lane(c, L, g, st)) return rc;
 			set_lane(a, q, L, isos[k + q]);
 		}
-		hipEvent_t e0 = c->ev_many[0], e1 = c->ev_many[1];
-		if (c->timing_level > 0) HIP_TRY(hipEventRecord(e0, st));
+		// (events around the pass are only recorded; read_timing asks for the elapsed time when the lane is consumed)
+		const bool timed = c->timing_level > 0 && pass < MC33_MANY_PASSES;
+		if (timed) HIP_TRY(hipEventRecord(c->ev_many[pass][0], st));
 		if (ni == 4) launch_sweep_ni<4>(c, a, st);
 		else if (ni == 2) launch_sweep_ni<2>(c, a, st);
 		else launch_sweep_ni<1>(c, a, st);
 		HIP_TRY(hipGetLastError());
-		float ms = 0.f;
-		if (c->timing_level > 0) {  // (developer timing only: waits for the pass)
-			HIP_TRY(hipEventRecord(e1, st));
-			HIP_TRY(hipEventSynchronize(e1));
-			(void)hipEventElapsedTime(&ms, e0, e1);
-		}
+		if (timed) HIP_TRY(hipEventRecord(c->ev_many[pass][1], st));
 		for (int q = 0; q < ni; q++) {
 			IsoLane &L = c->lanes[k + q];
-			L.swept = true; L.iso = isos[k + q]; L.range = c->range; L.sweep_ms = ms / (float)ni;
+			L.swept = true; L.tail_pending = true; L.iso = isos[k + q]; L.range = c->range;
+			L.many_pass = timed ? pass : -1; L.many_ni = ni;
 		}
 		k += ni;
+		pass++;
 	}
 	return 0;
 }
@@ -2392,9 +2410,15 @@ static void read_timing(mc33hip_ctx *c, bool with_emit, unsigned launches) {
 	}
 	if (c->timing_level > 0 && with_emit) (void)hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[3]);
 	else if (c->timing_level > 1) (void)hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[2]);
-	if (c->lane_presweeped && c->cur_lane && c->timing_level > 0) {  // the sweep was made ahead of time, NI isovalues per pass: its share
-		t.sweep_ms += c->cur_lane->sweep_ms;
-		t.total_ms += c->cur_lane->sweep_ms;
+	if (c->lane_presweeped && c->cur_lane && c->timing_level > 0 && c->cur_lane->many_pass >= 0) {
+		// the sweep was made ahead of time, NI isovalues per pass: its share.  (The pass lies before this call's work on the same
+		// stream, which fetch_counters has waited for: its events are complete)
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, c->ev_many[c->cur_lane->many_pass][0], c->ev_many[c->cur_lane->many_pass][1]) == hipSuccess) {
+			ms /= (float)c->cur_lane->many_ni;
+			t.sweep_ms += ms;
+			t.total_ms += ms;
+		}
 	}
 }
 
@@ -2444,6 +2468,12 @@ extern "C" int mc33hip_set_normal_neg(mc33hip_ctx *c, int on) {
 	if (!c) return MC33HIP_EINVAL;
 	c->normal_neg = on != 0;
 	c->counted = false;
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_set_timing(mc33hip_ctx *c, int level) {
+	if (!c || level < 0 || level > 2) return MC33HIP_EINVAL;
+	c->timing_level = level;
 	return MC33HIP_OK;
 }
 

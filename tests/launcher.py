@@ -7,6 +7,7 @@ The helper itself never imports torch or any HIP library.
 """
 import json
 import os
+import signal
 import subprocess
 import sys
 
@@ -18,12 +19,20 @@ def serve():
         env.update(req.get("env") or {})
         for k in req.get("unset") or []:
             env.pop(k, None)
+        # The command gets a process group of its own: on a timeout the whole group is killed - the rank grandchildren of a
+        # torch.distributed.run or a bench.py parent too, which would otherwise stay blocked in a collective holding cuda:0
+        # while the tests that follow hang or run out of memory instead of reporting the timeout.
+        p = subprocess.Popen(req["cmd"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=req.get("cwd"), start_new_session=True)
         try:
-            p = subprocess.run(req["cmd"], env=env, capture_output=True, text=True, timeout=req.get("timeout", 600), cwd=req.get("cwd"))
-            out = {"rc": p.returncode, "stdout": p.stdout[-20000:], "stderr": p.stderr[-20000:]}
-        except subprocess.TimeoutExpired as e:
-            out = {"rc": -999, "stdout": (e.stdout or b"").decode(errors="replace")[-20000:] if isinstance(e.stdout, bytes) else (e.stdout or ""),
-                   "stderr": "timeout after %s s" % req.get("timeout", 600)}
+            so, se = p.communicate(timeout=req.get("timeout", 600))
+            out = {"rc": p.returncode, "stdout": so[-20000:], "stderr": se[-20000:]}
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            so, se = p.communicate()
+            out = {"rc": -999, "stdout": (so or "")[-20000:], "stderr": (se or "")[-19000:] + "\ntimeout after %s s (process group killed)" % req.get("timeout", 600)}
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
 

@@ -91,11 +91,14 @@ def test_surface_helpers_without_gpu():
 
 
 @pytest.mark.parametrize("dtype", ["f32", "u16", "u8", "u32", "f64"])
-def test_orthogonal_flavour_exports_the_same_api(dtype):
-    lib = C.CDLL(product_path(dtype, ortho=True))
+def test_every_flavour_exports_the_same_api(dtype):
+    """GRD_ORTHOGONAL, MC33_NORMAL_NEG and both together (reference include/marching_cubes_33.h:59, source/libMC33.c:20-22):
+    one library per combination and sample type, all with the full API."""
     from mc33_c_library_amd import HIP_API, REFERENCE_API
-    for n in HIP_API + REFERENCE_API:
-        assert hasattr(lib, n), n
+    for ortho, nneg in ((True, False), (False, True), (True, True)):
+        lib = C.CDLL(product_path(dtype, ortho=ortho, nneg=nneg))
+        for n in HIP_API + REFERENCE_API:
+            assert hasattr(lib, n), (n, ortho, nneg)
 
 
 CALLER = r"""

@@ -165,4 +165,70 @@ def test_sweep_many_equals_single_sweeps(reflibs, dtype):
     g2 = DeviceGrid(t)
     V2, N2, T2, c2 = g2.extract(isos[1], rng)
     assert (c1.nV, c1.nT) == (c2.nV, c2.nT) and torch.equal(T1, T2) and torch.equal(V1.view(torch.int32), V2.view(torch.int32))
-    assert c0.nV == reflibs[dtype].isosurface(data, isos[1]).nV
+    # the whole-volume call reused lane 0, whose sweep over the slab was never consumed: the arrays, not only the count
+    ref = reflibs[dtype].isosurface(data, isos[1])
+    assert (c0.nV, c0.nT) == (ref.nV, ref.nT)
+    assert np.array_equal(T0.cpu().numpy().view(np.uint32), ref.T) and beq(V0.cpu().numpy(), ref.V)
+    nan = np.isnan(ref.N)
+    assert np.array_equal(N0.cpu().numpy()[~nan].view(np.uint32), ref.N[~nan].view(np.uint32))
+
+
+def _same_as_reference(got, ref, what):
+    V, N, T, cnt = got
+    assert (cnt.nV, cnt.nT) == (ref.nV, ref.nT), what
+    assert np.array_equal(T.cpu().numpy().view(np.uint32), ref.T) and beq(V.cpu().numpy(), ref.V), what
+    nan = np.isnan(ref.N)
+    assert np.array_equal(N.cpu().numpy()[~nan].view(np.uint32), ref.N[~nan].view(np.uint32)), what
+
+
+def test_sweeps_that_are_never_consumed_leave_nothing_behind(reflibs):
+    """A lane swept ahead by mc33hip_sweep_many has added its slices to the partial sums k_slots scans; when its count /
+    extract call never comes (another isovalue is asked for, the grid is adopted again, the range changes) the next sweep
+    into that lane must start from clean sums in BOTH halves (they alternate by extraction): several such sequences, every
+    result compared with the reference bit for bit."""
+    import torch
+    from mc33_c_library_amd import DeviceGrid, Range
+    data = fx.noise_quant(0, 3, shape=(40, 70, 300))
+    isos = [0.0, 1.0, -1.0, 0.5]
+    t = torch.from_numpy(data).cuda()
+    g = DeviceGrid(t)
+    refs = {iso: reflibs["f32"].isosurface(data, iso) for iso in isos + [0.25, 1.5]}
+    g.extract(0.25)                       # the lane has a history: both halves of the sums have been used
+    g.extract(1.5)
+    g.sweep_many(isos)                    # never consumed ...
+    g.sweep_many(isos[::-1])              # ... swept again, never consumed either
+    for k, iso in enumerate([0.25, 1.5, 0.25, 0.0]):   # lane 0, single sweeps, odd and even epochs
+        _same_as_reference(g.extract(iso), refs[iso], ("after unused sweeps", k, iso))
+    g.sweep_many(isos)
+    g.lib.mc33hip_adopt_device(g.ctx, t.data_ptr(), t.stride(1), t.stride(0))   # "the grid changed": sweeps are forgotten
+    for k, iso in enumerate([1.0, 0.0, 1.0]):
+        _same_as_reference(g.extract(iso), refs[iso], ("after re-adopt", k, iso))
+    nz = data.shape[0] - 1
+    g.sweep_many(isos, Range(nz // 2, nz, 1, 0))   # another range, unused
+    g.sweep_many(isos[:2])
+    _same_as_reference(g.extract(isos[1]), refs[isos[1]], "lane 1 of the second sweep")
+    _same_as_reference(g.extract(isos[0]), refs[isos[0]], "lane 0 of the second sweep")
+    _same_as_reference(g.extract(0.25), refs[0.25], "and a plain call after them")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_sweep_made_for_one_zero_is_not_used_for_the_other(reflibs, dtype):
+    """+0.0 and -0.0 compare equal, but a sample equal to the isovalue gives v = iso - F = -0 for -0.0: zero AND negative.
+    A lane swept for one zero must not serve a call with the other (the lanes are matched by the bit pattern of the
+    isovalue).  The grid holds many exact zeros.  For -0.0 the reference itself is not a function of its input:
+    that result is compared with a fresh context's."""
+    import torch
+    from mc33_c_library_amd import DeviceGrid
+    data = fx.noise_quant(0, 4, shape=(24, 40, 70)) if dtype == "f32" else fx.noise_u8(0, 4, 3, shape=(24, 40, 70))
+    assert (data == 0).sum() > 100
+    t = torch.from_numpy(data).cuda()
+    ref = reflibs[dtype].isosurface(data, 0.0)
+    fresh = DeviceGrid(t)
+    Vn, Nn, Tn, cn = fresh.extract(-0.0)
+    for order in ([-0.0, 0.0], [0.0, -0.0], [-0.0, 1.0], [0.0, 1.0]):
+        g = DeviceGrid(t)
+        g.sweep_many(order)
+        _same_as_reference(g.extract(0.0), ref, (dtype, order, "+0.0"))
+        V, N, T, c = g.extract(-0.0)
+        assert (c.nV, c.nT) == (cn.nV, cn.nT) and torch.equal(T, Tn) and torch.equal(V.view(torch.int32), Vn.view(torch.int32)), (dtype, order, "-0.0")
+        g.close()

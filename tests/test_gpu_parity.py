@@ -368,26 +368,79 @@ def test_grd_orthogonal_flavour(reflibs, dtype):
         assert (got.nV, got.nT) == (reflibs[dtype].isosurface(data, iso, r0, d).nV, ref.nT)  # and the same surface as the full-layout build
 
 
-@pytest.mark.parametrize("dtype", ["f32", "u16"])
-def test_normal_neg_flavour(reflibs, dtype):
-    """libMC33_<type>_nneg.so = the reference compiled with MC33_NORMAL_NEG 1 (source/libMC33.c:20-22): normals negated
-    (marching_cubes_33.c:509-513), first two indices of every triangle exchanged (:1246-1250) - fast cells, slow cells
-    (all table groups, degenerate corners), every store."""
+@pytest.mark.parametrize("dtype,ortho", [("f32", False), ("u16", False), ("u8", False), ("u32", False), ("f64", False), ("f32", True), ("u16", True)])
+def test_normal_neg_flavour(reflibs, dtype, ortho):
+    """libMC33_<type>[_ortho]_nneg.so = the reference compiled with MC33_NORMAL_NEG 1 (source/libMC33.c:20-22; the switch
+    applies to every GRD_data_type and combines with GRD_ORTHOGONAL): normals negated (marching_cubes_33.c:509-513), first
+    two indices of every triangle exchanged (:1246-1250) - fast cells, slow cells (all table groups, degenerate corners),
+    every store."""
     from mc33_capi import MC33Lib, product_path, ref_path
-    P, R = MC33Lib(product_path(dtype, nneg=True), dtype), MC33Lib(ref_path(dtype, nneg=True), dtype)
+    P = MC33Lib(product_path(dtype, ortho=ortho, nneg=True), dtype, ortho=ortho)
+    R = MC33Lib(ref_path(dtype, ortho=ortho, nneg=True), dtype, ortho=ortho)
+    inc = None if ortho else fx.general_matrices()
     if dtype == "f32":
         cases = [(fx.cos_field(70)[0], 0.0, (-4.0, -4.0, -4.0), (8 / 69,) * 3, None), (fx.noise_f32(32, 2), 0.0, None, None, None),
-                 (fx.noise_quant(24, 2), 1.0, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0), None),
-                 (fx.cos_field(40)[0], 0.1, (0.0, 0.0, 0.0), (0.2, 0.3, 0.45), fx.general_matrices())]
+                 (fx.noise_quant(24, 2), 1.0, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0), None)]
+        if not ortho:
+            cases.append((fx.cos_field(40)[0], 0.1, (0.0, 0.0, 0.0), (0.2, 0.3, 0.45), inc))
+    elif dtype == "f64":
+        cases = [(fx.cos_field(60)[0].astype(np.float64), 0.0, (-4.0, -4.0, -4.0), (8 / 59,) * 3, None),
+                 (fx.noise_quant(24, 2).astype(np.float64), 1.0, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0), None),
+                 (fx.cos_field(40)[0].astype(np.float64), 0.1, (0.0, 0.0, 0.0), (0.2, 0.3, 0.45), inc)]
+    elif dtype == "u8":
+        cases = [(fx.noise_u8(24, 3, 7), 3.0, None, None, None), (fx.noise_u8(40, 5), 100.5, None, (0.5, 0.5, 0.5), None)]
+    elif dtype == "u32":
+        cases = [(fx.noise_u32(24, 3, 7), 3.0, None, None, None), (fx.noise_u32(32, 5), 2.0e9, (1.0, 0.0, 0.0), (0.5, 0.25, 1.0), None)]
     else:
         cases = [(fx.noise_u16(24, 3, 7), 3.0, None, None, None), (fx.cos_field_u16(60, 50, 40), 25268.5, None, (0.5, 0.5, 0.5), None)]
-    for data, iso, r0, d, inc in cases:
-        got, ref = P.isosurface(data, iso, r0, d, inclined=inc), R.isosurface(data, iso, r0, d, inclined=inc)
-        assert_surface_parity(got, ref, float(max(data.shape)), "nneg " + dtype, bit_exact=True)
-        plain = reflibs[dtype].isosurface(data, iso, r0, d, inclined=inc)   # ... and really the mirror image of the default build
+    plain_lib = reflibs[dtype]
+    for data, iso, r0, d, inc_ in cases:
+        kw = {} if ortho else {"inclined": inc_}
+        got, ref = P.isosurface(data, iso, r0, d, **kw), R.isosurface(data, iso, r0, d, **kw)
+        assert_surface_parity(got, ref, float(max(data.shape)), "nneg %s%s" % (dtype, " ortho" if ortho else ""), bit_exact=True)
+        plain = plain_lib.isosurface(data, iso, r0, d, **({} if ortho else {"inclined": inc_}))   # ... and really the mirror image of the default build
         assert got.nV > 1000 and np.array_equal(got.T[:, [1, 0, 2]], plain.T)
         fin = np.isfinite(plain.N)
         assert np.array_equal(got.N[fin], -plain.N[fin])
+
+
+def test_grid_changed_uploads_the_samples_again(reflibs):
+    """The reference reads G->F on every call (marching_cubes_33.c:1792, 1832-1868); the product keeps a copy in HBM.
+    MC33_grid_changed(M) (extension) is how a caller says it rewrote samples: the next extraction and the next
+    size_of_isosurface see the new ones; without the call the resident copy is used (documented difference)."""
+    import ctypes as C
+    from mc33_capi import MC33Lib, product_path
+    lib = MC33Lib(product_path("f32"), "f32")
+    L = lib.lib
+    L.MC33_grid_changed.restype = None
+    L.MC33_grid_changed.argtypes = [C.POINTER(lib.MC33)]
+    a = fx.cos_field(48)[0].copy()
+    b = fx.noise_f32(48, 7)
+    G, keep = lib.make_grid(a)
+    M = L.create_MC33(G)
+    assert M
+
+    def run():
+        S = L.calculate_isosurface(M, C.c_float(0.0))
+        assert S
+        try:
+            return lib.copy_surface(S)
+        finally:
+            L.free_surface_memory(S)
+
+    ra, rb = reflibs["f32"].isosurface(a, 0.0), reflibs["f32"].isosurface(b, 0.0)
+    assert_surface_parity(run(), ra, 48.0, "before the change", bit_exact=True)
+    keep[...] = b                                      # the caller edits the samples in place (G->F points into this array) ...
+    assert_surface_parity(run(), ra, 48.0, "resident copy", bit_exact=True)   # ... and has not said so
+    L.MC33_grid_changed(M)
+    nV, nT = C.c_uint(0), C.c_uint(0)
+    L.size_of_isosurface(M, C.c_float(0.0), C.byref(nV), C.byref(nT))
+    assert (nV.value, nT.value) == (rb.nV, rb.nT)
+    L.MC33_grid_changed(M)
+    assert_surface_parity(run(), rb, 48.0, "after MC33_grid_changed", bit_exact=True)
+    assert_surface_parity(run(), rb, 48.0, "and it stays", bit_exact=True)
+    L.free_MC33(M)
+    L.free_memory_grd(G)
 
 
 def test_epoch_stamps_wrap_around(reflibs):
