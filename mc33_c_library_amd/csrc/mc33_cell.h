@@ -1146,48 +1146,56 @@ MC33_HD void fast_owned_vertex(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint
 }
 
 // ---- fast emit, split in two passes so that each has a short dependency chain and few registers -------
-// Vertices of one FAST record.  All samples the (up to three) owned vertices need are fetched up front as
-// short runs along x - the 2x2 rows of the cell (x..x+2) and the four rows one step outside it (y+2 on both
-// planes, plane z+2 on both rows) - instead of 8 + 8 per vertex scattered single loads.  The arithmetic and
-// its order are those of vertex_on_edge (MC:990-1000, 1029-1039, 1175-1185).
+// The samples the (up to three) owned vertices of a FAST record and the centre vertex of a TESTED one are made from:
+// short runs along x - the 2x2 rows of the cell (x..x+2) and the four rows one step outside it (y+2 on both planes,
+// plane z+2 on both rows) - 20 values.  Where an outer neighbour does not exist (far faces of the grid) the slot
+// holds a sample that does, and the arithmetic below never looks at it.
+//   F[row][col]: rows 0..3 = (y,z) (y+1,z) (y,z+1) (y+1,z+1); col = x, x+1, x+2 (x+1 again when x+2 is outside)
+//   Y2[p][col] = (y+2 | y, z+p), Z2[q][col] = (y+q, z+2 | z); col = x, x+1
 template <typename T>
-MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s) {
-	const uint32_t r5 = (en.w2 >> 20) & 15u, r6 = (en.w2 >> 24) & 15u, r10 = (en.w3 >> 8) & 15u, r12 = entry_rank_centre(en);
-	if ((r5 & r6 & r10 & r12) == 15u) return;  // the cell creates no vertex
-	const SegCoord sc = segment_coord(c.P, s);
-	const uint32_t y = sc.y, z = sc.z;
-	if (z < c.z_emit) return;
-	const uint32_t x = sc.xbase + (en.w0 & 0xFFu);
-	const Params &P = c.P;
-	const GridView<T> &G = c.G;
-	const uint32_t vbase = c.seg_base[s].vbase + (en.w1 & 0xFFFFu);
-	const bool xin = x + 1 < P.nx, yin = y + 1 < P.ny, zin = z + 1 < P.nz;  // the outer neighbours exist
-	// F[row][col]: rows 0..3 = (y,z) (y+1,z) (y,z+1) (y+1,z+1); col = x, x+1, x+2
+struct FastSamples {
 	T F[4][3];
+	T Y2[2][2], Z2[2][2];
+};
+// ... fetched from the grid by the thread itself: 12 loads, all asked for together (the round-2 vertex pass; the host
+// emulator; in the round-3 kernel the records whose rows are not staged in LDS)
+template <typename T>
+MC33_HD void fast_samples_direct(const GridView<T> &G, uint32_t x, uint32_t y, uint32_t z, bool xin, bool yin, bool zin, FastSamples<T> &S) {
 	for (int r = 0; r < 4; r++) {
 		const uint32_t yy = y + (r & 1), zz = z + (r >> 1);
 		const SamplePair<T> q = G.pair(x, yy, zz);
-		F[r][0] = q.a;
-		F[r][1] = q.b;
-		F[r][2] = G.at(xin ? x + 2 : x + 1, yy, zz);  // (x + 1 again on the last column: the same value as q.b, and a load without a branch -
-		                                             // a conditional load made the compiler wait for each row's pair before asking for the next row)
+		S.F[r][0] = q.a;
+		S.F[r][1] = q.b;
+		S.F[r][2] = G.at(xin ? x + 2 : x + 1, yy, zz);  // (x + 1 again on the last column: the same value as q.b, and a load without a branch -
+		                                               // a conditional load made the compiler wait for each row's pair before asking for the next row)
 	}
-	// rows outside the cell: Y2[p][col] = (y+2, z+p), Z2[q][col] = (y+q, z+2); col = x, x+1
-	T Y2[2][2], Z2[2][2];
 	for (int q = 0; q < 2; q++) {
 		const SamplePair<T> yq = G.pair(x, yin ? y + 2 : y, z + q), zq = G.pair(x, y + q, zin ? z + 2 : z);
-		Y2[q][0] = yq.a; Y2[q][1] = yq.b;
-		Z2[q][0] = zq.a; Z2[q][1] = zq.b;
+		S.Y2[q][0] = yq.a; S.Y2[q][1] = yq.b;
+		S.Z2[q][0] = zq.a; S.Z2[q][1] = zq.b;
 	}
 #if defined(__HIP_DEVICE_COMPILE__)
 	{  // every sample fetched above is needed HERE: without a use outside the per-vertex branches the compiler moves the loads
 		// a branch alone uses (half a pair, even) into that branch - a round trip of their own for the records that take it
 		uint32_t acc = 0;
-		for (int r = 0; r < 4; r++) acc += (uint32_t)F[r][0] + (uint32_t)F[r][1] + (uint32_t)F[r][2];
-		for (int q = 0; q < 2; q++) acc += (uint32_t)Y2[q][0] + (uint32_t)Y2[q][1] + (uint32_t)Z2[q][0] + (uint32_t)Z2[q][1];
+		for (int r = 0; r < 4; r++) acc += (uint32_t)S.F[r][0] + (uint32_t)S.F[r][1] + (uint32_t)S.F[r][2];
+		for (int q = 0; q < 2; q++) acc += (uint32_t)S.Y2[q][0] + (uint32_t)S.Y2[q][1] + (uint32_t)S.Z2[q][0] + (uint32_t)S.Z2[q][1];
 		asm volatile("" ::"v"(acc));
 	}
 #endif
+}
+
+// Vertices of one FAST / TESTED record from its samples: positions, normals, stores.  The arithmetic and its order are
+// those of vertex_on_edge (MC:990-1000, 1029-1039, 1175-1185).  rN: rank of the vertex of edge N / of the centre among the
+// vertices this cell creates (15: none); vbase: id of the cell's first vertex.
+template <typename T>
+MC33_HD void fast_vertices_compute(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint32_t z, uint32_t vbase, uint32_t r5, uint32_t r6, uint32_t r10,
+                                   uint32_t r12, const FastSamples<T> &S) {
+	const Params &P = c.P;
+	const bool xin = x + 1 < P.nx, yin = y + 1 < P.ny, zin = z + 1 < P.nz;  // the outer neighbours exist
+	const T(&F)[4][3] = S.F;
+	const T(&Y2)[2][2] = S.Y2;
+	const T(&Z2)[2][2] = S.Z2;
 	const real_t iso = P.iso;
 	const real_t v1 = iso - (real_t)F[1][0], v2 = iso - (real_t)F[3][0], v3 = iso - (real_t)F[2][0];
 	const real_t v4 = iso - (real_t)F[0][1], v5 = iso - (real_t)F[1][1], v6 = iso - (real_t)F[3][1], v7 = iso - (real_t)F[2][1];
@@ -1228,6 +1236,22 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 		vertex_centre(x, y, z, VRef{vv, 1}, r);
 		store_vertex(P, r, c.V, c.N, vbase + r12 - c.v_skip);
 	}
+}
+
+// Vertices of one FAST record, one thread on its own: the samples by 12 loads of its own (fast_samples_direct), then the
+// arithmetic.  (The host emulator's vertex pass; the GPU runs k_emit_vertices, which stages the rows of 64 records in LDS.)
+template <typename T>
+MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s) {
+	const uint32_t r5 = (en.w2 >> 20) & 15u, r6 = (en.w2 >> 24) & 15u, r10 = (en.w3 >> 8) & 15u, r12 = entry_rank_centre(en);
+	if ((r5 & r6 & r10 & r12) == 15u) return;  // the cell creates no vertex
+	const SegCoord sc = segment_coord(c.P, s);
+	const uint32_t y = sc.y, z = sc.z;
+	if (z < c.z_emit) return;
+	const uint32_t x = sc.xbase + (en.w0 & 0xFFu);
+	const uint32_t vbase = c.seg_base[s].vbase + (en.w1 & 0xFFFFu);
+	FastSamples<T> S;
+	fast_samples_direct(c.G, x, y, z, x + 1 < c.P.nx, y + 1 < c.P.ny, z + 1 < c.P.nz, S);
+	fast_vertices_compute(c, x, y, z, vbase, r5, r6, r10, r12, S);
 }
 
 // Triangles of one FAST (or TESTED) record.  ids: 13-slot scratch.

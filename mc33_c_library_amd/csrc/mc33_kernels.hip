@@ -79,11 +79,12 @@ struct Counters {
 	uint32_t entry_cursor;  // work records requested (may exceed the capacity)
 	uint32_t slow_cursor;   // records left to k_slow_plan
 	uint32_t dirty_cursor;  // row segments whose offsets k_seg_fix has to rebuild
-	uint32_t mask_cursor;   // activity-mask records handed out
+	uint32_t batch_cursor;  // batches of <= 64 records of one slice slot (BatchDesc) the emit passes walk
 	uint32_t emit_skipped;  // set by the emit kernels when they refused to run (capacity / overflow)
 	uint32_t count_pending; // set by k_slow_plan when a record waits for k_slow_count
 	uint64_t totV, totT;    // totals over all classified slices (ghost included)
 	uint64_t ghostV, ghostT;
+	uint32_t debug[8];      // (-DMC33_DEV: what a guarded kernel found wrong)
 };
 
 // One record per (wave tile, cell slice) of the sweep: the sign-bit rows of the two planes of the slice,
@@ -132,7 +133,7 @@ struct SweepLane {
 	                         // what the sweep pays for (100 MB of them cost as much as 600 MB of reads), and consecutive slices
 	                         // share a plane
 	uint8_t *plane_fmt;      // [slice_slot of the PLANE]: PLANE_COMPACT / PLANE_RAW - how its record in slice_bits is written (store_plane)
-	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: rows << 32 | cells of the slices of that chunk
+	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: record batches << 32 | cells of the slices of that chunk
 	uint4 *edge_bits;        // [tile * 2 + (0 bottom | 1 top)][2][lane]: bit rows of the tile's first / last plane
 	uint4 *edge_hdr;         // ... their halo-column bits and "a sample equals the isovalue" flag
 	uint32_t epoch;          // number of this extraction (stamped into the slice headers)
@@ -395,9 +396,9 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 #endif
 	// cut cells and non-empty rows of the slice: the record ranges are prefix sums of these (k_slots)
 	uint32_t ncell = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
-	const uint32_t nrow = (uint32_t)__popcll(__ballot(ncell != 0));
 #pragma unroll
 	for (int dlt = 32; dlt; dlt >>= 1) ncell += __shfl_xor(ncell, dlt);
+	const uint32_t nbatch = (ncell + 63u) >> 6;  // the records of a slice are handed to the emit passes 64 at a time (BatchDesc)
 	if (lane == 0) {
 		SliceHeader h;
 		h.flags = a.epoch << 2 | SLICE_VALID | (zrows ? SLICE_HAS_ISO : 0u);
@@ -406,7 +407,7 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 		h.cells = ncell; h.zr_lo = (uint32_t)zrows; h.zr_hi = (uint32_t)(zrows >> 32);
 		h.zc_lo = (uint32_t)zcols; h.zc_hi = (uint32_t)(zcols >> 32); h.pad_[0] = h.pad_[1] = 0;
 		a.slice_hdr[slot] = h;
-		atomicAdd(a.slot_part + slot / SLOT_CHUNK, (unsigned long long)nrow << 32 | ncell);
+		atomicAdd(a.slot_part + slot / SLOT_CHUNK, (unsigned long long)nbatch << 32 | ncell);
 	}
 }
 
@@ -794,8 +795,8 @@ struct ChunkMap {  // per block, in LDS: exclusive prefix sums of the group coun
 };
 
 // ---------------------------------------------------------------------------------------------------
-// k_slots: exclusive prefix sums of (cut cells, non-empty rows) over the slice slots in slot order = the
-// work-record range and the mask-record range of every slice.  The sweep has already added every slice
+// k_slots: exclusive prefix sums of (cut cells, batches of 64 of them) over the slice slots in slot order = the
+// work-record range and the range of batch descriptors of every slice.  The sweep has already added every slice
 // into the partial sum of its chunk of SLOT_CHUNK slots; block c sums the partials below c and scans its
 // own chunk.  Record order is therefore a function of the grid alone (no allocation atomics).
 // ---------------------------------------------------------------------------------------------------
@@ -809,6 +810,7 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 	if (c == 0 && t == 0) {        // ... and so are the counters the later passes of this one add to
 		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0; ctr->count_pending = 0;
 		ctr->totV = ctr->totT = ctr->ghostV = ctr->ghostT = 0;
+		for (int q = 0; q < 8; q++) ctr->debug[q] = 0;
 	}
 	unsigned long long below = 0;
 	for (uint32_t q = t; q < c; q += 256u) below += part[q];
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 		const bool in = s0 + k < nslots;
 		const uint4 h = in ? *(const uint4 *)((const uint32_t *)(hdr + s0 + k) + 4) : uint4{0, 0, 0, 0};  // {curh_hi, cells, rows, pad}
 		const bool valid = in && slice_valid(hdr[s0 + k].flags, epoch);
-		cells[k] = valid ? h.y : 0u; rows[k] = 0u;
+		cells[k] = valid ? h.y : 0u; rows[k] = (cells[k] + 63u) >> 6;  // (second sum: batches of 64 records, as the sweep added them)
 		mine += (unsigned long long)rows[k] << 32 | cells[k];
 	}
 	s_red[t] = mine;
@@ -849,7 +851,7 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 	if (c == gridDim.x - 1 && t == 255) {  // totals; 32-bit fields (a carry out of the cells would also exceed every capacity)
 		const unsigned long long tot = base + s_red[255];
 		ctr->entry_cursor = (tot & 0xFFFFFFFFull) > 0xFFFFFF00ull ? 0xFFFFFFFFu : (uint32_t)tot;
-		ctr->mask_cursor = (uint32_t)(tot >> 32);
+		ctr->batch_cursor = (uint32_t)(tot >> 32);
 	}
 }
 
@@ -862,6 +864,17 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 // equal to iso) from the sign index via the LDS table; the in-segment vertex / triangle offsets are a
 // segmented scan over the 64 cells.  Records of a slice are written as one contiguous run.
 // ---------------------------------------------------------------------------------------------------
+// The records of one slice slot, 64 at a time: what a wave of the emit passes works on.  Everything a wave needs to know
+// about where its records live is wave-uniform and comes from here (one scalar load): no division per record, and all 64
+// records share their three sample planes and their 63 cell rows - which is what lets the vertex pass stage the sample
+// rows of a batch in LDS.  Written by k_cells; slot s owns the descriptors [slot_base[s].y, slot_base[s + 1].y).
+struct alignas(32) BatchDesc {
+	uint32_t first, count;   // work records [first, first + count), count <= 64
+	uint32_t sidx0;          // row-segment index (entry_seg) of cell row 0 of the slot's tile: entry_seg - sidx0 = row in the tile
+	uint32_t z, y0, xbase;   // cell slice, first cell row of the y tile, first cell of the row segment
+	uint32_t pad_[2];
+};
+
 struct CellsArgs {
 	uint32_t dev;            // (-DMC33_DEV: MC33_HIP_CELLS_DEV experiments)
 	uint32_t pack;           // samples per lane and load of the sweep that made the records (lane_of_column)
@@ -873,7 +886,7 @@ struct CellsArgs {
 	const uint4 *slice_bits;
 	const uint8_t *plane_fmt;
 	uint32_t epoch;          // number of this extraction: headers written by earlier ones are not valid
-	const uint2 *slot_base;  // [slice_slot]: {first work record, first mask record} (k_slots)
+	const uint2 *slot_base;  // [slice_slot]: {first work record, first batch descriptor} (k_slots)
 	uint32_t *seg_cnt;
 	SegDir *seg_dir;
 	EntryA *entries_a;       // work records, half A
@@ -884,6 +897,8 @@ struct CellsArgs {
 	uint32_t *slow_list, *dirty_list;
 	ListChunks lc;
 	uint32_t entry_cap;
+	BatchDesc *batches;
+	uint32_t batch_cap;
 	Counters *ctr;
 	unsigned long long *trace;  // MC33_HIP_TRACE_CELLS: per wave {start, bits in, rows done, end}
 };
@@ -1000,6 +1015,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 	const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
 	const unsigned long long t_bits = a.trace ? __builtin_amdgcn_s_memrealtime() + (total & 0u) : 0ull;
 	const uint32_t ebase = base.x;
+	{  // the slot's records in batches of 64 for the emit passes
+		const uint32_t nb = (total + 63u) >> 6;
+		for (uint32_t k = lane; k < nb; k += 64u)
+			if (base.y + k < a.batch_cap) {
+				BatchDesc bd;
+				bd.first = ebase + 64u * k; bd.count = min(64u, total - 64u * k);
+				bd.sidx0 = (uint32_t)(((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y0);
+				bd.z = z; bd.y0 = y0; bd.xbase = xbase; bd.pad_[0] = bd.pad_[1] = 0;
+				a.batches[base.y + k] = bd;
+			}
+	}
 
 	// rows whose cells cannot take the fast path: on the y = 0 / z = 0 faces (extra owned edges), or in a
 	// tile plane pair that holds a sample equal to the isovalue
@@ -1378,6 +1404,9 @@ struct EmitArgs {
 	uint64_t capV, capT;
 	uint64_t ghost_segs;  // row segments of the ghost slice (0 without ghost)
 	uint32_t id_base;
+	const BatchDesc *batches;  // the records in batches of one slice slot (k_cells)
+	uint32_t batch_cap;
+	uint32_t stage_rows;  // every sample row of the grid starts on a 16-byte boundary: k_emit_vertices may stage rows in LDS
 };
 
 // The fast emit passes take the records in storage order, which k_slots made (4 slices of a tile column, next
@@ -1431,6 +1460,336 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 		asm volatile("" ::"v"(seg), "v"(ea.a0));  // (both wanted here: the compiler would move the segment's load behind the flag test)
 		const Entry en = entry_join(ea, ctx_half_b(c, ea, e));
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, seg);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_emit_vertices: the vertices of the fast and tested records, one WAVE per batch of <= 64 records of one slice slot.
+//
+// The round-2 pass (k_emit_fast_vertices, kept behind MC33_HIP_OLD_VERTEX_PASS=1 for A/B) was one thread per record with 12 short
+// sample loads each; its 64 lanes sit in 64 different sample rows, so every load instruction is 64 cache-line look-ups
+// in the CU's L1 - 65 cycles whatever its width (tools/tcp_probe.hip, profiles/r03_tcp_probe.txt), ~800 cycles per 64
+// records, although the 64 records of a batch share their rows: record (x, y, z) reads rows y, y+1, y+2 of planes z,
+// z+1 and rows y, y+1 of plane z+2, and its neighbour one row up reads two of those three again.
+//
+// Here the wave first finds, per sample row r of the tile (lane r), the x interval the batch needs of it - the union over
+// the records of cell rows r-2 .. r, from the first and the last record of each row (the records of a slot are sorted by
+// row, then x) - in 16-byte chunks; a prefix sum gives every row its place in an LDS image [plane][chunk]; then the
+// chunks are loaded ONE PER LANE, consecutive lanes on consecutive chunks of a row, the three planes of a chunk by the
+// same lane (lanes that share a line cost one look-up: 17 cycles for 16 rows of 64 bytes); finally every lane computes
+// its record's vertices from LDS.  MC:990-1000, 1029-1039, 1175-1185 (the stencil), 485-585 (the stores).
+// Rows that are wide and sparse (noise: a few records spread over the 256 cells of a row) are not staged - their records
+// load for themselves as before (fast_samples_direct) - and so are rows beyond the image's capacity.
+// ---------------------------------------------------------------------------------------------------
+// Window of a sample row in the LDS image: EV_W 16-byte chunks from the chunk that holds the first sample the batch needs of
+// that row.  A row that needs more (a long run of records along x, or records far apart: noise) is not staged; the
+// records that read it load for themselves - which is cheap exactly then, many lanes of a load sharing a row.
+#ifndef MC33_EV_W
+#define MC33_EV_W (sizeof(sample_t) == 8 ? 4u : sizeof(sample_t) == 4 ? 3u : 2u)
+#endif
+constexpr uint32_t EV_W = MC33_EV_W;
+constexpr uint32_t EV_ROWS = 65;         // sample rows 0..64 of a tile (63 cell rows, y + 2 above the last)
+constexpr uint32_t EV_EMPTY = 0xFFFFFFFFu;
+struct EmitVLds {                        // per wave
+	uint32_t rowA[64], rowB[64];         // cell rows 0..62 of the tile: first / last record of the batch in that row, lane << 8 | x in the segment
+	uint32_t rowvb[64];                  // cell rows: id of the first vertex of the row segment (seg_base)
+	uint32_t rowinfo[EV_ROWS + 1];       // sample rows: staged << 31 | chunks - 1 << 16 | first chunk - chunk of the segment's first sample
+	uint32_t vlist[256];                 // vertices of the batch: record (lane) | kind << 8, by kind
+	uint4 data[3 * EV_ROWS * EV_W];      // [plane][row][chunk]
+};
+
+// Which wave takes which batch: each XCD gets one contiguous eighth of the batches (its own L2: see XcdWalk), and the waves
+// resident on it walk that eighth side by side - wave k of the XCD takes batches k, k + W, k + 2 W, ... (W waves per XCD) -
+// so that consecutive batches (consecutive slices of a tile column share two of their three sample planes; neighbouring
+// row segments share the lines their vertices are written to) are in flight together.
+// Measured alternatives (round 3, C3, HBM traffic of the pass / time): this walk 451 MB / 125 us - the waves drift apart
+// over their ~20 batches; blocks of 4 batches in launch order, nothing prefetched: 383 MB (the vertex writes then cost
+// exactly their bytes) but 157 us, every block paying its start-up chain; the same with 2-4 rounds per block 139 us;
+// batches handed out in order by per-XCD atomic counters: 402 MB but 171 us (the compiler waits for every atomic on the
+// spot).  MC33_EV_BLOCKED: every block a contiguous piece of its XCD's eighth instead.
+struct XcdBatchWalk {
+	uint32_t first, end, stride;
+	__device__ XcdBatchWalk(uint32_t n) {
+		const uint32_t per_xcd = (n + 7u) / 8u;
+		const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, blocks_per_xcd = (gridDim.x + 7u) >> 3;
+		const uint32_t xend = min((xcd + 1u) * per_xcd, n);
+#ifdef MC33_EV_BLOCKED
+		const uint32_t piece = ((per_xcd + blocks_per_xcd - 1u) / blocks_per_xcd + 3u) & ~3u;  // batches per block
+		first = xcd * per_xcd + slot * piece + (threadIdx.x >> 6);
+		end = min(xcd * per_xcd + (slot + 1u) * piece, xend);
+		stride = 4u;
+#else
+		first = xcd * per_xcd + slot * 4u + (threadIdx.x >> 6);
+		end = xend;
+		stride = blocks_per_xcd * 4u;
+#endif
+	}
+};
+
+__device__ __forceinline__ uint32_t lane_below(uint32_t v) {  // lane r <- lane r-1 (lane 0 <- 63): DPP wave_shr:1
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) {  // set bits of m in the lanes below this one
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// what a wave knows about its batch (wave-uniform: SGPRs)
+struct BatchInfo { uint32_t first, count, sidx0, z, y0, xbase; };
+__device__ __forceinline__ BatchInfo load_batch(const BatchDesc *batches, uint32_t j) {
+	// read through the constant address space: the descriptors are not written while the emit passes run, and a uniform
+	// address there is a SCALAR load (one request per wave, not 64 lanes asking for the same line)
+	typedef const __attribute__((address_space(4))) uint32_t *cptr;
+	cptr p = (cptr)(uintptr_t)(batches + __builtin_amdgcn_readfirstlane((int)j));
+	return BatchInfo{p[0], p[1], p[2], p[3], p[4], p[5]};
+}
+
+#ifndef MC33_EV_WAVES
+#define MC33_EV_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAVES, 4))) void k_emit_vertices(const EmitArgs a) {
+	constexpr uint32_t SZ = (uint32_t)sizeof(sample_t);
+	__shared__ EntryB s_fast_b[256];
+	__shared__ EmitVLds s_w[4];
+	s_fast_b[threadIdx.x] = a.c.fast_b[threadIdx.x];
+	__syncthreads();
+	const Counters ctr = *a.ctr;
+	EmitCtx<sample_t> c = a.c;
+	c.fast_b = s_fast_b; c.fast_b_in_lds = true;
+	if (!emit_prepare(a, c, ctr)) return;
+	const uint32_t lane = threadIdx.x & 63u;
+	EmitVLds &L = s_w[threadIdx.x >> 6];
+	const Params &P = c.P;
+	const GridView<sample_t> &G = c.G;
+	const uint64_t sliceB = G.slice * SZ;
+	const uint32_t nbatch = min(ctr.batch_cursor, a.batch_cap);
+	const XcdBatchWalk w(nbatch);
+	if (w.first >= w.end) return;
+#ifdef MC33_DEV  // a descriptor that cannot be right is reported (Counters::debug; the first one) and replaced by an empty one instead of followed
+	auto load_batch = [&](const BatchDesc *b, uint32_t jj) -> BatchInfo {
+		BatchInfo d = ::load_batch(b, jj);
+		if (jj >= nbatch || d.count == 0u || d.count > 64u || (uint64_t)d.first + d.count > ctr.entry_cursor || d.z >= P.nz || d.y0 >= P.ny || d.xbase >= P.nx) {
+			if (lane == 0 && atomicCAS(&a.ctr->debug[0], 0u, 1u) == 0u) {
+				a.ctr->debug[1] = d.first; a.ctr->debug[2] = d.count; a.ctr->debug[3] = d.z; a.ctr->debug[4] = jj; a.ctr->debug[5] = w.first; a.ctr->debug[6] = w.end; a.ctr->debug[7] = nbatch;
+			}
+			d = BatchInfo{0u, 0u, 0u, c.z_emit, 0u, 0u};
+		}
+		return d;
+	};
+#endif
+	// A wave walks its batches with the NEXT batch's records already asked for (and the descriptor after that): what is left
+	// between two batches is the one round trip of the staging loads.  Loads and stores complete in issue order: whatever is
+	// waited for after a batch's vertex stores have been issued waits for those stores as well, so everything the next batch
+	// needs from memory is asked for AND waited for before the stores (finish_rec).
+	struct Rec { EntryA a; EntryB b; uint32_t seg, rowvb; };
+	auto load_rec = [&](const BatchInfo &d) -> Rec {
+		Rec r;
+		const uint32_t e = d.first + (lane < d.count ? lane : 0u);
+		r.seg = c.entry_seg[e];
+		r.a = c.entries_a[e];
+		r.b = EntryB{0u, 0u};
+		// first vertex of row segment (cell row `lane` of the tile): by row, not by record - it does not depend on the records
+		const uint32_t rows = min(63u, P.ny - d.y0);
+		r.rowvb = c.seg_base[d.sidx0 + min(lane, rows - 1u)].vbase;
+		return r;
+	};
+	auto finish_rec = [&](Rec &r, const BatchInfo &d) {  // half B: from the sign index; a tested record's (rare: noisy fields) is a load of its own
+		r.b = fast_half_b(c, (r.a.a0 >> 8) & 0xFFu);
+		const bool stored = lane < d.count && (r.a.a0 & (ENTRYA_SLOW | ENTRYA_TESTED)) == ENTRYA_TESTED;
+		if (__ballot(stored)) {  // wave-uniform
+			if (stored) r.b = c.entries_b[d.first + lane];
+			asm volatile("" ::"v"(r.b.b0), "v"(r.b.b1));  // (here, not at its first use behind the stores)
+		}
+		asm volatile("" ::"v"(r.seg), "v"(r.rowvb));
+	};
+	uint32_t j = w.first;
+	BatchInfo d0 = load_batch(a.batches, j), d1 = d0;
+	if (j + w.stride < w.end) d1 = load_batch(a.batches, j + w.stride);
+	Rec rec0 = load_rec(d0), rec1 = rec0;
+	finish_rec(rec0, d0);
+	for (;;) {  // wave-uniform
+		const bool more = j + w.stride < w.end, more2 = j + 2u * w.stride < w.end;
+		BatchInfo d2 = d1;
+		if (more2) d2 = load_batch(a.batches, j + 2u * w.stride);
+		auto next_batch = [&]() {  // (before the vertex stores: see above)
+			if (more) finish_rec(rec1, d1);
+		};
+		const uint32_t z = d0.z, y0 = d0.y0, xbase = d0.xbase, count = d0.count, sidx0 = d0.sidx0;
+		const bool on = lane < count;
+		const EntryA ea = rec0.a;
+		const uint32_t seg = rec0.seg;
+		const Entry en = entry_join(ea, rec0.b);
+		if (more) rec1 = load_rec(d1);
+		const uint32_t r5 = (en.w2 >> 20) & 15u, r6 = (en.w2 >> 24) & 15u, r10 = (en.w3 >> 8) & 15u, r12 = entry_rank_centre(en);
+		// (a ghost slice of a z-slab - z < z_emit - has its vertices written by the rank below)
+		const bool creates = on && z >= c.z_emit && !(en.w3 & ENTRY_SLOW) && (r5 & r6 & r10 & r12) != 15u;
+		if (__ballot(creates)) {
+			const uint32_t rho = seg - sidx0, xl = en.w0 & 0xFFu;  // cell row in the tile (0..62), x in the segment
+			const uint32_t x = xbase + xl, y = y0 + rho;
+			const bool xin = x + 1 < P.nx, yin = y + 1 < P.ny, zin = z + 1 < P.nz;  // (zin: wave-uniform)
+			const uint32_t cbase = (xbase * SZ) >> 4;
+			L.rowvb[lane] = rec0.rowvb;
+			bool staged_lane = false;
+			uint32_t i0 = 0, i1 = 0, i2 = 0;
+			if (a.stage_rows) {
+				// ---- which records begin and end each cell row of the batch
+				L.rowA[lane] = EV_EMPTY;
+				L.rowB[lane] = EV_EMPTY;
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				{
+					const uint32_t below = lane_below(rho), above = row_above(rho);
+					if (on && (lane == 0u || below != rho)) L.rowA[rho] = lane << 8 | xl;
+					if (on && (lane + 1u == count || above != rho)) L.rowB[rho] = lane << 8 | xl;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				// ---- lane = sample row r of the tile: the chunks of it the batch needs (the records of cell rows r-2 .. r)
+				auto row_window = [&](uint32_t r) -> uint32_t {
+					uint32_t xmin = 255u, xmax = 0u;
+					bool any = false;
+#pragma unroll
+					for (uint32_t k = 0; k < 3; k++) {
+						const int ri = (int)r - (int)k;  // (signed: see valid_masks)
+						const bool in = ri >= 0 && ri <= 62;
+						const uint32_t rr = in ? (uint32_t)ri : 0u;
+						const uint32_t fa = L.rowA[rr], fb = L.rowB[rr];
+						const bool have = in && fa != EV_EMPTY;
+						xmin = have ? min(xmin, fa & 0xFFu) : xmin;
+						xmax = have ? max(xmax, fb & 0xFFu) : xmax;
+						any |= have;
+					}
+					const uint32_t lo = xbase + xmin, hi = min(xbase + xmax + 2u, P.nx);
+					const uint32_t clo = (lo * SZ) >> 4, nm1 = ((hi * SZ + SZ - 1u) >> 4) - clo;  // first chunk, chunks - 1
+					const bool staged = any && y0 + r <= P.ny && nm1 < EV_W;
+					return (staged ? 1u << 31 : 0u) | (nm1 & 3u) << 16 | ((clo - cbase) & 0xFFFFu);
+				};
+				L.rowinfo[lane] = row_window(lane);
+				const uint32_t info64 = row_window(64u);  // (sample row 64, needed by cell row 62: every lane computes the same)
+				if (lane == 0) L.rowinfo[64] = info64;
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				i0 = L.rowinfo[rho]; i1 = L.rowinfo[rho + 1u]; i2 = L.rowinfo[yin ? rho + 2u : rho];
+				staged_lane = creates && ((i0 & i1 & i2) >> 31) != 0u;
+				// (a batch of long runs along x - many records per row, every window too narrow - stages nothing: its records
+				// load for themselves, consecutive lanes reading consecutive samples of a row)
+				if (__ballot(staged_lane)) {
+				// ---- lane = chunk: item i of a plane is chunk i % EV_W of row i / EV_W; the three planes of a chunk by the same
+				// lane, all loads of the batch issued before the first one is waited for (named registers: an array indexed by
+				// the group ended up in scratch memory)
+				const char *plane0 = (const char *)G.p + ((uint64_t)(z - G.z0) * G.slice + (uint64_t)y0 * G.pitch) * SZ + (uint64_t)cbase * 16u;
+				const uint32_t pitchB = G.pitch * SZ;
+				const uint4 zero4 = {0u, 0u, 0u, 0u};
+				constexpr uint32_t NITEM = EV_ROWS * EV_W, NGRP = (NITEM + 63u) / 64u;
+				static_assert(NGRP <= 5, "groups of the staging loads");
+				uint4 qa0 = zero4, qa1 = zero4, qa2 = zero4, qb0 = zero4, qb1 = zero4, qb2 = zero4, qc0 = zero4, qc1 = zero4, qc2 = zero4;
+				uint4 qd0 = zero4, qd1 = zero4, qd2 = zero4, qe0 = zero4, qe1 = zero4, qe2 = zero4;
+				auto fetch = [&](uint32_t g, uint4 &q0, uint4 &q1, uint4 &q2) -> bool {
+					const uint32_t it = g * 64u + lane;
+					const uint32_t r = it / EV_W, ck = it - r * EV_W;
+					const uint32_t info = L.rowinfo[min(r, EV_ROWS - 1u)];
+					const bool need = it < NITEM && (info >> 31) && ck <= ((info >> 16) & 3u);
+					if (need) {
+						const char *addr = plane0 + (uint64_t)r * pitchB + (uint64_t)((info & 0xFFFFu) + ck) * 16u;
+						q0 = *(const uint4 *)addr;
+						q1 = *(const uint4 *)(addr + sliceB);
+						if (zin) q2 = *(const uint4 *)(addr + 2u * sliceB);
+					}
+					return need;
+				};
+				auto put = [&](uint32_t g, bool need, const uint4 &q0, const uint4 &q1, const uint4 &q2) {
+					const uint32_t it = g * 64u + lane;
+					if (need) {
+						L.data[it] = q0;
+						L.data[NITEM + it] = q1;
+						L.data[2u * NITEM + it] = q2;
+					}
+				};
+				const bool na = fetch(0u, qa0, qa1, qa2), nb = fetch(1u, qb0, qb1, qb2), nc = fetch(2u, qc0, qc1, qc2);
+				const bool nd = NGRP > 3 ? fetch(3u, qd0, qd1, qd2) : false, ne = NGRP > 4 ? fetch(4u, qe0, qe1, qe2) : false;
+				put(0u, na, qa0, qa1, qa2); put(1u, nb, qb0, qb1, qb2); put(2u, nc, qc0, qc1, qc2);
+				if (NGRP > 3) put(3u, nd, qd0, qd1, qd2);
+				if (NGRP > 4) put(4u, ne, qe0, qe1, qe2);
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				}
+			} else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			const uint32_t vbase = L.rowvb[rho] + (en.w1 & 0xFFFFu);
+			next_batch();  // (before the stores below)
+			// ---- the vertices.  Staged records: one LANE PER VERTEX (a record makes one on average; one branch per owned edge
+			// would run three times for a third of the lanes each).  The vertex of the edge from corner A to corner 6 = B
+			// along axis k: t = vA / (vA - vB); along the edge the gradient is vB - vA, across it (axes u1, u2) central
+			// differences at both ends blended by t, or one-sided ones on the far faces of the grid - vertex_on_edge's
+			// arithmetic in its order (MC:990-1000 edge 5, 1029-1039 edge 6, 1175-1185 edge 10), whatever the axis.
+			const bool direct = creates && (!staged_lane || r12 != 15u);  // (a centre vertex needs all 8 corners: rare, the record's own loads)
+			const bool viaimg = creates && !direct;
+			const uint64_t m5 = __ballot(viaimg && r5 != 15u), m6 = __ballot(viaimg && r6 != 15u), m10 = __ballot(viaimg && r10 != 15u);
+			const uint32_t n5 = (uint32_t)__popcll(m5), n6 = (uint32_t)__popcll(m6), nv = n5 + n6 + (uint32_t)__popcll(m10);
+			if (nv) {
+				if (viaimg && r5 != 15u) L.vlist[lanes_below(m5)] = lane;
+				if (viaimg && r6 != 15u) L.vlist[n5 + lanes_below(m6)] = lane | 1u << 8;
+				if (viaimg && r10 != 15u) L.vlist[n5 + n6 + lanes_below(m10)] = lane | 2u << 8;
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				// what a vertex lane needs of its record
+				const uint32_t rw0 = xl | rho << 8 | r5 << 16 | r6 << 20 | r10 << 24 | (xin ? 1u << 28 : 0u) | (yin ? 1u << 29 : 0u);
+				const uint32_t rw1 = (i0 & 0xFFu) | (i1 & 0xFFu) << 8 | (i2 & 0xFFu) << 16;  // first chunk of rows rho, rho + 1, rho + 2 | rho
+				const char *img = (const char *)L.data;
+				constexpr uint32_t NITEM = EV_ROWS * EV_W;
+				for (uint32_t v0 = 0; v0 < nv; v0 += 64u) {  // wave-uniform
+					const bool act = v0 + lane < nv;
+					const uint32_t ent = L.vlist[act ? v0 + lane : 0u];
+					const uint32_t src = (ent & 63u) << 2, kind = ent >> 8;
+					const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)rw0), w1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)rw1);
+					const uint32_t vb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)vbase);
+					if (act) {
+						const uint32_t vxl = w0 & 0xFFu, vrho = (w0 >> 8) & 0xFFu;
+						const bool vxin = (w0 >> 28) & 1u, vyin = (w0 >> 29) & 1u;
+						const uint32_t rank = kind == 0u ? (w0 >> 16) & 15u : kind == 1u ? (w0 >> 20) & 15u : (w0 >> 24) & 15u;
+						// sample (dx, dy, dz) of the cell: byte in the image
+						const uint32_t xb0 = vxl * SZ + ((xbase * SZ) & 15u);
+						auto smp = [&](uint32_t dx, uint32_t dy, uint32_t dz) -> sample_t {
+							const uint32_t clo = dy == 0u ? w1 & 0xFFu : dy == 1u ? (w1 >> 8) & 0xFFu : (w1 >> 16) & 0xFFu;
+							const uint32_t byte = ((dz * EV_ROWS + vrho + dy) * EV_W - clo) * 16u + xb0 + dx * SZ;
+							return *(const sample_t *)(img + byte);
+						};
+						// corner A of the edge: (1,1,0) edge 5 | (1,0,1) edge 6 | (0,1,1) edge 10; B = (1,1,1)
+						const uint32_t ax = kind != 2u, ay = kind != 1u, az = kind != 0u;
+						const real_t iso = P.iso;
+						const sample_t fA = smp(ax, ay, az), fB = smp(1u, 1u, 1u);
+						// across the edge: u1 = x (edges 5, 6) or y (edge 10); u2 = y (edge 5) or z (edges 6, 10).  Where the outer
+						// neighbour does not exist (far faces) the inner one is read twice and the one-sided form is taken.
+						const bool in1 = kind != 2u ? vxin : vyin, in2 = kind == 0u ? vyin : zin;
+						const uint32_t x2 = vxin ? 2u : 1u, y2 = vyin ? 2u : 0u, z2 = zin ? 2u : 0u;
+						sample_t a1m, a1p, b1m, b1p, a2m, a2p, b2m, b2p;
+						if (kind != 2u) { a1m = smp(0u, ay, az); a1p = smp(x2, ay, az); b1m = smp(0u, 1u, 1u); b1p = smp(x2, 1u, 1u); }
+						else { a1m = smp(0u, 0u, 1u); a1p = smp(0u, y2, 1u); b1m = smp(1u, 0u, 1u); b1p = smp(1u, y2, 1u); }
+						if (kind == 0u) { a2m = smp(1u, 0u, 0u); a2p = smp(1u, y2, 0u); b2m = smp(1u, 0u, 1u); b2p = smp(1u, y2, 1u); }
+						else { a2m = smp(ax, ay, 0u); a2p = smp(ax, ay, z2); b2m = smp(1u, 1u, 0u); b2p = smp(1u, 1u, z2); }
+						const real_t va = iso - (real_t)fA, vbv = iso - (real_t)fB;
+						const real_t t = va / (va - vbv);
+						const real_t g0 = vbv - va;
+						const real_t g1 = in1 ? 0.5f * (sample_diff(a1m, a1p) * (1 - t) + sample_diff(b1m, b1p) * t)
+						                      : (va - (iso - (real_t)a1m)) * (1 - t) + (vbv - (iso - (real_t)b1m)) * t;
+						const real_t g2 = in2 ? 0.5f * (sample_diff(a2m, a2p) * (1 - t) + sample_diff(b2m, b2p) * t)
+						                      : (va - (iso - (real_t)a2m)) * (1 - t) + (vbv - (iso - (real_t)b2m)) * t;
+						const uint32_t vx = xbase + vxl, vy = y0 + vrho;
+						real_t r[6];
+						r[0] = kind == 2u ? (real_t)vx + t : (real_t)(vx + 1u);
+						r[1] = kind == 1u ? (real_t)vy + t : (real_t)(vy + 1u);
+						r[2] = kind == 0u ? (real_t)z + t : (real_t)(z + 1u);
+						r[3] = kind == 2u ? g0 : g1;
+						r[4] = kind == 0u ? g2 : kind == 1u ? g0 : g1;
+						r[5] = kind == 0u ? g0 : g2;
+						store_vertex(P, r, c.V, c.N, vb + rank - c.v_skip);
+					}
+				}
+			}
+			if (__ballot(direct)) {  // (wave-uniform: records of rows that are not staged, tested records with a centre vertex)
+				if (direct) {
+					FastSamples<sample_t> S;
+					fast_samples_direct(G, x, y, z, xin, yin, zin, S);
+					fast_vertices_compute(c, x, y, z, vbase, r5, r6, r10, r12, S);
+				}
+			}
+		} else next_batch();
+		if (!more) break;
+		j += w.stride;
+		d0 = d1; d1 = d2; rec0 = rec1;
 	}
 }
 
@@ -1537,6 +1896,8 @@ struct mc33hip_ctx {
 	EntryB *d_fast_b;
 	uint32_t *d_pat;
 	uint32_t *entry_seg, *slow_list, *dirty_list;
+	BatchDesc *batches;       // the records in batches of <= 64 of one slice slot (k_cells writes, the emit passes walk)
+	uint64_t batch_cap;
 	uint32_t *list_cnt;       // [2][LIST_CHUNKS] cursors of the slow / dirty list parts (ListChunks)
 	ListChunks lc;            // ... for the range last counted
 	uint64_t entry_cap;
@@ -1551,6 +1912,8 @@ struct mc33hip_ctx {
 	uint64_t tiles_cap, ntiles, nbounds;
 	uint32_t tiles_zs, tiles_ze, tiles_depth;
 	uint32_t resident_blocks; // k_sweep blocks the device holds at once
+	int cus;                  // compute units of the device
+	int emit_v_blocks_per_cu; // blocks of k_emit_vertices a CU holds
 	Counters *d_ctr, *h_ctr;
 	hipEvent_t ev[4];
 	hipEvent_t ev_many[MC33_MANY_PASSES][2];  // mc33hip_sweep_many's passes: recorded around each, read in read_timing (nobody waits)
@@ -1619,6 +1982,13 @@ void pool_give(int device, hipStream_t s) {
 }
 }  // namespace
 
+// row pitch (samples) of the library's own copy of the grid: every row starts on a 16-byte boundary, whatever the sample
+// type (the sweep loads dwords, k_emit_vertices stages 16-byte chunks of the rows)
+static size_t own_pitch(size_t npx) {
+	const size_t unit = sizeof(sample_t) >= 4 ? 4 : 16 / sizeof(sample_t);
+	return (npx + unit - 1) / unit * unit;
+}
+
 extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	if (!out || !d) return MC33HIP_EINVAL;
 	*out = nullptr;
@@ -1635,7 +2005,7 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	*out = c;
 	int rc = use_device(c);
 	if (rc) { free(c); *out = nullptr; return rc; }
-	c->pitch = ((size_t)d->npx + 3) & ~(size_t)3;  // rows start 16-byte aligned for float samples
+	c->pitch = own_pitch(d->npx);
 	c->slice = c->pitch * d->npy;
 	hipError_t e;
 #define CREATE_TRY(expr)                                                                    \
@@ -1694,7 +2064,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_rules); (void)hipFree(c->d_rule_index); (void)hipFree(c->d_fast);
 	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base);
 	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
-	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->entries_c); (void)hipFree(c->d_fast_b); (void)hipFree(c->d_pat); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
+	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->entries_c); (void)hipFree(c->d_fast_b); (void)hipFree(c->d_pat); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list); (void)hipFree(c->batches);
 	for (int k = 0; k < MC33_LANES; k++) {
 		IsoLane &L = c->lanes[k];
 		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.plane_fmt); (void)hipFree(L.slot_part); (void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
@@ -1731,7 +2101,7 @@ extern "C" int mc33hip_set_stream(mc33hip_ctx *c, void *s) {
 static int ensure_grid(mc33hip_ctx *c) {
 	if (c->d_grid && c->owns_grid) return 0;
 	if (c->d_grid && !c->owns_grid) { c->d_grid = nullptr; }
-	c->pitch = ((size_t)c->desc.npx + 3) & ~(size_t)3;
+	c->pitch = own_pitch(c->desc.npx);
 	c->slice = c->pitch * c->desc.npy;
 	// +64 samples of slack: tile loads clamp their addresses into the row, never past the buffer
 	HIP_TRY(hipMalloc(&c->d_grid, (c->slice * c->desc.npz_resident + 64) * sizeof(sample_t)));
@@ -2145,6 +2515,15 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 		HIP_TRY(hipMalloc(&c->slot_base, g.nslots * sizeof(uint2)));
 		c->slot_base_cap = g.nslots;
 	}
+	{  // batch descriptors: every 64 records one, plus at most one partly filled batch per slice slot
+		const uint64_t need = c->entry_cap / 64 + g.nslots + 64;
+		if (c->batch_cap < need) {
+			(void)hipFree(c->batches);
+			c->batches = nullptr; c->batch_cap = 0;
+			HIP_TRY(hipMalloc(&c->batches, need * sizeof(BatchDesc)));
+			c->batch_cap = need;
+		}
+	}
 	SweepArgs a;
 	sweep_args(c, g, a);
 	set_lane(a, 0, L, P.iso);
@@ -2168,6 +2547,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir;
 	ca.entries_a = c->entries_a; ca.entries_b = c->entries_b; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
 	ca.entry_cap = (uint32_t)c->entry_cap;
+	ca.batches = c->batches; ca.batch_cap = (uint32_t)std::min<uint64_t>(c->batch_cap, 0xFFFFFFFFull);
 	ca.ctr = c->d_ctr;
 	ca.trace = nullptr;
 	if (getenv("MC33_HIP_TRACE_CELLS")) {
@@ -2324,6 +2704,11 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.capV = capV; a.capT = capT;
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
+	a.batches = c->batches; a.batch_cap = (uint32_t)std::min<uint64_t>(c->batch_cap, 0xFFFFFFFFull);
+	// rows may be staged in 16-byte chunks when every row of the grid starts on a 16-byte boundary (always so for the library's
+	// own copy; a caller's device buffer may have any pitch: its records then load for themselves)
+	a.stage_rows = ((uintptr_t)c->d_grid % 16u) == 0 && (c->pitch * sizeof(sample_t)) % 16u == 0 && (c->slice * sizeof(sample_t)) % 16u == 0 &&
+	               !env_u32("MC33_HIP_NO_STAGE", 0);
 	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 64u);
 	// The three emit passes are independent (V/N vs T, fast vs slow records).  While each of them waited through a chain of
 	// dependent loads (rounds 1 and most of 2) running them side by side on three streams paid on large grids (0.15 instead
@@ -2347,7 +2732,17 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 		hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, ss, a);
 		HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
 	}
-	hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);
+	if (!env_u32("MC33_HIP_OLD_VERTEX_PASS", 0)) {
+		// as many blocks as the device holds at once (one more round of blocks would run with most of the GPU idle); every wave
+		// walks many batches, its next batch's records in flight while it works on one
+		if (!c->cus) {
+			HIP_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, c->device));
+			HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->emit_v_blocks_per_cu, k_emit_vertices, 256, 0));
+		}
+		const uint32_t vblocks = (uint32_t)std::max(1, c->cus) * env_u32("MC33_HIP_EMIT_V_BLOCKS_PER_CU", (uint32_t)std::max(1, c->emit_v_blocks_per_cu));
+		hipLaunchKernelGGL(k_emit_vertices, dim3((vblocks + 7u) & ~7u), dim3(256), 0, c->stream, a);
+	}
+	else hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);  // (the round-2 pass, for A/B timing)
 	hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, sv, a);
 	if (fork_all) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
 	if (!fork_slow) hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, ss, a);
@@ -2363,8 +2758,11 @@ static int fetch_counters(mc33hip_ctx *c) {
 	HIP_TRY(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (getenv("MC33_HIP_VERBOSE"))
-		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, non-empty row segments %u)\n", c->h_ctr->entry_cursor,
-		        c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->mask_cursor);
+		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, record batches %u)\n", c->h_ctr->entry_cursor,
+		        c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->batch_cursor);
+	if (c->h_ctr->debug[0])
+		fprintf(stderr, "[mc33hip] DEBUG words %u: first %u count %u z %u y0 %u xbase %u batch %u of %u\n", c->h_ctr->debug[0], c->h_ctr->debug[1], c->h_ctr->debug[2],
+		        c->h_ctr->debug[3], c->h_ctr->debug[4], c->h_ctr->debug[5], c->h_ctr->debug[6], c->h_ctr->debug[7]);
 	if (c->trace_cells && getenv("MC33_HIP_TRACE_CELLS")) {
 		void *h = malloc(c->trace_cells_n * 32);
 		if (h && hipMemcpy(h, c->trace_cells, c->trace_cells_n * 32, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -2530,6 +2928,15 @@ extern "C" int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t) {
 	*t = c->timing;
 	return MC33HIP_OK;
 }
+
+#ifdef MC33_DEV
+extern "C" int mc33hip_debug_words(mc33hip_ctx *c, unsigned int *out /*[8]*/) {  // what a guarded kernel found wrong (developer builds)
+	if (!c || !out) return MC33HIP_EINVAL;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipMemcpy(out, (const char *)c->d_ctr + offsetof(Counters, debug), 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	return MC33HIP_OK;
+}
+#endif
 
 extern "C" int mc33hip_synchronize(mc33hip_ctx *c) {
 	if (!c) return MC33HIP_EINVAL;
