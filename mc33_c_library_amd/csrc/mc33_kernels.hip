@@ -148,8 +148,8 @@ struct SweepArgs {
 	uint32_t nYT, nseg_pad;  // y tiles, row segments per slot row (= P.nseg)
 	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz), {start, end} (s_memtime, shader clock)
 	uint32_t z_end;          // end of the classified range: tiles that reach it have no tile above
-	uint32_t debug;          // MC33_HIP_DEBUG, developer builds (-DMC33_DEV) only - timing experiments, every count is 0: 2 = stream
-	                         // only, 16 = stream + the cut-cell test of every slice but no slice is handed on
+	uint32_t debug;          // MC33_HIP_DEBUG, developer builds (-DMC33_DEV) only - timing experiments, results are wrong: 2 = stream
+	                         // only, 16 = stream + the cut-cell test of every slice but no slice is handed on, 64 = no halo-column load
 	SweepLane lane[SWEEP_MAXNI];
 };
 #ifdef MC33_DEV
@@ -458,6 +458,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	const SweepTile tile = a.tiles[wtile];
 	const uint32_t yt = tile.yt, seg = tile.seg;
 	const Params &P = a.P;
+	// The halo column (the first sample of the next row segment, one per row) used to be a load of its own: RB lanes of a
+	// batch each touching a different line for ONE sample - 8 % of the sweep's fabric reads at 1024^3 float, 15 % on the
+	// ushort grid of configs[4], two thirds of them missing L2 (the main loads are non-temporal), 6 % of the float sweep's
+	// time (tools/halo_cost.sh, profiles/r03_halo_cost.txt).  When the four waves of a block are the four segments of one
+	// 1024-sample group over the same rows and planes (the plan makes them so wherever the grid allows), wave k gets the bit
+	// from wave k + 1, which has just classified that very sample: every wave posts the column-0 bits of the plane it has
+	// completed (one ballot) in an LDS mailbox, one block barrier per PLANE (the four waves run in step anyway: a plane is
+	// ~270 loads), and only the last segment of the group still loads its halo.  All four waves complete the same number
+	// of planes (same rows, same z range), so every wave reaches every barrier; blocks of unrelated tiles keep the load.
+	bool grouped = !(MC33_DEBUG_BITS(a) & 128u);
+	{
+		const uint32_t t0 = blockIdx.x * 4u;
+		if (t0 + 3u >= a.ntiles) grouped = false;
+		else {
+			const SweepTile first = a.tiles[t0];
+#pragma unroll
+			for (uint32_t k = 1; k < 4; k++) {
+				const SweepTile o = a.tiles[t0 + k];
+				grouped = grouped && o.seg == first.seg + k && o.yt == first.yt && o.z_lo == first.z_lo && o.z_hi == first.z_hi;
+			}
+		}
+	}
+	__shared__ uint64_t s_mail[2][4][NI][2];  // [plane parity][wave][isovalue]{column-0 bits of the rows, rows whose column-0 sample may equal the isovalue}
+	const bool from_right = grouped && (threadIdx.x >> 6) < 3u;  // this wave's halo bits come from the wave to its right
 	const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	const unsigned long long c_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
@@ -560,7 +584,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 				else d[rr * LPR + k] = __builtin_amdgcn_raw_buffer_load_b32(rs, xo[k], so, MC33_SWEEP_AUX);
 			}
 		}
-		hv = MC33_LOAD(rs, (lane / (uint32_t)RB) == bi ? xh : 0xFFFFFFF0u, 0u);
+		// (MC33_HIP_DEBUG 64, developer builds: no halo sample is ever fetched - what the one-sample-per-row load costs the stream)
+		hv = MC33_LOAD(rs, ((lane / (uint32_t)RB) == bi && !from_right && !(MC33_DEBUG_BITS(a) & 64u)) ? xh : 0xFFFFFFF0u, 0u);
 	};
 	// the four samples of row rr of a batch in word order of layout S
 	auto sample = [&](const raw_t (&dd)[16], int rr, int k) -> real_t {
@@ -619,12 +644,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 		}
 		if (bi != NB - 1) return;
 		// ---- the plane is complete ----
+		uint64_t nb_bits[NI], nb_zero[NI];
+		if (grouped) {  // (block-uniform) column 0 of this plane for the wave to the left; the right neighbour's for this wave
+			const uint32_t par = (p - pl0) & 1u;
+#pragma unroll
+			for (int q = 0; q < NI; q++) {
+				const uint64_t hb = __ballot((c_lo[q][0] & 1u) != 0u);  // (word 0 bit 0 is the segment's first sample in every layout S)
+				if (lane == 0) {
+					s_mail[par][wv][q][0] = hb;
+					s_mail[par][wv][q][1] = (ZM != 2 && (zcacc[q] & 1ull)) ? zacc[q] : 0ull;  // (lane 0 loaded column 0; rows to the batch: a superset is fine)
+				}
+			}
+			// (not __syncthreads(): that also waits for the prefetched batch's loads - only the mailbox's LDS writes must have landed)
+			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+			for (int q = 0; q < NI; q++) {
+				nb_bits[q] = from_right ? s_mail[par][wv + 1u][q][0] : 0ull;
+				nb_zero[q] = from_right ? s_mail[par][wv + 1u][q][1] : 0ull;
+			}
+		}
 #pragma unroll
 		for (int q = 0; q < NI; q++) {
 			const SweepLane &L = a.lane[q];
 #pragma unroll
 			for (int k = 0; k < 4; k++) { cur[q][k] = u64(c_lo[q][k], c_hi[q][k]); c_lo[q][k] = c_hi[q][k] = 0; }
-			{
+			if (from_right) {  // (wave-uniform)
+				cur_h[q] = (uint32_t)((nb_bits[q] >> lane) & 1ull);
+				const uint64_t zh = nb_zero[q] & (nrows >= 64u ? ~0ull : ((1ull << nrows) - 1ull));
+				cur_z[q] = zacc[q] | zh;
+				cur_zc[q] = zh ? ~0ull : zcacc[q];
+				zacc[q] = zcacc[q] = 0;
+			} else {
 				const real_t dh = iso[q] - halo;
 				cur_h[q] = sign_of(dh);
 #ifdef MC33_NAN_SAMPLES

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (-DMC33_DEV build in tools/_dev): sweep time per sample type with the developer switches of k_sweep
-(MC33_HIP_DEBUG=2: the read stream alone; 16: stream + cut-cell test, nothing handed on)."""
+(MC33_HIP_DEBUG=2: the read stream alone; 16: stream + cut-cell test, nothing handed on; 64: no halo-column load).
+    python tools/time_sweep_dev.py f32|u16|u16c5|u8 0,64,0,64"""
 import os
 import sys
 
@@ -14,6 +15,12 @@ which = sys.argv[1] if len(sys.argv) > 1 else "u16"
 if which == "f32":
     t, r0, d = fields.cos_field_cube(1024, dev)
     iso = 0.0
+elif which == "u16c5":  # the grid of BASELINE configs[4]
+    t = fields.cos_field_u16(2048, 2048, 1024, dev)
+    iso = 30268.5
+elif which == "u8":
+    t = (fields.cos_field_u16(1024, 1024, 1024, dev).to(torch.int32) & 0xFFFF).div(256, rounding_mode="floor").to(torch.uint8)
+    iso = 128.5
 else:
     t = fields.cos_field_u16(1024, 1024, 1024, dev)
     iso = 32768.5
