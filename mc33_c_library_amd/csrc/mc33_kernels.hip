@@ -644,9 +644,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 		}
 		if (bi != NB - 1) return;
 		// ---- the plane is complete ----
-		uint64_t nb_bits[NI], nb_zero[NI];
+		const uint32_t par = (p - pl0) & 1u;
 		if (grouped) {  // (block-uniform) column 0 of this plane for the wave to the left; the right neighbour's for this wave
-			const uint32_t par = (p - pl0) & 1u;
 #pragma unroll
 			for (int q = 0; q < NI; q++) {
 				const uint64_t hb = __ballot((c_lo[q][0] & 1u) != 0u);  // (word 0 bit 0 is the segment's first sample in every layout S)
@@ -657,20 +656,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 			}
 			// (not __syncthreads(): that also waits for the prefetched batch's loads - only the mailbox's LDS writes must have landed)
 			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-			for (int q = 0; q < NI; q++) {
-				nb_bits[q] = from_right ? s_mail[par][wv + 1u][q][0] : 0ull;
-				nb_zero[q] = from_right ? s_mail[par][wv + 1u][q][1] : 0ull;
-			}
 		}
 #pragma unroll
 		for (int q = 0; q < NI; q++) {
 			const SweepLane &L = a.lane[q];
 #pragma unroll
 			for (int k = 0; k < 4; k++) { cur[q][k] = u64(c_lo[q][k], c_hi[q][k]); c_lo[q][k] = c_hi[q][k] = 0; }
-			if (from_right) {  // (wave-uniform)
-				cur_h[q] = (uint32_t)((nb_bits[q] >> lane) & 1ull);
-				const uint64_t zh = nb_zero[q] & (nrows >= 64u ? ~0ull : ((1ull << nrows) - 1ull));
+			if (from_right) {  // (wave-uniform; the mailbox word is read here, per isovalue: held over the loop it cost the 4-isovalue form registers it does not have)
+				const uint64_t nb_bits = s_mail[par][wv + 1u][q][0], nb_zero = ZM != 2 ? s_mail[par][wv + 1u][q][1] : 0ull;
+				cur_h[q] = (uint32_t)((nb_bits >> lane) & 1ull);
+				const uint64_t zh = nb_zero & (nrows >= 64u ? ~0ull : ((1ull << nrows) - 1ull));
 				cur_z[q] = zacc[q] | zh;
 				cur_zc[q] = zh ? ~0ull : zcacc[q];
 				zacc[q] = zcacc[q] = 0;

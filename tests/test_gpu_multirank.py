@@ -80,6 +80,35 @@ def test_bench_self_launch_c3_strong_scaling(launcher, reflibs, tmp_path):
     assert np.array_equal(got["N"].view(np.uint32), ref.N.view(np.uint32))
 
 
+@pytest.mark.parametrize("gather", ["allgather", "pairs", "root"])
+def test_bench_strong_scaling_six_rank_processes(launcher, reflibs, tmp_path, gather):
+    """configs[3]'s geometry with as many rank PROCESSES as a one-GPU box allows (6 may use the card together; the config
+    names 8): `bench.py --gpus 6 --strong --points 256` started exactly as the driver starts it, the 256^3 grid in six
+    z-slabs of 42 / 43 slices, every exchange mode; the concatenated surface against oracle/_ref on the whole grid."""
+    dump = str(tmp_path / "surf.npz")
+    n = 256
+    res, out = bench(launcher, ["--gpus", "6", "--steps", "2", "--warmup", "1", "--points", str(n), "--gather", gather, "--strong", "--rank-timeout", "600"],
+                     {"MC33_BENCH_DUMP": dump, "OMP_NUM_THREADS": "2"}, timeout=900)
+    assert res["n_gpus"] == 6 and res["scaling"] == "strong" and res["gather"]["mode"] == gather
+    assert "equals whole-volume result: True" in out["stderr"]
+    assert res["rank_sweep_ms"]["min"] > 0 and res["rank_sweep_ms"]["max"] >= res["rank_sweep_ms"]["min"]
+    data, r0, d = fx.cos_field(n)
+    ref = reflibs["f32"].isosurface(data, 0.0, r0, d)
+    got = np.load(dump)
+    assert res["config"]["vertices"] == ref.nV and res["config"]["triangles"] == ref.nT
+    assert np.array_equal(got["T"], ref.T) and np.array_equal(got["V"].view(np.uint32), ref.V.view(np.uint32))
+    assert np.array_equal(got["N"].view(np.uint32), ref.N.view(np.uint32))
+
+
+def test_bench_parent_kills_stuck_ranks(launcher):
+    """--rank-timeout: a self-launched run whose ranks do not finish in time is killed by the parent (process groups of
+    fresh children, never a re-exec), which exits non-zero and says so - instead of holding the GPU until somebody else's
+    limit.  One second is not enough for anything."""
+    out = launcher.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--points", "96", "--rank-timeout", "1"],
+                       env={"MC33_BENCH_REHEARSAL": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, unset=["WORLD_SIZE", "RANK", "LOCAL_RANK"], timeout=300)
+    assert out["rc"] != 0 and "--rank-timeout" in out["stderr"] and not any(l.startswith("{") for l in out["stdout"].splitlines())
+
+
 def test_bench_self_launch_c5_rehearsal(launcher, reflibs, tmp_path):
     """The ushort / 8-isovalue config on 3 rank processes (strong scaling: one grid cut into z-slabs)."""
     dump = str(tmp_path / "surf.npz")
@@ -98,7 +127,7 @@ def test_bench_self_launch_c5_rehearsal(launcher, reflibs, tmp_path):
 
 def test_bench_single_gpu_lines(launcher):
     """The default line and the C5 line at reduced size: contract keys, roofline and cpu_baseline objects."""
-    for args, name in ((["--points", "128"], "c3"), (["--config", "c5", "--points", "64"], "c5")):
+    for args, name in ((["--points", "128", "--with-c5", "on", "--c5-points", "48", "--c5-steps", "2"], "c3"), (["--config", "c5", "--points", "64"], "c5")):
         res, _ = bench(launcher, ["--steps", "3", "--warmup", "1"] + args, {"MC33_BENCH_REHEARSAL": "0", "MC33_BENCH_VERIFY": "0"})
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                     "data", "config", "roofline", "cpu_baseline", "step_ms_min", "step_ms_median", "step_ms_max"):
@@ -106,6 +135,13 @@ def test_bench_single_gpu_lines(launcher):
         assert res["config"]["name"] == name and res["n_gpus"] == 1 and res["vs_baseline"] is None
         assert res["roofline"]["bound"] == "hbm" and res["roofline"]["frac"] > 0 and res["roofline"]["traffic"] is None
         assert res["cpu_baseline"]["kind"] == "reference" and res["cpu_baseline"]["cores"] == 1 and res["cpu_baseline"]["value"] > 0
+        assert res["without_event_records"]["ms_per_step"] > 0 and res["roofline"]["step_bytes_moved"] > res["roofline"]["algorithmic_bytes_per_launch"]
+        if name == "c3":  # the configs[4] workload rides on the default line as a compact object
+            c5 = res["c5"]
+            assert c5["dtype"] == "u16" and c5["value"] > 0 and c5["roofline"]["isovalues_per_launch"] == 4 and c5["roofline"]["frac"] > 0
+            assert c5["roofline"]["step_frac"] > 0 and c5["cpu_baseline"]["value"] > 0 and "all 8 isovalues" in c5["cpu_baseline"]["sample"]
+        else:
+            assert "c5" not in res and res["roofline"]["whole_call_reference_equivalent"]["frac"] > res["roofline"]["step_frac"]
 
 
 def test_programs_built_against_the_reference_header(launcher):

@@ -270,6 +270,42 @@ def test_config2_cos1024_full_size(products, reflibs):
     # size-independent properties: closed level set away from the box faces -> every interior edge is shared by
     # exactly two triangles; ids are dense
     assert got.T.max() == got.nV - 1 and np.all(got.color == got.color[0])
+    # BASELINE.json configs[3] at ITS size, as far as one GPU allows: the same 1024^3 grid cut into 8 z-slabs of 128 / 127
+    # cell slices (the --strong reading; `Slab` is what every rank of bench.py builds), each slab a context of its own
+    # holding only its planes + ghost, one after the other on this GPU: counts exchanged on the host, every slab emitting at
+    # its global vertex base.  The concatenation in rank order must be the whole-volume arrays, bit for bit - and so the
+    # reference's.
+    import torch
+    from mc33_c_library_amd import DeviceGrid
+    from mc33_c_library_amd.slabs import Slab
+    world, nz_total = 8, data.shape[0] - 1
+    slabs = [Slab(r, world, nz_total) for r in range(world)]
+    assert [sl.z_end - sl.z_begin for sl in slabs] == [127, 128, 128, 128, 128, 128, 128, 128] and slabs[-1].z_end == nz_total
+    counts = []
+    for sl in slabs:   # pass 1 (every rank: count)
+        t = torch.from_numpy(data[sl.p_lo:sl.p_hi + 1]).cuda()
+        g = DeviceGrid(t, nz_total=nz_total, plane0=sl.p_lo, r0=r0, d=d)
+        c = g.count(0.0, sl.range())
+        counts.append((c.nV, c.nT))
+        g.close()
+        del g, t
+    assert (sum(c[0] for c in counts), sum(c[1] for c in counts)) == (ref.nV, ref.nT)
+    Vc = torch.empty((ref.nV, 3), dtype=torch.float32, device="cuda"); Nc = torch.empty_like(Vc)
+    Tc = torch.empty((ref.nT, 3), dtype=torch.int32, device="cuda")
+    vb = tb = 0
+    for sl, (nV, nT) in zip(slabs, counts):   # pass 2 (every rank: emit at its global base, straight into its place)
+        t = torch.from_numpy(data[sl.p_lo:sl.p_hi + 1]).cuda()
+        g = DeviceGrid(t, nz_total=nz_total, plane0=sl.p_lo, r0=r0, d=d)
+        c = g.count(0.0, sl.range())
+        assert (c.nV, c.nT) == (nV, nT)
+        g.emit_into(Vc[vb:vb + nV], Nc[vb:vb + nV], Tc[tb:tb + nT], vb)
+        torch.cuda.synchronize()
+        g.close()
+        del g, t
+        vb += nV; tb += nT
+    assert np.array_equal(Tc.cpu().numpy().view(np.uint32), ref.T)
+    assert np.array_equal(Vc.cpu().numpy().view(np.uint32), ref.V.view(np.uint32))
+    assert np.array_equal(Nc.cpu().numpy().view(np.uint32), ref.N.view(np.uint32))
 
 
 def test_config4_u16_wide_rows(products, reflibs):
