@@ -1265,6 +1265,8 @@ MC33_HD void emit_fast_vertices(const EmitCtx<T> &c, const Entry &en, uint32_t s
 // addresses), so the loads carry no control flow.  The edges have no end point equal to the isovalue (they
 // are edges of a fast cell), so their owners created regular vertices: no alias to follow.
 template <typename T>
+MC33_HD void fast_triangles_write(const EmitCtx<T> &c, const Entry &en, const Entry (&oe)[6], const uint32_t (&ovb)[6], const SegBase &sb, const URef &ids);
+template <typename T>
 MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t s, uint32_t self_index, const URef &ids) {
 	if (segment_coord(c.P, s).z < c.z_emit) return;
 	const uint32_t xl = en.w0 & 0xFFu;
@@ -1327,6 +1329,14 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, uint32_t 
 		}
 		for (int o = 0; o < 6; o++) oe[o] = entry_join(oa[o], ctx_half_b(c, oa[o], oi[o]));
 	}
+	fast_triangles_write(c, en, oe, ovb, sb, ids);
+}
+
+// ... the second half: the triangles of the record from its six owner records oe[] (o0 .. o5 above; a record that is not
+// needed may be anything) and the first vertex of each owner's row segment ovb[]; sb: the record's own segment.
+template <typename T>
+MC33_HD void fast_triangles_write(const EmitCtx<T> &c, const Entry &en, const Entry (&oe)[6], const uint32_t (&ovb)[6], const SegBase &sb, const URef &ids) {
+	const uint32_t i = (en.w0 >> 8) & 0xFFu;
 	uint32_t ob[6];
 	for (int o = 0; o < 6; o++) ob[o] = ovb[o] + (oe[o].w1 & 0xFFFFu);
 	ids[0] = ob[0] + entry_rank(oe[0], 6);

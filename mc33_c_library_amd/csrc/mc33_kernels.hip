@@ -1838,7 +1838,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 	}
 }
 
-// triangles of the fast records (ids of shared edges through the owners' records)
+// triangles of the fast records (ids of shared edges through the owners' records).
+// (Round 3 tried the wave-per-batch form of k_emit_vertices here too: row bases by row, the batch's owner records - two short
+// runs of the record array, bounded by a wave minimum / maximum - staged in LDS by coalesced loads, 10 instead of 22 load
+// instructions per 64 records.  Bit-identical, and slower: 568 against 395 us per isovalue at C5.  A batch is a chain of
+// dependent steps - directory words, run bounds, staging, LDS, ids - and 16 waves per CU do not hide it; one thread per
+// record at 32 waves per CU does.  Dropped.)
 __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	__shared__ uint32_t s_id[13][256];
 	__shared__ EntryB s_fast_b[256];
@@ -2755,6 +2760,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.stage_rows = ((uintptr_t)c->d_grid % 16u) == 0 && (c->pitch * sizeof(sample_t)) % 16u == 0 && (c->slice * sizeof(sample_t)) % 16u == 0 &&
 	               !env_u32("MC33_HIP_NO_STAGE", 0);
 	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 64u);
+	if (!c->cus) HIP_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, c->device));
 	// The three emit passes are independent (V/N vs T, fast vs slow records).  While each of them waited through a chain of
 	// dependent loads (rounds 1 and most of 2) running them side by side on three streams paid on large grids (0.15 instead
 	// of 0.18 ms at 768^3); with the loads of a round trip asked for together they keep the GPU busy by themselves and
@@ -2780,10 +2786,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	if (!env_u32("MC33_HIP_OLD_VERTEX_PASS", 0)) {
 		// as many blocks as the device holds at once (one more round of blocks would run with most of the GPU idle); every wave
 		// walks many batches, its next batch's records in flight while it works on one
-		if (!c->cus) {
-			HIP_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, c->device));
-			HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->emit_v_blocks_per_cu, k_emit_vertices, 256, 0));
-		}
+		if (!c->emit_v_blocks_per_cu) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->emit_v_blocks_per_cu, k_emit_vertices, 256, 0));
 		const uint32_t vblocks = (uint32_t)std::max(1, c->cus) * env_u32("MC33_HIP_EMIT_V_BLOCKS_PER_CU", (uint32_t)std::max(1, c->emit_v_blocks_per_cu));
 		hipLaunchKernelGGL(k_emit_vertices, dim3((vblocks + 7u) & ~7u), dim3(256), 0, c->stream, a);
 	}

@@ -81,15 +81,16 @@ def test_bench_self_launch_c3_strong_scaling(launcher, reflibs, tmp_path):
 
 
 @pytest.mark.parametrize("gather", ["allgather", "pairs", "root"])
-def test_bench_strong_scaling_six_rank_processes(launcher, reflibs, tmp_path, gather):
-    """configs[3]'s geometry with as many rank PROCESSES as a one-GPU box allows (6 may use the card together; the config
-    names 8): `bench.py --gpus 6 --strong --points 256` started exactly as the driver starts it, the 256^3 grid in six
-    z-slabs of 42 / 43 slices, every exchange mode; the concatenated surface against oracle/_ref on the whole grid."""
+def test_bench_strong_scaling_five_rank_processes(launcher, reflibs, tmp_path, gather):
+    """configs[3]'s geometry with as many rank PROCESSES as a one-GPU box allows (6 processes may have the card open, this
+    pytest process is one of them; the config names 8): `bench.py --gpus 5 --strong --points 256` started exactly as the
+    driver starts it, the 256^3 grid in five z-slabs of 51 slices, every exchange mode; the concatenated surface against
+    oracle/_ref on the whole grid."""
     dump = str(tmp_path / "surf.npz")
     n = 256
-    res, out = bench(launcher, ["--gpus", "6", "--steps", "2", "--warmup", "1", "--points", str(n), "--gather", gather, "--strong", "--rank-timeout", "600"],
+    res, out = bench(launcher, ["--gpus", "5", "--steps", "2", "--warmup", "1", "--points", str(n), "--gather", gather, "--strong", "--rank-timeout", "600"],
                      {"MC33_BENCH_DUMP": dump, "OMP_NUM_THREADS": "2"}, timeout=900)
-    assert res["n_gpus"] == 6 and res["scaling"] == "strong" and res["gather"]["mode"] == gather
+    assert res["n_gpus"] == 5 and res["scaling"] == "strong" and res["gather"]["mode"] == gather
     assert "equals whole-volume result: True" in out["stderr"]
     assert res["rank_sweep_ms"]["min"] > 0 and res["rank_sweep_ms"]["max"] >= res["rank_sweep_ms"]["min"]
     data, r0, d = fx.cos_field(n)

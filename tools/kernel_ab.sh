@@ -11,7 +11,7 @@ k=0
 for setting in "$@"; do
   k=$((k+1))
   d=$O/run$k
-  ( export $setting MC33_BENCH_NO_CPU=1; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o r -- python3 bench.py "${ARGS[@]}" > $d.json 2> $d.err )
+  ( export $setting MC33_BENCH_NO_CPU=1 MC33_BENCH_WITH_C5=off; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o r -- python3 bench.py "${ARGS[@]}" > $d.json 2> $d.err )
   echo "==== [$setting] ${ARGS[*]}"
   python3 - "$d" <<'PY'
 import csv, glob, sys
