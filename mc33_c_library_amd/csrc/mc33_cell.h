@@ -630,18 +630,22 @@ MC33_HD void mat_vec(const double *A, real_t *b, bool transposed, bool triangula
 	b[0] = (real_t)u; b[1] = (real_t)v;
 }
 
-// world position and unit normal of vertex `id` (MC:485-621)
+// world position and unit normal of vertex `id` (MC:485-621).  MODE: the store (Params::store_mode) when the caller knows it
+// at compile time - the kernels that are bound by their instruction count are built once per store, and the two 3 x 3
+// double matrices of MC33_spnC stay out of the registers of the other three; -1: looked up in P.
+template <int MODE = -1>
 MC33_HD void store_vertex(const Params &P, real_t *r, real_t *V, float *N, uint32_t id) {
+	const int store_mode = MODE < 0 ? P.store_mode : MODE;
 	real_t *p = V + 3 * (uint64_t)id;
-	if (P.store_mode == 0) {
+	if (store_mode == 0) {
 		p[0] = r[0]; p[1] = r[1]; p[2] = r[2];
-	} else if (P.store_mode == 3) {  // MC:607-612
+	} else if (store_mode == 3) {  // MC:607-612
 		mat_vec(P.A, r, false, P.triangular != 0);
 		for (int k = 0; k < 3; k++) p[k] = r[k] + P.O[k];
 		mat_vec(P.Ai, r + 3, true, P.triangular != 0);
 	} else {
 		for (int k = 0; k < 3; k++) p[k] = r[k] * P.D[k] + P.O[k];
-		if (P.store_mode == 2) { r[3] *= P.ca; r[4] *= P.cb; }
+		if (store_mode == 2) { r[3] *= P.ca; r[4] *= P.cb; }
 	}
 	// MC:510-515: the squared length is MC33_real, the inverse root and the normal are float
 	float s = inv_sqrt_exact((float)(r[3] * r[3] + r[4] * r[4] + r[5] * r[5]));
@@ -1188,7 +1192,7 @@ MC33_HD void fast_samples_direct(const GridView<T> &G, uint32_t x, uint32_t y, u
 // Vertices of one FAST / TESTED record from its samples: positions, normals, stores.  The arithmetic and its order are
 // those of vertex_on_edge (MC:990-1000, 1029-1039, 1175-1185).  rN: rank of the vertex of edge N / of the centre among the
 // vertices this cell creates (15: none); vbase: id of the cell's first vertex.
-template <typename T>
+template <typename T, int MODE = -1>
 MC33_HD void fast_vertices_compute(const EmitCtx<T> &c, uint32_t x, uint32_t y, uint32_t z, uint32_t vbase, uint32_t r5, uint32_t r6, uint32_t r10,
                                    uint32_t r12, const FastSamples<T> &S) {
 	const Params &P = c.P;
@@ -1208,7 +1212,7 @@ MC33_HD void fast_vertices_compute(const EmitCtx<T> &c, uint32_t x, uint32_t y, 
 		r[4] = yin ? 0.5f * (sample_diff(F[0][1], Y2[0][1]) * (1 - t) + sample_diff(F[2][1], Y2[1][1]) * t)
 		           : (v5 - v4) * (1 - t) + (v6 - v7) * t;
 		r[5] = v6 - v5;
-		store_vertex(P, r, c.V, c.N, vbase + r5 - c.v_skip);
+		store_vertex<MODE>(P, r, c.V, c.N, vbase + r5 - c.v_skip);
 	}
 	if (r6 != 15u) {  // edge 6: (x+1, y, z+1) -> (x+1, y+1, z+1)
 		const real_t t = v7 / (v7 - v6);
@@ -1218,7 +1222,7 @@ MC33_HD void fast_vertices_compute(const EmitCtx<T> &c, uint32_t x, uint32_t y, 
 		r[4] = v6 - v7;
 		r[5] = zin ? 0.5f * (sample_diff(F[0][1], Z2[0][1]) * (1 - t) + sample_diff(F[1][1], Z2[1][1]) * t)
 		           : (v7 - v4) * (1 - t) + (v6 - v5) * t;
-		store_vertex(P, r, c.V, c.N, vbase + r6 - c.v_skip);
+		store_vertex<MODE>(P, r, c.V, c.N, vbase + r6 - c.v_skip);
 	}
 	if (r10 != 15u) {  // edge 10: (x, y+1, z+1) -> (x+1, y+1, z+1)
 		const real_t t = v2 / (v2 - v6);
@@ -1228,13 +1232,13 @@ MC33_HD void fast_vertices_compute(const EmitCtx<T> &c, uint32_t x, uint32_t y, 
 		           : (v2 - v3) * (1 - t) + (v6 - v7) * t;
 		r[5] = zin ? 0.5f * (sample_diff(F[1][0], Z2[1][0]) * (1 - t) + sample_diff(F[1][1], Z2[1][1]) * t)
 		           : (v2 - v1) * (1 - t) + (v6 - v5) * t;
-		store_vertex(P, r, c.V, c.N, vbase + r10 - c.v_skip);
+		store_vertex<MODE>(P, r, c.V, c.N, vbase + r10 - c.v_skip);
 	}
 	if (r12 != 15u) {  // centre vertex of a tested cell (MC:1225-1230)
 		real_t vv[8] = {iso_diff(iso, (real_t)F[0][0]), iso_diff(iso, (real_t)F[1][0]), iso_diff(iso, (real_t)F[3][0]), iso_diff(iso, (real_t)F[2][0]),
 		                iso_diff(iso, (real_t)F[0][1]), iso_diff(iso, (real_t)F[1][1]), iso_diff(iso, (real_t)F[3][1]), iso_diff(iso, (real_t)F[2][1])};
 		vertex_centre(x, y, z, VRef{vv, 1}, r);
-		store_vertex(P, r, c.V, c.N, vbase + r12 - c.v_skip);
+		store_vertex<MODE>(P, r, c.V, c.N, vbase + r12 - c.v_skip);
 	}
 }
 

@@ -1588,10 +1588,13 @@ __device__ __forceinline__ BatchInfo load_batch(const BatchDesc *batches, uint32
 	return BatchInfo{p[0], p[1], p[2], p[3], p[4], p[5]};
 }
 
+// waves per SIMD the LDS image allows (4 blocks of 35 KiB with 2-chunk windows, 3 of 47 KiB with 3, 2 of 60 KiB with 4): the
+// kernel may use the registers that leaves it, and no more
 #ifndef MC33_EV_WAVES
-#define MC33_EV_WAVES 3
+#define MC33_EV_WAVES (MC33_SAMPLE_BYTES <= 2 ? 4 : MC33_SAMPLE_BYTES == 8 ? 2 : 3)
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAVES, 4))) void k_emit_vertices(const EmitArgs a) {
+template <int MODE>  // the vertex store (Params::store_mode): one kernel per store, see store_vertex
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAVES, MC33_EV_WAVES))) void k_emit_vertices(const EmitArgs a) {
 	constexpr uint32_t SZ = (uint32_t)sizeof(sample_t);
 	__shared__ EntryB s_fast_b[256];
 	__shared__ EmitVLds s_w[4];
@@ -1686,29 +1689,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 					if (on && (lane + 1u == count || above != rho)) L.rowB[rho] = lane << 8 | xl;
 				}
 				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-				// ---- lane = sample row r of the tile: the chunks of it the batch needs (the records of cell rows r-2 .. r)
-				auto row_window = [&](uint32_t r) -> uint32_t {
-					uint32_t xmin = 255u, xmax = 0u;
-					bool any = false;
-#pragma unroll
-					for (uint32_t k = 0; k < 3; k++) {
-						const int ri = (int)r - (int)k;  // (signed: see valid_masks)
-						const bool in = ri >= 0 && ri <= 62;
-						const uint32_t rr = in ? (uint32_t)ri : 0u;
-						const uint32_t fa = L.rowA[rr], fb = L.rowB[rr];
-						const bool have = in && fa != EV_EMPTY;
-						xmin = have ? min(xmin, fa & 0xFFu) : xmin;
-						xmax = have ? max(xmax, fb & 0xFFu) : xmax;
-						any |= have;
-					}
+				// ---- lane = sample row r of the tile: the chunks of it the batch needs = those of the records of cell rows r-2 .. r.
+				// Lane r reads the first / last record of cell row r and gets rows r-1, r-2 from the lanes below (DPP); sample row 64
+				// (above cell row 62 only) is lane 62's own interval, computed by every lane alike.
+				const uint32_t fa = L.rowA[lane], fb = L.rowB[lane];
+				const bool have = lane <= 62u && fa != EV_EMPTY;
+				const uint32_t mn0 = have ? fa & 0xFFu : 255u, mx0 = have ? fb & 0xFFu : 0u;
+				// (the shifts with every lane enabled, pinned by an empty asm: written as `lane >= 1 ? lane_below(..) : ..` the compiler
+				// turned the select into a branch and ran the DPP move under it - lane 0 disabled, so lane 1 read nothing)
+				uint32_t mn1 = lane_below(mn0), mx1 = lane_below(mx0);
+				asm volatile("" : "+v"(mn1), "+v"(mx1));
+				uint32_t mn2 = lane_below(mn1), mx2 = lane_below(mx1);
+				asm volatile("" : "+v"(mn2), "+v"(mx2));
+				mn1 = lane >= 1u ? mn1 : 255u; mx1 = lane >= 1u ? mx1 : 0u;
+				mn2 = lane >= 2u ? mn2 : 255u; mx2 = lane >= 2u ? mx2 : 0u;
+				auto window = [&](uint32_t r, uint32_t xmin, uint32_t xmax) -> uint32_t {  // (xmin > xmax: no record needs the row)
 					const uint32_t lo = xbase + xmin, hi = min(xbase + xmax + 2u, P.nx);
 					const uint32_t clo = (lo * SZ) >> 4, nm1 = ((hi * SZ + SZ - 1u) >> 4) - clo;  // first chunk, chunks - 1
-					const bool staged = any && y0 + r <= P.ny && nm1 < EV_W;
+					const bool staged = xmin <= xmax && y0 + r <= P.ny && nm1 < EV_W;
 					return (staged ? 1u << 31 : 0u) | (nm1 & 3u) << 16 | ((clo - cbase) & 0xFFFFu);
 				};
-				L.rowinfo[lane] = row_window(lane);
-				const uint32_t info64 = row_window(64u);  // (sample row 64, needed by cell row 62: every lane computes the same)
-				if (lane == 0) L.rowinfo[64] = info64;
+				L.rowinfo[lane] = window(lane, min(mn0, min(mn1, mn2)), max(mx0, max(mx1, mx2)));
+#ifdef MC33_DEV  // the same interval straight from the table
+				{
+					uint32_t xmin = 255u, xmax = 0u;
+					for (int k = 0; k < 3; k++) {
+						const int ri = (int)lane - k;
+						if (ri >= 0 && ri <= 62 && L.rowA[ri] != EV_EMPTY) { xmin = min(xmin, L.rowA[ri] & 0xFFu); xmax = max(xmax, L.rowB[ri] & 0xFFu); }
+					}
+					if (xmin != min(mn0, min(mn1, mn2)) || xmax != max(mx0, max(mx1, mx2)))
+						if (atomicCAS(&a.ctr->debug[0], 0u, 2u) == 0u) { a.ctr->debug[1] = lane; a.ctr->debug[2] = xmin; a.ctr->debug[3] = xmax; a.ctr->debug[4] = min(mn0, min(mn1, mn2)); a.ctr->debug[5] = max(mx0, max(mx1, mx2)); a.ctr->debug[6] = mn1; a.ctr->debug[7] = mn2; }
+				}
+#endif
+				{
+					const uint32_t info64 = window(64u, (uint32_t)__builtin_amdgcn_readlane((int)mn0, 62), (uint32_t)__builtin_amdgcn_readlane((int)mx0, 62));
+					if (lane == 0) L.rowinfo[64] = info64;
+				}
 				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 				i0 = L.rowinfo[rho]; i1 = L.rowinfo[rho + 1u]; i2 = L.rowinfo[yin ? rho + 2u : rho];
 				staged_lane = creates && ((i0 & i1 & i2) >> 31) != 0u;
@@ -1720,18 +1736,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 				// the group ended up in scratch memory)
 				const char *plane0 = (const char *)G.p + ((uint64_t)(z - G.z0) * G.slice + (uint64_t)y0 * G.pitch) * SZ + (uint64_t)cbase * 16u;
 				const uint32_t pitchB = G.pitch * SZ;
-				const uint4 zero4 = {0u, 0u, 0u, 0u};
 				constexpr uint32_t NITEM = EV_ROWS * EV_W, NGRP = (NITEM + 63u) / 64u;
 				static_assert(NGRP <= 5, "groups of the staging loads");
+				// (the row words of all groups first: one LDS wait, not one per group)
+				uint32_t info[NGRP];
+#pragma unroll
+				for (uint32_t g = 0; g < NGRP; g++) info[g] = L.rowinfo[min((g * 64u + lane) / EV_W, EV_ROWS - 1u)];
+				const uint4 zero4 = {0u, 0u, 0u, 0u};
 				uint4 qa0 = zero4, qa1 = zero4, qa2 = zero4, qb0 = zero4, qb1 = zero4, qb2 = zero4, qc0 = zero4, qc1 = zero4, qc2 = zero4;
 				uint4 qd0 = zero4, qd1 = zero4, qd2 = zero4, qe0 = zero4, qe1 = zero4, qe2 = zero4;
 				auto fetch = [&](uint32_t g, uint4 &q0, uint4 &q1, uint4 &q2) -> bool {
 					const uint32_t it = g * 64u + lane;
 					const uint32_t r = it / EV_W, ck = it - r * EV_W;
-					const uint32_t info = L.rowinfo[min(r, EV_ROWS - 1u)];
-					const bool need = it < NITEM && (info >> 31) && ck <= ((info >> 16) & 3u);
-					if (need) {
-						const char *addr = plane0 + (uint64_t)r * pitchB + (uint64_t)((info & 0xFFFFu) + ck) * 16u;
+					const bool need = it < NITEM && (info[g] >> 31) && ck <= ((info[g] >> 16) & 3u);
+					if (need) {  // (unconditional loads from a safe address for the other lanes were tried: 4 % slower on ushort grids)
+						const char *addr = plane0 + (uint64_t)r * pitchB + (uint64_t)((info[g] & 0xFFFFu) + ck) * 16u;
 						q0 = *(const uint4 *)addr;
 						q1 = *(const uint4 *)(addr + sliceB);
 						if (zin) q2 = *(const uint4 *)(addr + 2u * sliceB);
@@ -1787,10 +1806,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 						const uint32_t rank = kind == 0u ? (w0 >> 16) & 15u : kind == 1u ? (w0 >> 20) & 15u : (w0 >> 24) & 15u;
 						// sample (dx, dy, dz) of the cell: byte in the image
 						const uint32_t xb0 = vxl * SZ + ((xbase * SZ) & 15u);
+						// (the byte of sample x in the three rows of the cell, once; a plane is EV_ROWS * EV_W chunks on)
+						const uint32_t rb0 = (vrho * EV_W - (w1 & 0xFFu)) * 16u + xb0, rb1 = ((vrho + 1u) * EV_W - ((w1 >> 8) & 0xFFu)) * 16u + xb0,
+						               rb2 = ((vrho + 2u) * EV_W - ((w1 >> 16) & 0xFFu)) * 16u + xb0;
 						auto smp = [&](uint32_t dx, uint32_t dy, uint32_t dz) -> sample_t {
-							const uint32_t clo = dy == 0u ? w1 & 0xFFu : dy == 1u ? (w1 >> 8) & 0xFFu : (w1 >> 16) & 0xFFu;
-							const uint32_t byte = ((dz * EV_ROWS + vrho + dy) * EV_W - clo) * 16u + xb0 + dx * SZ;
-							return *(const sample_t *)(img + byte);
+							const uint32_t rb = dy == 0u ? rb0 : dy == 1u ? rb1 : rb2;
+							return *(const sample_t *)(img + rb + dz * (EV_ROWS * EV_W * 16u) + dx * SZ);
 						};
 						// corner A of the edge: (1,1,0) edge 5 | (1,0,1) edge 6 | (0,1,1) edge 10; B = (1,1,1)
 						const uint32_t ax = kind != 2u, ay = kind != 1u, az = kind != 0u;
@@ -1820,7 +1841,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 						r[3] = kind == 2u ? g0 : g1;
 						r[4] = kind == 0u ? g2 : kind == 1u ? g0 : g1;
 						r[5] = kind == 0u ? g0 : g2;
-						store_vertex(P, r, c.V, c.N, vb + rank - c.v_skip);
+						store_vertex<MODE>(P, r, c.V, c.N, vb + rank - c.v_skip);
 					}
 				}
 			}
@@ -1828,7 +1849,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 				if (direct) {
 					FastSamples<sample_t> S;
 					fast_samples_direct(G, x, y, z, xin, yin, zin, S);
-					fast_vertices_compute(c, x, y, z, vbase, r5, r6, r10, r12, S);
+					fast_vertices_compute<sample_t, MODE>(c, x, y, z, vbase, r5, r6, r10, r12, S);
 				}
 			}
 		} else next_batch();
@@ -2786,9 +2807,15 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	if (!env_u32("MC33_HIP_OLD_VERTEX_PASS", 0)) {
 		// as many blocks as the device holds at once (one more round of blocks would run with most of the GPU idle); every wave
 		// walks many batches, its next batch's records in flight while it works on one
-		if (!c->emit_v_blocks_per_cu) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->emit_v_blocks_per_cu, k_emit_vertices, 256, 0));
+		if (!c->emit_v_blocks_per_cu) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->emit_v_blocks_per_cu, k_emit_vertices<3>, 256, 0));
 		const uint32_t vblocks = (uint32_t)std::max(1, c->cus) * env_u32("MC33_HIP_EMIT_V_BLOCKS_PER_CU", (uint32_t)std::max(1, c->emit_v_blocks_per_cu));
-		hipLaunchKernelGGL(k_emit_vertices, dim3((vblocks + 7u) & ~7u), dim3(256), 0, c->stream, a);
+		const dim3 vgrid((vblocks + 7u) & ~7u);
+		switch (c->P.store_mode) {
+		case 0: hipLaunchKernelGGL(k_emit_vertices<0>, vgrid, dim3(256), 0, c->stream, a); break;
+		case 1: hipLaunchKernelGGL(k_emit_vertices<1>, vgrid, dim3(256), 0, c->stream, a); break;
+		case 2: hipLaunchKernelGGL(k_emit_vertices<2>, vgrid, dim3(256), 0, c->stream, a); break;
+		default: hipLaunchKernelGGL(k_emit_vertices<3>, vgrid, dim3(256), 0, c->stream, a); break;
+		}
 	}
 	else hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);  // (the round-2 pass, for A/B timing)
 	hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, sv, a);
