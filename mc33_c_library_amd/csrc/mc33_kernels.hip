@@ -1452,6 +1452,7 @@ struct EmitArgs {
 	const BatchDesc *batches;  // the records in batches of one slice slot (k_cells)
 	uint32_t batch_cap;
 	uint32_t stage_rows;  // every sample row of the grid starts on a 16-byte boundary: k_emit_vertices may stage rows in LDS
+	Counters *host_ctr;   // pinned host copy of the counters: the triangle pass (the last kernel of an extraction) leaves them there
 };
 
 // The fast emit passes take the records in storage order, which k_slots made (4 slices of a tile column, next
@@ -1873,7 +1874,16 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
 	c.fast_b = s_fast_b; c.fast_b_in_lds = true;
-	if (!emit_prepare(a, c, ctr)) return;
+	const bool ok = emit_prepare(a, c, ctr);
+	// The counters of the extraction for the host, straight into its pinned copy (everything before this kernel on the stream
+	// has finished: they are final, and every emit kernel decides `emit_skipped` alike): the call's one synchronisation then
+	// finds them there, without a device-to-host copy command of 100 bytes behind the last kernel.
+	if (a.host_ctr && blockIdx.x == 0 && threadIdx.x == 0) {
+		Counters out = ctr;
+		out.emit_skipped = ok ? 0u : 1u;
+		*a.host_ctr = out;
+	}
+	if (!ok) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
 	const XcdWalk w(ctr.entry_cursor);
 	for (uint32_t e = w.first; e < w.end; e += w.stride) {
@@ -1986,6 +1996,7 @@ struct mc33hip_ctx {
 	int cus;                  // compute units of the device
 	int emit_v_blocks_per_cu; // blocks of k_emit_vertices a CU holds
 	Counters *d_ctr, *h_ctr;
+	bool ctr_published;       // the emit pass enqueued last leaves the counters in h_ctr itself (k_emit_fast_triangles)
 	hipEvent_t ev[4];
 	hipEvent_t ev_many[MC33_MANY_PASSES][2];  // mc33hip_sweep_many's passes: recorded around each, read in read_timing (nobody waits)
 	hipStream_t aux, aux2;    // the triangle pass and the slow-record pass run beside the vertex pass
@@ -2671,6 +2682,7 @@ static bool same_range(const mc33hip_range &x, const mc33hip_range &y) {
 // mc33hip_sweep_many has already classified this isovalue over this range, its lane is used and nothing is streamed.
 static int enqueue_count(mc33hip_ctx *c, bool rerun = false) {
 	const Params &P = c->P;
+	c->ctr_published = false;  // (the counters of THIS count are on the device until somebody brings them over)
 	hipStream_t st = c->stream;
 	if (int rc = plan_sweep(c, P.zs, c->range.z_end)) return rc;
 	SlotGeom g;
@@ -2776,6 +2788,8 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
 	a.batches = c->batches; a.batch_cap = (uint32_t)std::min<uint64_t>(c->batch_cap, 0xFFFFFFFFull);
+	a.host_ctr = c->h_ctr;  // (hipHostMalloc'ed: the same address on the device)
+	c->ctr_published = true;
 	// rows may be staged in 16-byte chunks when every row of the grid starts on a 16-byte boundary (always so for the library's
 	// own copy; a caller's device buffer may have any pitch: its records then load for themselves)
 	a.stage_rows = ((uintptr_t)c->d_grid % 16u) == 0 && (c->pitch * sizeof(sample_t)) % 16u == 0 && (c->slice * sizeof(sample_t)) % 16u == 0 &&
@@ -2830,7 +2844,9 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 }
 
 static int fetch_counters(mc33hip_ctx *c) {
-	HIP_TRY(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+	// (after an emit pass the triangle kernel has already written them into h_ctr: only the wait is left)
+	if (!c->ctr_published) HIP_TRY(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+	c->ctr_published = false;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (getenv("MC33_HIP_VERBOSE"))
 		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, record batches %u)\n", c->h_ctr->entry_cursor,
