@@ -5,27 +5,31 @@
 //     -DMC33_GRD_F64     -> double samples AND double arithmetic / vertices (libMC33_f64.so)
 //     -DMC33_GRD_U8 / _U16 / _U32 -> unsigned char / short / int samples (libMC33_u8 / _u16 / _u32.so)
 //
-// Passes of one extraction, in launch order ("MC:" = reference source/marching_cubes_33.c; DESIGN.md 4):
-//   k_sweep<S,NI> - streams the volume once (MC:1832-1868) and does nothing else that costs bandwidth: sign bit
-//                   per sample by wave ballot, the bit rows of a 64-row x 256-sample tile slice parked one row
-//                   per LANE, so that "is any cell of this slice cut" is a handful of 64-bit logic ops.  For
-//                   each slice that is cut it leaves the two 2 KiB bit planes (each plane once), a 32-byte
-//                   header (active cells, active rows, halo bits) and a partial sum for k_slots.  S: narrow
-//                   samples are loaded S to a dword; NI: isovalues classified per pass (mc33hip_sweep_many),
-//                   each with its own "lane" of output buffers.
+// Passes of one extraction, in launch order ("MC:" = reference source/marching_cubes_33.c; DESIGN.md 4, 5):
+//   k_sweep<S,NI,ZM> - streams the volume once (MC:1832-1868) and does nothing else that costs bandwidth: sign bit per
+//                   sample by wave ballot, the bit rows of a 64-row x 256-sample tile slice parked one row per LANE, so
+//                   that "is any cell of this slice cut" is a handful of 64-bit logic ops.  For each slice that is cut it
+//                   leaves the bit planes (each plane once; 256 bytes in compact form), a header (cut cells, halo bits)
+//                   and a partial sum for k_slots.  The halo column comes from the neighbouring wave through an LDS
+//                   mailbox.  S: narrow samples are loaded S to a dword; NI: isovalues classified per pass
+//                   (mc33hip_sweep_many), each with its own "lane" of output buffers; ZM: how a sample is classified.
 //   k_boundary    - the slice between two z-tiles of k_sweep, from the edge planes both left behind.
-//   k_slots       - exclusive sums of (cells, rows) over the slice slots in sweep order.
-//   k_cells       - one wave per cut slice, 64 active cells per step: case index from the bit planes, fast
-//                   cells (interior, simple case, no sample == iso) planned from a 256-entry table, the
-//                   others queued for k_slow_plan; one 16-byte work record per active cell, contiguous in
-//                   the reference's visiting order, plus (#new vertices, #triangles) per row segment.
-//   k_slow_plan   - full MC33 classification with the interior tests (MC:683-779) of the queued cells.
-//   k_seg_fix     - recount of the row segments a slow cell changed.
+//   k_slots       - exclusive sums of (cut cells, batches of 64 of them) over the slice slots in storage order.
+//   k_cells       - one wave per cut slice, 64 cut cells per step: sign index from the bit planes; fast cells (interior,
+//                   no test needed, no sample == iso) finished from a 256-entry table, cells whose sign index needs the
+//                   face / interior tests tested here (TESTED records), the rest queued for k_slow_plan; one 8-byte work
+//                   record per cut cell, contiguous in the reference's visiting order, (#new vertices, #triangles) per
+//                   row segment, and one descriptor per batch of 64 records for the vertex pass.
+//   k_slow_plan   - the generic plan (MC:683-779, 788-1224: cells on the grid's 0-faces, corners equal to the isovalue).
+//   k_slow_count  - triangles of cells with a corner equal to the isovalue, by vertex identity (MC:1235).
+//   k_seg_fix     - offsets of the row segments a slow cell changed.
 //   k_scan_*      - exclusive prefix sums over the row segments in the reference's sweep order: this IS the
-//                   reference's vertex/triangle numbering.
-//   k_emit_*      - one thread per active cell: interpolated vertices + normals (MC:810-1230, 485-585),
-//                   vertex ids of shared edges through the owner cell's record, triangles (MC:1235-1250);
-//                   fast vertices, fast triangles and slow cells run concurrently on three streams.
+//                   reference's vertex / triangle numbering.
+//   k_emit_vertices<MODE> - one WAVE per batch of 64 records of one slice slot: the sample rows the batch needs staged in
+//                   LDS by cooperative 16-byte loads, one lane per vertex (MC:810-1230, 485-585).
+//   k_emit_fast_triangles - one thread per record: vertex ids of the nine shared edges through the owners' records,
+//                   triangles (MC:1235-1250); leaves the counters of the extraction in the host's pinned copy.
+//   k_emit_slow   - the generic emit of the slow records (on a second stream beside the other two on large grids).
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -1490,7 +1494,9 @@ __device__ __forceinline__ bool emit_prepare(const EmitArgs &a, EmitCtx<sample_t
 	return true;
 }
 
-// vertices of the fast records (positions + normals)
+#ifdef MC33_DEV
+// vertices of the fast records (positions + normals), one thread per record with 12 loads of its own: the round-2 pass,
+// kept in developer builds for A/B timing against k_emit_vertices (MC33_HIP_OLD_VERTEX_PASS=1)
 __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 	__shared__ EntryB s_fast_b[256];
 	s_fast_b[threadIdx.x] = a.c.fast_b[threadIdx.x];
@@ -1508,24 +1514,36 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_vertices(c, en, seg);
 	}
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // k_emit_vertices: the vertices of the fast and tested records, one WAVE per batch of <= 64 records of one slice slot.
 //
-// The round-2 pass (k_emit_fast_vertices, kept behind MC33_HIP_OLD_VERTEX_PASS=1 for A/B) was one thread per record with 12 short
-// sample loads each; its 64 lanes sit in 64 different sample rows, so every load instruction is 64 cache-line look-ups
-// in the CU's L1 - 65 cycles whatever its width (tools/tcp_probe.hip, profiles/r03_tcp_probe.txt), ~800 cycles per 64
-// records, although the 64 records of a batch share their rows: record (x, y, z) reads rows y, y+1, y+2 of planes z,
-// z+1 and rows y, y+1 of plane z+2, and its neighbour one row up reads two of those three again.
+// The round-2 pass (k_emit_fast_vertices; developer builds keep it for A/B) was one thread per record with 12 short sample
+// loads each; its 64 lanes sit in 64 different sample rows, so every load instruction is 64 cache-line look-ups in the
+// CU's L1 - 65 cycles whatever its width, against 17 when four lanes share a row (tools/tcp_probe.hip,
+// profiles/r03_tcp_probe.txt) - ~800 cycles per 64 records, although the 64 records of a batch share their rows: record
+// (x, y, z) reads rows y, y+1, y+2 of planes z, z+1 and rows y, y+1 of plane z+2, and its neighbour one row up reads two
+// of those three again.
 //
-// Here the wave first finds, per sample row r of the tile (lane r), the x interval the batch needs of it - the union over
-// the records of cell rows r-2 .. r, from the first and the last record of each row (the records of a slot are sorted by
-// row, then x) - in 16-byte chunks; a prefix sum gives every row its place in an LDS image [plane][chunk]; then the
-// chunks are loaded ONE PER LANE, consecutive lanes on consecutive chunks of a row, the three planes of a chunk by the
-// same lane (lanes that share a line cost one look-up: 17 cycles for 16 rows of 64 bytes); finally every lane computes
-// its record's vertices from LDS.  MC:990-1000, 1029-1039, 1175-1185 (the stencil), 485-585 (the stores).
-// Rows that are wide and sparse (noise: a few records spread over the 256 cells of a row) are not staged - their records
-// load for themselves as before (fast_samples_direct) - and so are rows beyond the image's capacity.
+// Per batch (all 64 records in one tile of one slice: same three planes, 63 cell rows):
+//   1. lane = record: first / last record of every cell row of the batch (the records of a slot are sorted by row, then x);
+//   2. lane = sample row r of the tile: the x interval the batch needs of row r - the records of cell rows r-2 .. r - as a
+//      window of EV_W 16-byte chunks; a row that needs more is not staged;
+//   3. lane = chunk: the chunks of all windows, the three planes of a chunk by the same lane, consecutive lanes on
+//      consecutive chunks of a row - every load of the batch issued before the first is waited for - into an LDS image
+//      [plane][row][chunk];
+//   4. lane = VERTEX: a record makes one vertex on average; one lane per record with a branch per owned edge ran each
+//      branch for a third of the lanes.  The vertices of the batch are listed by kind (edge 5, 6, 10), a lane takes one,
+//      fetches its 10 samples from the image and runs vertex_on_edge's arithmetic in its order.  MC:990-1000, 1029-1039,
+//      1175-1185 (the stencil), 485-585 (the stores);
+//   5. records of rows that are not staged (long runs along x - where consecutive lanes read consecutive samples anyway -
+//      or noise) and tested records with a centre vertex load for themselves as before (fast_samples_direct).
+// The records and row bases of the next batch and the descriptor of the one after are in flight while a batch is worked on.
+// What bounds it (profiles/r03_v1_c3_pmc.txt): 447 MB of HBM traffic for 94 MB of vertices, in 64-byte sectors scattered
+// over three planes, at the 3.5 - 3.8 TB/s such traffic reaches on this part (tcp_probe: 64 lanes x 64 B per 720 cycles
+// and CU); fewer instructions (1100 -> 830 per batch) changed nothing.  In launch order the same batches move 383 MB -
+// see XcdBatchWalk.
 // ---------------------------------------------------------------------------------------------------
 // Window of a sample row in the LDS image: EV_W 16-byte chunks from the chunk that holds the first sample the batch needs of
 // that row.  A row that needs more (a long run of records along x, or records far apart: noise) is not staged; the
@@ -2818,7 +2836,11 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 		hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, ss, a);
 		HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
 	}
-	if (!env_u32("MC33_HIP_OLD_VERTEX_PASS", 0)) {
+#ifdef MC33_DEV
+	if (env_u32("MC33_HIP_OLD_VERTEX_PASS", 0)) hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);  // (the round-2 pass, for A/B timing)
+	else
+#endif
+	{
 		// as many blocks as the device holds at once (one more round of blocks would run with most of the GPU idle); every wave
 		// walks many batches, its next batch's records in flight while it works on one
 		if (!c->emit_v_blocks_per_cu) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->emit_v_blocks_per_cu, k_emit_vertices<3>, 256, 0));
@@ -2830,8 +2852,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 		case 2: hipLaunchKernelGGL(k_emit_vertices<2>, vgrid, dim3(256), 0, c->stream, a); break;
 		default: hipLaunchKernelGGL(k_emit_vertices<3>, vgrid, dim3(256), 0, c->stream, a); break;
 		}
-	}
-	else hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);  // (the round-2 pass, for A/B timing)
+		}
 	hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, sv, a);
 	if (fork_all) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
 	if (!fork_slow) hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, ss, a);
