@@ -86,6 +86,8 @@ struct Counters {
 	uint32_t batch_cursor;  // batches of <= 64 records of one slice slot (BatchDesc) the emit passes walk
 	uint32_t emit_skipped;  // set by the emit kernels when they refused to run (capacity / overflow)
 	uint32_t count_pending; // set by k_slow_plan when a record waits for k_slow_count
+	uint32_t scan_ticket;   // k_scan: the chunks are taken in the order its blocks start
+	uint32_t pad_;
 	uint64_t totV, totT;    // totals over all classified slices (ghost included)
 	uint64_t ghostV, ghostT;
 	uint32_t debug[8];      // (-DMC33_DEV: what a guarded kernel found wrong)
@@ -121,9 +123,37 @@ __host__ __device__ inline bool slice_valid(uint32_t flags, uint32_t epoch) { re
 struct SweepTile { uint32_t seg, yt, z_lo, z_hi; };  // the piece of the volume ONE WAVE of k_sweep streams: row segment, y tile, planes
 
 // slice record of (cell slice z, y tile, row segment): groups of 4 consecutive slices of one tile column are
-// adjacent (one k_cells block; the emit kernels find neighbouring cells in neighbouring records)
-__host__ __device__ inline uint64_t slice_slot(uint32_t dz, uint32_t yt, uint32_t seg, uint32_t nYT, uint32_t nseg_pad) {
-	return ((((uint64_t)(dz >> 2) * nYT + yt) * nseg_pad + seg) << 2) | (dz & 3u);
+// adjacent (one k_cells block).  The order of the groups is the order the work records are stored in and the emit
+// passes walk them in - it has nothing to do with the numbering of vertices and triangles, which comes from the scan
+// over the row segments.  z group outermost (order 0).  Measured against y tile / z group / segment (1) and y tile /
+// segment / z group (2), which keep the groups of a tile column - three of a slice's four sample planes are the next
+// slice's too - close together in an XCD's share of the walk (round 3, profiles/r03_slot_order.txt): the vertex pass
+// fetches 5 % (float 1024^3) to 10 % (ushort 2048 x 2048 x 1024) less with (1) and is 2 - 6 us faster, k_cells is
+// 6 - 33 us slower (its row-segment counts and directory lines, stored [z][segment][y], are then written far apart by
+// blocks that run together); (2) loses everywhere.  The L2 fetches 128-byte lines: what the vertex pass moves is
+// within 1.5 x (float) / 2.2 x (ushort) of the distinct lines its stencils touch under ANY order.
+#ifndef MC33_SLOT_ORDER
+#define MC33_SLOT_ORDER 0
+#endif
+struct SlotDims { uint32_t nZG, nYT, nseg; };  // z groups (planes: one more than slices), y tiles, row segments
+__host__ __device__ inline uint64_t slice_slot(uint32_t dz, uint32_t yt, uint32_t seg, const SlotDims &d) {
+#if MC33_SLOT_ORDER == 0
+	return ((((uint64_t)(dz >> 2) * d.nYT + yt) * d.nseg + seg) << 2) | (dz & 3u);
+#elif MC33_SLOT_ORDER == 1
+	return ((((uint64_t)yt * d.nZG + (dz >> 2)) * d.nseg + seg) << 2) | (dz & 3u);
+#else
+	return ((((uint64_t)yt * d.nseg + seg) * d.nZG + (dz >> 2)) << 2) | (dz & 3u);
+#endif
+}
+// the inverse for a group of four: block of k_cells -> (z group, y tile, row segment)
+__device__ inline void slot_group_coords(uint32_t b, const SlotDims &d, uint32_t &zq, uint32_t &yt, uint32_t &seg) {
+#if MC33_SLOT_ORDER == 0
+	seg = b % d.nseg; const uint32_t t = b / d.nseg; yt = t % d.nYT; zq = t / d.nYT;
+#elif MC33_SLOT_ORDER == 1
+	seg = b % d.nseg; const uint32_t t = b / d.nseg; zq = t % d.nZG; yt = t / d.nZG;
+#else
+	zq = b % d.nZG; const uint32_t t = b / d.nZG; seg = t % d.nseg; yt = t / d.nseg;
+#endif
 }
 
 // What one sweep leaves behind for ONE isovalue.  k_sweep can classify the samples it streams against several isovalues
@@ -149,7 +179,7 @@ struct SweepArgs {
 	Params P;                // (P.iso is not used by the sweep: every lane has its own)
 	const SweepTile *tiles;  // [wave]: the waves of a block are independent, a block is any four consecutive tiles
 	uint32_t ntiles;
-	uint32_t nYT, nseg_pad;  // y tiles, row segments per slot row (= P.nseg)
+	SlotDims sd;             // slice_slot
 	unsigned long long *trace;  // MC33_HIP_TRACE_FILE: per wave {start, end} (s_memrealtime, 100 MHz), {start, end} (s_memtime, shader clock)
 	uint32_t z_end;          // end of the classified range: tiles that reach it have no tile above
 	uint32_t debug;          // MC33_HIP_DEBUG, developer builds (-DMC33_DEV) only - timing experiments, results are wrong: 2 = stream
@@ -687,7 +717,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 			auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary (a plane record like those of slice_bits)
 				// (in compact form where it fits only in the passes over several isovalues, which are bound by what they write:
 				// 2.26 -> 2.19 ms per 4-isovalue pass at C5; the single-isovalue pass lost with it - 0.789 -> 0.818 ms at C3,
-				// eight processes each way - and keeps the raw form)
+				// eight processes each way - and keeps the raw form.  These 17 MB (1024^3, two records per tile) cost the float
+				// sweep 0.065 of its 0.73 ms - the first plane's 0.045, the last one's 0.02 - and three times what the 25 MB of the
+				// slices handed on cost; holding the first plane's record back in registers for 1 - 8 planes by tile number, or
+				// to the tile's end, or storing it nontemporal, changes nothing (round 3, profiles/r03_sweep_parts.txt))
 				uint32_t fmt = PLANE_RAW;
 				uint4 *rec = L.edge_bits + ((uint64_t)wtile * 2u + which) * 128u;
 				if constexpr (NI >= 2) fmt = store_plane_record<S>(rec, cur[q]);
@@ -705,8 +738,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 			};
 			if (MC33_DEBUG_BITS(a) & 2u) {
 			} else {
-				if (p == pl0 && pl0 != z_lo) leave_edge(0);
-				if (p > pl0) {
+				// (developer builds: 256 no edge records, 1024 / 2048 none for the first / last plane, 512 no cut-cell test)
+				if (p == pl0 && pl0 != z_lo && !(MC33_DEBUG_BITS(a) & (256u | 1024u))) leave_edge(0);
+				if (p > pl0 && !(MC33_DEBUG_BITS(a) & 512u)) {
 					uint64_t act[4], pq[4];
 #pragma unroll
 					for (int k = 0; k < 4; k++) {
@@ -716,13 +750,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 					if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(MC33_DEBUG_BITS(a) & 16u)) {  // wave-uniform: hand the slice to k_cells
 						uint64_t pz, pzc;
 						if constexpr (PREV_LDS) { pz = s_prevz[q][0][wv]; pzc = s_prevz[q][1][wv]; } else { pz = prev_z[q]; pzc = prev_zc[q]; }
-						hand_over_slice<S>(L, slice_slot(p - 1 - P.zs, yt, seg, a.nYT, a.nseg_pad), slice_slot(p - P.zs, yt, seg, a.nYT, a.nseg_pad), pq, cur[q],
+						hand_over_slice<S>(L, slice_slot(p - 1 - P.zs, yt, seg, a.sd), slice_slot(p - P.zs, yt, seg, a.sd), pq, cur[q],
 						                   !prev_written[q], true, __ballot(prev_h[q] != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act,
 						                   MC33_DEBUG_BITS(a));
 						cur_written[q] = true;
 					}
 				}
-				if (p == z_hi && has_above) leave_edge(1);
+				if (p == z_hi && has_above && !(MC33_DEBUG_BITS(a) & (256u | 2048u))) leave_edge(1);
 			}
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
@@ -741,6 +775,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	// past the end of the tile the prefetch simply re-reads the last batch (it is never processed)
 #define MC33_ADV(p_, b_) do { if (++(b_) == NB) { (b_) = 0; ++(p_); } } while (0)
 #define MC33_ADV_ISSUE() do { if (ip != z_hi || ib + 1 != NB) MC33_ADV(ip, ib); } while (0)
+	// (Tried in round 3: the loads that refill a buffer issued as soon as its rows are bit rows, BEFORE the work on a complete
+	// plane, so that two batches stay in flight during that work and a hand-over's stores are younger than the refill.  The
+	// refill's registers are then live across the plane's work: 92 -> 134 VGPRs for one isovalue per pass = 3 waves per SIMD
+	// instead of 4, float 1024^3 0.73 -> 0.82 ms; held to 128 (36 bytes of scratch) 0.73 - 0.75 -> 0.74 - 0.75, ushort
+	// 1.66 -> 1.72 ms.  No gain.  What the plane's work costs the stream is its stores, wherever they are issued:
+	// profiles/r03_sweep_parts.txt.)
 	issue(dA, hA, ip, ib); MC33_ADV_ISSUE();
 	for (uint32_t t = 0; t < T; t += 2) {
 		issue(dB, hB, ip, ib); MC33_ADV_ISSUE();
@@ -788,7 +828,7 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 	active_cells(prev, cur, (uint32_t)((bp >> lane) & 1ull), (uint32_t)((bc >> lane) & 1ull), valid, rowvalid, act);
 	if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull))
 		// (the two tiles may have written these planes for slices of their own: same bytes again)
-		hand_over_slice<1>(L, slice_slot(b.z - P.zs, b.yt, seg, a.nYT, a.nseg_pad), slice_slot(b.z + 1u - P.zs, b.yt, seg, a.nYT, a.nseg_pad), prev, cur,
+		hand_over_slice<1>(L, slice_slot(b.z - P.zs, b.yt, seg, a.sd), slice_slot(b.z + 1u - P.zs, b.yt, seg, a.sd), prev, cur,
 		                true, true, bp, bc, u64(hp.z, hp.w) | u64(hc.z, hc.w), u64(zp.x, zp.y) | u64(zc.x, zc.y), act);
 }
 
@@ -850,14 +890,16 @@ struct ChunkMap {  // per block, in LDS: exclusive prefix sums of the group coun
 // own chunk.  Record order is therefore a function of the grid alone (no allocation atomics).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const unsigned long long *part, unsigned long long *part_next,
-                                               uint32_t part_cap, uint32_t epoch, uint64_t nslots, uint2 *slot_base, Counters *ctr, ListChunks lc) {
+                                               uint32_t part_cap, uint32_t epoch, uint64_t nslots, uint2 *slot_base, Counters *ctr, ListChunks lc,
+                                               unsigned long long *scan_state, uint32_t scan_words) {
 	__shared__ unsigned long long s_red[256];
 	const uint32_t c = blockIdx.x, t = threadIdx.x;
+	for (uint32_t q = c * 256u + t; q < scan_words; q += gridDim.x * 256u) scan_state[q] = 0;  // k_scan of this extraction: no chunk is known yet
 	if (t == 0) part_next[c] = 0;  // the partial sums of the NEXT extraction live in the other half: cleared here
 	if (c == 0) for (uint32_t q = gridDim.x + t; q < part_cap; q += 256u) part_next[q] = 0;  // (a later range may be longer)
 	if (c == 0) for (uint32_t q = t; q < LIST_CHUNKS; q += 256u) { lc.slow_cnt[q] = 0; lc.dirty_cnt[q] = 0; }  // the list cursors of this extraction
 	if (c == 0 && t == 0) {        // ... and so are the counters the later passes of this one add to
-		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0; ctr->count_pending = 0;
+		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0; ctr->count_pending = 0; ctr->scan_ticket = 0;
 		ctr->totV = ctr->totT = ctr->ghostV = ctr->ghostT = 0;
 		for (int q = 0; q < 8; q++) ctr->debug[q] = 0;
 	}
@@ -930,7 +972,8 @@ struct CellsArgs {
 	GridView<sample_t> G;    // (only looked at for cells of rows that may hold a sample equal to the isovalue)
 	Params P;
 	const uint4 *fast;       // per sign index: record words of a FAST cell (fast_record_table)
-	uint32_t ze, nYT, nseg_pad;
+	uint32_t ze;
+	SlotDims sd;
 	const SliceHeader *slice_hdr;
 	const uint4 *slice_bits;
 	const uint8_t *plane_fmt;
@@ -1006,8 +1049,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 	const Params &P = a.P;
 	// block -> 4 consecutive slices of one tile column (slice_slot order)
 	const uint64_t slot = (uint64_t)blockIdx.x * 4 + wv;
-	const uint32_t seg = blockIdx.x % a.nseg_pad, bt = blockIdx.x / a.nseg_pad;
-	const uint32_t yt = bt % a.nYT, zq = bt / a.nYT;
+	uint32_t seg, yt, zq;
+	slot_group_coords(blockIdx.x, a.sd, zq, yt, seg);
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
 	const uint32_t z = P.zs + zq * 4u + wv;
 	const uint32_t y = y0 + lane;
@@ -1028,7 +1071,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 		// the records of the two planes of the slice (the upper plane's sits in the slot of the slice above): their compact
 		// form, one dword per row, and how they are written; a plane in raw form (a row with more than two changes) costs
 		// a second round trip below
-		slot_up = slice_slot(z + 1u - P.zs, yt, seg, a.nYT, a.nseg_pad);
+		slot_up = slice_slot(z + 1u - P.zs, yt, seg, a.sd);
 		dl = ((const uint32_t *)(a.slice_bits + slot * 128u))[lane];
 		du = ((const uint32_t *)(a.slice_bits + slot_up * 128u))[lane];
 		fmt_l = a.plane_fmt[slot]; fmt_u = a.plane_fmt[slot_up];
@@ -1372,6 +1415,7 @@ struct SweepWalk {
 	}
 };
 
+#ifdef MC33_DEV  // (the two-pass scan of rounds 1 and 2: MC33_HIP_TWO_PASS_SCAN=1 in developer builds, A/B timing)
 // The records are stored [z][segment][y]; the scan runs over them in sweep order [z][y][segment]: a chunk of
 // SCAN_CHUNK consecutive sweep positions is the same set of records whatever the order inside it only
 // when it covers whole (y, all segments) groups - so the mapping is applied per element.
@@ -1428,6 +1472,96 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uin
 	if (lane == 63) { sv[wv] = iv; st[wv] = it; }
 	__syncthreads();
 	uint32_t ev = (uint32_t)bv + iv - v, et = (uint32_t)bt + it - t;
+	for (uint32_t k = 0; k < wv; k++) { ev += sv[k]; et += st[k]; }
+#pragma unroll
+	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
+		if (q0 + k < n) {
+			if (cv[k] | ct[k]) seg_base[st_idx[k]] = SegBase{ev, et};  // (nobody asks for the base of a row segment that holds nothing)
+			if (q0 + k == ghost_segs) { ctr->ghostV = ev; ctr->ghostT = et; }  // first segment of the emitted range
+		}
+		ev += cv[k]; et += ct[k];
+	}
+}
+
+#endif
+// One pass instead of the two above (round 3; the two stay for A/B timing in developer builds): every block publishes the
+// sum of its chunk, looks BACK over the chunks before it until it meets one whose sum of everything before is known
+// (decoupled look-back), publishes its own, and scans its chunk out of the registers it loaded it into.  k_scan_apply
+// read the sums of all chunks before its own - 16 M row segments are 8 180 chunks (1024^3), 32 724 at 2048 x 2048 x 1024:
+// half a megabyte per block - and the counts a second time.  A chunk's state is ONE 64-bit word per sum {2 bits: nothing /
+// the chunk's own sum / the sum up to and including it; 62 bits: the value}, written and read whole by agent-scope
+// atomics: no fence, no order between two words needed - a reader that finds the two words of a chunk in different
+// states reads again.  Chunks are handed out by a ticket, so the chunks a block waits for belong to blocks that have
+// started and wait for nobody behind them: every wait ends.  k_slots clears states and ticket.
+constexpr uint64_t SCAN_OWN = 1ull << 62, SCAN_UPTO = 2ull << 62, SCAN_VALUE = (1ull << 62) - 1ull;
+__global__ __launch_bounds__(256) void k_scan(const uint32_t *seg_cnt, uint64_t n, Params P, unsigned long long *stV, unsigned long long *stT,
+                                              SegBase *seg_base, uint64_t ghost_segs, Counters *ctr) {
+	__shared__ uint32_t sv[4], st[4], s_chunk;
+	__shared__ uint64_t s_before[2];
+	if (threadIdx.x == 0) s_chunk = atomicAdd(&ctr->scan_ticket, 1u);
+	__syncthreads();
+	const uint32_t chunk = s_chunk;
+	const uint64_t q0 = (uint64_t)chunk * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+	uint32_t cv[SCAN_PER_THREAD], ct[SCAN_PER_THREAD], v = 0, t = 0;
+	uint64_t st_idx[SCAN_PER_THREAD];
+	SweepWalk walk(P, q0);
+#pragma unroll
+	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
+		st_idx[k] = (q0 + k < n) ? walk.store() : 0;
+		walk.next();
+		const uint32_t c = (q0 + k < n) ? seg_cnt[st_idx[k]] : 0u;
+		cv[k] = c & 0xFFFFu; ct[k] = c >> 16;
+		v += cv[k]; t += ct[k];
+	}
+	uint32_t iv = v, it = t;
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t a = __shfl_up(iv, d), b = __shfl_up(it, d);
+		if ((int)lane >= d) { iv += a; it += b; }
+	}
+	if (lane == 63) { sv[wv] = iv; st[wv] = it; }
+	__syncthreads();
+	if (wv == 0) {  // the first wave: the chunk's sums out, the sums of everything before it in
+		const uint64_t ownV = (uint64_t)sv[0] + sv[1] + sv[2] + sv[3], ownT = (uint64_t)st[0] + st[1] + st[2] + st[3];
+		uint64_t beforeV = 0, beforeT = 0;
+		if (chunk != 0) {
+			if (lane == 0) {
+				__hip_atomic_store(stV + chunk, SCAN_OWN | ownV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(stT + chunk, SCAN_OWN | ownT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			for (int64_t top = (int64_t)chunk - 1;; top -= 64) {  // lane l looks at chunk top - l
+				const int64_t k = top - (int64_t)lane;
+				uint64_t a = SCAN_UPTO, b = SCAN_UPTO;  // (before chunk 0: nothing, and known)
+				for (uint32_t polls = 0;; polls++) {
+					if (k >= 0) {
+						a = __hip_atomic_load(stV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						b = __hip_atomic_load(stT + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+					if (!__ballot((a >> 62) == 0 || (a >> 62) != (b >> 62))) break;
+					if (polls == (1u << 22)) {  // (seconds: cannot happen - but no wave of this kernel may wait for ever; the host reports it)
+						if (lane == 0) atomicCAS(&ctr->debug[0], 0u, 3u);
+						a = b = SCAN_UPTO;
+						break;
+					}
+					__builtin_amdgcn_s_sleep(1);
+				}
+				const uint64_t known = __ballot((a >> 62) == 2u);
+				const uint32_t stop = known ? (uint32_t)__builtin_ctzll(known) : 63u;  // the nearest chunk whose running sum is known ends the walk
+				beforeV += wave_sum(lane <= stop ? (a & SCAN_VALUE) : 0ull);
+				beforeT += wave_sum(lane <= stop ? (b & SCAN_VALUE) : 0ull);
+				if (known) break;
+			}
+		}
+		if (lane == 0) {
+			__hip_atomic_store(stV + chunk, SCAN_UPTO | (beforeV + ownV), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(stT + chunk, SCAN_UPTO | (beforeT + ownT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			s_before[0] = beforeV; s_before[1] = beforeT;
+			if (chunk == gridDim.x - 1) { ctr->totV = beforeV + ownV; ctr->totT = beforeT + ownT; }
+		}
+	}
+	__syncthreads();
+	uint32_t ev = (uint32_t)s_before[0] + iv - v, et = (uint32_t)s_before[1] + it - t;
 	for (uint32_t k = 0; k < wv; k++) { ev += sv[k]; et += st[k]; }
 #pragma unroll
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
@@ -1812,7 +1946,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 				const uint32_t rw0 = xl | rho << 8 | r5 << 16 | r6 << 20 | r10 << 24 | (xin ? 1u << 28 : 0u) | (yin ? 1u << 29 : 0u);
 				const uint32_t rw1 = (i0 & 0xFFu) | (i1 & 0xFFu) << 8 | (i2 & 0xFFu) << 16;  // first chunk of rows rho, rho + 1, rho + 2 | rho
 				const char *img = (const char *)L.data;
-				constexpr uint32_t NITEM = EV_ROWS * EV_W;
 				for (uint32_t v0 = 0; v0 < nv; v0 += 64u) {  // wave-uniform
 					const bool act = v0 + lane < nv;
 					const uint32_t ent = L.vlist[act ? v0 + lane : 0u];
@@ -2163,7 +2296,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	if (c->owns_grid) (void)hipFree(c->d_grid);
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_rules); (void)hipFree(c->d_rule_index); (void)hipFree(c->d_fast);
 	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base);
-	(void)hipFree(c->bsV); (void)hipFree(c->bsT);
+	(void)hipFree(c->bsV);
 	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->entries_c); (void)hipFree(c->d_fast_b); (void)hipFree(c->d_pat); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list); (void)hipFree(c->batches);
 	for (int k = 0; k < MC33_LANES; k++) {
 		IsoLane &L = c->lanes[k];
@@ -2367,11 +2500,11 @@ static int ensure_workspaces(mc33hip_ctx *c) {
 	}
 	const uint64_t nb = (c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK;
 	if (c->bs_cap < nb) {
-		(void)hipFree(c->bsV); (void)hipFree(c->bsT);
+		(void)hipFree(c->bsV);
 		c->bsV = c->bsT = nullptr;
 		c->bs_cap = 0;
-		HIP_TRY(hipMalloc(&c->bsV, nb * 8));
-		HIP_TRY(hipMalloc(&c->bsT, nb * 8));
+		HIP_TRY(hipMalloc(&c->bsV, 2 * nb * 8));  // (k_scan: the states of the two sums, one after the other)
+		c->bsT = c->bsV + nb;
 		c->bs_cap = nb;
 	}
 	if (!c->entries_a) {
@@ -2491,13 +2624,15 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 // slot geometry of the range being classified
 struct SlotGeom {
 	uint32_t nYT, nseg;
+	SlotDims sd;
 	uint64_t cell_blocks, nslots, nchunks;
 };
 static int slot_geometry(mc33hip_ctx *c, SlotGeom &g) {
 	const Params &P = c->P;
 	g.nYT = (P.ny + 62) / 63;
 	g.nseg = P.nseg;  // (the slots of a slice group are its real row segments)
-	g.cell_blocks = (uint64_t)((c->range.z_end - P.zs + 3) / 4) * g.nYT * g.nseg;
+	g.sd = SlotDims{(c->range.z_end - P.zs + 1 + 3) / 4, g.nYT, g.nseg};  // the plane above the last slice has a slot too
+	g.cell_blocks = (uint64_t)g.sd.nZG * g.nYT * g.nseg;
 	if (g.cell_blocks > 0x3FFFFFFFull) { set_err("grid too large for one launch"); return MC33HIP_EINVAL; }
 	g.nslots = g.cell_blocks * 4;
 	g.nchunks = 0;
@@ -2510,8 +2645,8 @@ static int begin_lane(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g, hipStream_t
 		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.plane_fmt); (void)hipFree(L.slot_part);
 		L.slice_hdr = nullptr; L.slice_bits = nullptr; L.plane_fmt = nullptr; L.slot_part = nullptr; L.slice_cap = 0;
 		HIP_TRY(hipMalloc(&L.slice_hdr, g.nslots * sizeof(SliceHeader)));
-		HIP_TRY(hipMalloc(&L.slice_bits, (g.nslots + 4ull * g.nYT * g.nseg) * 2048));  // planes: one more than slices
-		HIP_TRY(hipMalloc(&L.plane_fmt, g.nslots + 4ull * g.nYT * g.nseg));
+		HIP_TRY(hipMalloc(&L.slice_bits, g.nslots * 2048));  // (slots of planes: SlotDims)
+		HIP_TRY(hipMalloc(&L.plane_fmt, g.nslots));
 		const uint64_t part_bytes = ((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK) * 8;
 		HIP_TRY(hipMalloc(&L.slot_part, 2 * part_bytes));  // two halves, used by alternate extractions
 		HIP_TRY(hipMemsetAsync(L.slice_hdr, 0, g.nslots * sizeof(SliceHeader), st));
@@ -2554,7 +2689,7 @@ static unsigned long long *lane_part(const IsoLane &L, bool next) {
 static void sweep_args(mc33hip_ctx *c, const SlotGeom &g, SweepArgs &a) {
 	a.G.p = c->d_grid; a.G.pitch = (uint32_t)c->pitch; a.G.z0 = c->desc.plane0; a.G.slice = c->slice;
 	a.P = c->P;
-	a.nYT = g.nYT; a.nseg_pad = g.nseg;
+	a.sd = g.sd;
 	a.tiles = c->d_tiles;
 	a.ntiles = (uint32_t)c->ntiles;
 	a.z_end = c->range.z_end;
@@ -2641,7 +2776,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 #endif
 	ca.G.p = c->d_grid; ca.G.pitch = (uint32_t)c->pitch; ca.G.z0 = c->desc.plane0; ca.G.slice = c->slice;
 	ca.P = P; ca.fast = c->d_fast; ca.pat = c->d_pat;
-	ca.ze = ze; ca.nYT = g.nYT; ca.nseg_pad = g.nseg;
+	ca.ze = ze; ca.sd = g.sd;
 	ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.plane_fmt = L.plane_fmt; ca.slot_base = c->slot_base;
 	ca.epoch = L.epoch;
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir;
@@ -2666,7 +2801,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	}
 	ca.lc = c->lc;
 	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK)), dim3(256), 0, st, L.slice_hdr, lane_part(L, false), lane_part(L, true),
-	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr, c->lc);
+	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr, c->lc, (unsigned long long *)c->bsV, (uint32_t)(2 * c->bs_cap));
 	L.tail_pending = false;  // k_slots has read this epoch's partial sums and cleared the half of the next one
 	hipLaunchKernelGGL(k_cells, dim3((uint32_t)g.cell_blocks), dim3(256), 0, st, ca);
 	SlowArgs sa;
@@ -2682,9 +2817,14 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	hipLaunchKernelGGL(k_slow_count, dim3(slow_blocks), dim3(256), 0, st, sa);
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
 	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
-	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT);
-	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, c->seg_base,
-	                   c->ghost_segs, c->d_ctr);
+#ifdef MC33_DEV
+	if (env_u32("MC33_HIP_TWO_PASS_SCAN", 0)) {  // (the scan of rounds 1 and 2, for A/B timing)
+		hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT);
+		hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, c->seg_base, c->ghost_segs, c->d_ctr);
+	} else
+#endif
+	hipLaunchKernelGGL(k_scan, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, (unsigned long long *)c->bsV, (unsigned long long *)c->bsT,
+	                   c->seg_base, c->ghost_segs, c->d_ctr);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -2872,6 +3012,7 @@ static int fetch_counters(mc33hip_ctx *c) {
 	if (getenv("MC33_HIP_VERBOSE"))
 		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, record batches %u)\n", c->h_ctr->entry_cursor,
 		        c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->batch_cursor);
+	if (c->h_ctr->debug[0] == 3u) { set_err("k_scan: the sum of a chunk never arrived"); return MC33HIP_ERUNTIME; }
 	if (c->h_ctr->debug[0])
 		fprintf(stderr, "[mc33hip] DEBUG words %u: first %u count %u z %u y0 %u xbase %u batch %u of %u\n", c->h_ctr->debug[0], c->h_ctr->debug[1], c->h_ctr->debug[2],
 		        c->h_ctr->debug[3], c->h_ctr->debug[4], c->h_ctr->debug[5], c->h_ctr->debug[6], c->h_ctr->debug[7]);
