@@ -86,8 +86,6 @@ struct Counters {
 	uint32_t batch_cursor;  // batches of <= 64 records of one slice slot (BatchDesc) the emit passes walk
 	uint32_t emit_skipped;  // set by the emit kernels when they refused to run (capacity / overflow)
 	uint32_t count_pending; // set by k_slow_plan when a record waits for k_slow_count
-	uint32_t scan_ticket;   // k_scan: the chunks are taken in the order its blocks start
-	uint32_t pad_;
 	uint64_t totV, totT;    // totals over all classified slices (ghost included)
 	uint64_t ghostV, ghostT;
 	uint32_t debug[8];      // (-DMC33_DEV: what a guarded kernel found wrong)
@@ -717,21 +715,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 			auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary (a plane record like those of slice_bits)
 				// (in compact form where it fits only in the passes over several isovalues, which are bound by what they write:
 				// 2.26 -> 2.19 ms per 4-isovalue pass at C5; the single-isovalue pass lost with it - 0.789 -> 0.818 ms at C3,
-				// eight processes each way - and keeps the raw form.  These 17 MB (1024^3, two records per tile) cost the float
+				// eight processes each way, and again in round 3: 0.73 -> 0.77 - 0.81 - and keeps the raw form.  These 17 MB (1024^3, two records per tile) cost the float
 				// sweep 0.065 of its 0.73 ms - the first plane's 0.045, the last one's 0.02 - and three times what the 25 MB of the
-				// slices handed on cost; holding the first plane's record back in registers for 1 - 8 planes by tile number, or
-				// to the tile's end, or storing it nontemporal, changes nothing (round 3, profiles/r03_sweep_parts.txt))
+				// slices handed on cost; it is the two 1 KiB stores, not the header; holding the first plane's record back in registers
+				// for 1 - 8 planes by tile number, or to the tile's end, or storing it nontemporal, changes nothing (round 3,
+				// profiles/r03_sweep_parts.txt))
 				uint32_t fmt = PLANE_RAW;
 				uint4 *rec = L.edge_bits + ((uint64_t)wtile * 2u + which) * 128u;
 				if constexpr (NI >= 2) fmt = store_plane_record<S>(rec, cur[q]);
-				else {
+				else if (!(MC33_DEBUG_BITS(a) & 8192u)) {  // (developer builds: 8192 no record, 4096 no header)
 					uint64_t o[4];
 					to_standard<S>(cur[q], o);
 					rec[lane] = uint4{(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)};
 					rec[64 + lane] = uint4{(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)};
 				}
 				const uint64_t bh = __ballot(cur_h[q] != 0);
-				if (lane == 0) {
+				if (lane == 0 && !(MC33_DEBUG_BITS(a) & 4096u)) {
 					L.edge_hdr[((uint64_t)wtile * 2u + which) * 2u] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), (uint32_t)cur_z[q], (uint32_t)(cur_z[q] >> 32)};
 					L.edge_hdr[((uint64_t)wtile * 2u + which) * 2u + 1u] = uint4{(uint32_t)cur_zc[q], (uint32_t)(cur_zc[q] >> 32), fmt, 0u};
 				}
@@ -894,12 +893,12 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
                                                unsigned long long *scan_state, uint32_t scan_words) {
 	__shared__ unsigned long long s_red[256];
 	const uint32_t c = blockIdx.x, t = threadIdx.x;
-	for (uint32_t q = c * 256u + t; q < scan_words; q += gridDim.x * 256u) scan_state[q] = 0;  // k_scan of this extraction: no chunk is known yet
+	for (uint32_t q = c * 256u + t; q < scan_words; q += gridDim.x * 256u) scan_state[q] = 0;  // the group sums of this extraction's scan (k_scan_reduce adds to them)
 	if (t == 0) part_next[c] = 0;  // the partial sums of the NEXT extraction live in the other half: cleared here
 	if (c == 0) for (uint32_t q = gridDim.x + t; q < part_cap; q += 256u) part_next[q] = 0;  // (a later range may be longer)
 	if (c == 0) for (uint32_t q = t; q < LIST_CHUNKS; q += 256u) { lc.slow_cnt[q] = 0; lc.dirty_cnt[q] = 0; }  // the list cursors of this extraction
 	if (c == 0 && t == 0) {        // ... and so are the counters the later passes of this one add to
-		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0; ctr->count_pending = 0; ctr->scan_ticket = 0;
+		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0; ctr->count_pending = 0;
 		ctr->totV = ctr->totT = ctr->ghostV = ctr->ghostT = 0;
 		for (int q = 0; q < 8; q++) ctr->debug[q] = 0;
 	}
@@ -1395,7 +1394,8 @@ __global__ __launch_bounds__(256) void k_seg_fix(const SlowArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // prefix sums over the row segments (sweep order)
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t SCAN_PER_THREAD = 8, SCAN_CHUNK = 256 * SCAN_PER_THREAD;
+constexpr uint32_t SCAN_PER_THREAD = 8, SCAN_CHUNK = 256 * SCAN_PER_THREAD, SCAN_GROUP = 32, SCAN_GROUPED_FROM = 12288;
+__host__ __device__ inline uint64_t scan_groups(uint64_t nchunks) { return (nchunks + SCAN_GROUP - 1) / SCAN_GROUP; }
 
 
 // position in sweep order -> storage index, advanced incrementally (one division per thread, not per element)
@@ -1415,11 +1415,10 @@ struct SweepWalk {
 	}
 };
 
-#ifdef MC33_DEV  // (the two-pass scan of rounds 1 and 2: MC33_HIP_TWO_PASS_SCAN=1 in developer builds, A/B timing)
 // The records are stored [z][segment][y]; the scan runs over them in sweep order [z][y][segment]: a chunk of
 // SCAN_CHUNK consecutive sweep positions is the same set of records whatever the order inside it only
 // when it covers whole (y, all segments) groups - so the mapping is applied per element.
-__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, uint64_t n, Params P, uint64_t *bsV, uint64_t *bsT) {
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, uint64_t n, Params P, uint64_t *bsV, uint64_t *bsT, uint64_t *grV, uint64_t *grT) {
 	__shared__ uint64_t sv[4], st[4];
 	const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
 	uint64_t v = 0, t = 0;
@@ -1433,18 +1432,33 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, ui
 	v = wave_sum(v); t = wave_sum(t);
 	if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; st[threadIdx.x >> 6] = t; }
 	__syncthreads();
-	if (threadIdx.x == 0) { bsV[blockIdx.x] = sv[0] + sv[1] + sv[2] + sv[3]; bsT[blockIdx.x] = st[0] + st[1] + st[2] + st[3]; }
+	if (threadIdx.x == 0) {
+		const uint64_t cv = sv[0] + sv[1] + sv[2] + sv[3], ct = st[0] + st[1] + st[2] + st[3];
+		bsV[blockIdx.x] = cv; bsT[blockIdx.x] = ct;
+		// ... and into the sum of the chunk's group of SCAN_GROUP chunks (cleared by k_slots): k_scan_apply then adds up the groups
+		// before its own and the chunks of its own group before it - a few hundred values instead of up to 32 724 (2048 x 2048 x 1024)
+		// (grV == nullptr: not worth its atomics - 4 us at 1024^3 - below SCAN_GROUPED_FROM chunks)
+		if (grV && cv) atomicAdd((unsigned long long *)grV + blockIdx.x / SCAN_GROUP, (unsigned long long)cv);
+		if (grV && ct) atomicAdd((unsigned long long *)grT + blockIdx.x / SCAN_GROUP, (unsigned long long)ct);
+	}
 }
 
-// Second pass: every block first adds up the sums of the chunks before its own (a few thousand values, resident in
-// L2; cheaper than a separate one-block scan kernel between the two passes), then scans its chunk.  The last block
-// also knows the totals.
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uint64_t n, Params P, const uint64_t *bsV, const uint64_t *bsT,
+// Second pass: every block first adds up what lies before its chunk - the sums of the groups of SCAN_GROUP chunks before its
+// own group and of the chunks of its group before it (a few hundred values, resident in L2; cheaper than a separate
+// one-block scan kernel between the two passes) - then scans its chunk.  The last block also knows the totals.
+// (Until round 3 a block added up ALL chunk sums before its own: 8 180 chunks at 1024^3, 32 724 at 2048 x 2048 x 1024 -
+// half a megabyte per block there.  One pass with a decoupled look-back - chunk states {nothing / own sum / running sum}
+// in one 64-bit word per sum, agent-scope atomics, chunks by ticket - was written and is correct and slower: 41 us against
+// 10 + 9 at 1024^3, 116 against 76 at 2048 x 2048 x 1024: a state crosses from one XCD's L2 to another's through memory,
+// and the chain of running sums is as long as the launch has rounds of blocks.)
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uint64_t n, Params P, const uint64_t *bsV, const uint64_t *bsT, const uint64_t *grV, const uint64_t *grT,
                                                     SegBase *seg_base, uint64_t ghost_segs, Counters *ctr) {
 	__shared__ uint32_t sv[4], st[4];
 	__shared__ uint64_t s_bv[4], s_bt[4];
 	uint64_t bv = 0, bt = 0;  // vertices / triangles of all chunks before this one
-	for (uint32_t k = threadIdx.x; k < blockIdx.x; k += 256u) { bv += bsV[k]; bt += bsT[k]; }
+	const uint32_t grp = grV ? blockIdx.x / SCAN_GROUP : 0u;
+	for (uint32_t k = threadIdx.x; k < grp; k += 256u) { bv += grV[k]; bt += grT[k]; }
+	for (uint32_t k = grp * SCAN_GROUP + threadIdx.x; k < blockIdx.x; k += 256u) { bv += bsV[k]; bt += bsT[k]; }
 	bv = wave_sum(bv); bt = wave_sum(bt);
 	if ((threadIdx.x & 63u) == 0) { s_bv[threadIdx.x >> 6] = bv; s_bt[threadIdx.x >> 6] = bt; }
 	__syncthreads();
@@ -1472,96 +1486,6 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uin
 	if (lane == 63) { sv[wv] = iv; st[wv] = it; }
 	__syncthreads();
 	uint32_t ev = (uint32_t)bv + iv - v, et = (uint32_t)bt + it - t;
-	for (uint32_t k = 0; k < wv; k++) { ev += sv[k]; et += st[k]; }
-#pragma unroll
-	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
-		if (q0 + k < n) {
-			if (cv[k] | ct[k]) seg_base[st_idx[k]] = SegBase{ev, et};  // (nobody asks for the base of a row segment that holds nothing)
-			if (q0 + k == ghost_segs) { ctr->ghostV = ev; ctr->ghostT = et; }  // first segment of the emitted range
-		}
-		ev += cv[k]; et += ct[k];
-	}
-}
-
-#endif
-// One pass instead of the two above (round 3; the two stay for A/B timing in developer builds): every block publishes the
-// sum of its chunk, looks BACK over the chunks before it until it meets one whose sum of everything before is known
-// (decoupled look-back), publishes its own, and scans its chunk out of the registers it loaded it into.  k_scan_apply
-// read the sums of all chunks before its own - 16 M row segments are 8 180 chunks (1024^3), 32 724 at 2048 x 2048 x 1024:
-// half a megabyte per block - and the counts a second time.  A chunk's state is ONE 64-bit word per sum {2 bits: nothing /
-// the chunk's own sum / the sum up to and including it; 62 bits: the value}, written and read whole by agent-scope
-// atomics: no fence, no order between two words needed - a reader that finds the two words of a chunk in different
-// states reads again.  Chunks are handed out by a ticket, so the chunks a block waits for belong to blocks that have
-// started and wait for nobody behind them: every wait ends.  k_slots clears states and ticket.
-constexpr uint64_t SCAN_OWN = 1ull << 62, SCAN_UPTO = 2ull << 62, SCAN_VALUE = (1ull << 62) - 1ull;
-__global__ __launch_bounds__(256) void k_scan(const uint32_t *seg_cnt, uint64_t n, Params P, unsigned long long *stV, unsigned long long *stT,
-                                              SegBase *seg_base, uint64_t ghost_segs, Counters *ctr) {
-	__shared__ uint32_t sv[4], st[4], s_chunk;
-	__shared__ uint64_t s_before[2];
-	if (threadIdx.x == 0) s_chunk = atomicAdd(&ctr->scan_ticket, 1u);
-	__syncthreads();
-	const uint32_t chunk = s_chunk;
-	const uint64_t q0 = (uint64_t)chunk * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
-	uint32_t cv[SCAN_PER_THREAD], ct[SCAN_PER_THREAD], v = 0, t = 0;
-	uint64_t st_idx[SCAN_PER_THREAD];
-	SweepWalk walk(P, q0);
-#pragma unroll
-	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
-		st_idx[k] = (q0 + k < n) ? walk.store() : 0;
-		walk.next();
-		const uint32_t c = (q0 + k < n) ? seg_cnt[st_idx[k]] : 0u;
-		cv[k] = c & 0xFFFFu; ct[k] = c >> 16;
-		v += cv[k]; t += ct[k];
-	}
-	uint32_t iv = v, it = t;
-	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint32_t a = __shfl_up(iv, d), b = __shfl_up(it, d);
-		if ((int)lane >= d) { iv += a; it += b; }
-	}
-	if (lane == 63) { sv[wv] = iv; st[wv] = it; }
-	__syncthreads();
-	if (wv == 0) {  // the first wave: the chunk's sums out, the sums of everything before it in
-		const uint64_t ownV = (uint64_t)sv[0] + sv[1] + sv[2] + sv[3], ownT = (uint64_t)st[0] + st[1] + st[2] + st[3];
-		uint64_t beforeV = 0, beforeT = 0;
-		if (chunk != 0) {
-			if (lane == 0) {
-				__hip_atomic_store(stV + chunk, SCAN_OWN | ownV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__hip_atomic_store(stT + chunk, SCAN_OWN | ownT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			for (int64_t top = (int64_t)chunk - 1;; top -= 64) {  // lane l looks at chunk top - l
-				const int64_t k = top - (int64_t)lane;
-				uint64_t a = SCAN_UPTO, b = SCAN_UPTO;  // (before chunk 0: nothing, and known)
-				for (uint32_t polls = 0;; polls++) {
-					if (k >= 0) {
-						a = __hip_atomic_load(stV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						b = __hip_atomic_load(stT + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					}
-					if (!__ballot((a >> 62) == 0 || (a >> 62) != (b >> 62))) break;
-					if (polls == (1u << 22)) {  // (seconds: cannot happen - but no wave of this kernel may wait for ever; the host reports it)
-						if (lane == 0) atomicCAS(&ctr->debug[0], 0u, 3u);
-						a = b = SCAN_UPTO;
-						break;
-					}
-					__builtin_amdgcn_s_sleep(1);
-				}
-				const uint64_t known = __ballot((a >> 62) == 2u);
-				const uint32_t stop = known ? (uint32_t)__builtin_ctzll(known) : 63u;  // the nearest chunk whose running sum is known ends the walk
-				beforeV += wave_sum(lane <= stop ? (a & SCAN_VALUE) : 0ull);
-				beforeT += wave_sum(lane <= stop ? (b & SCAN_VALUE) : 0ull);
-				if (known) break;
-			}
-		}
-		if (lane == 0) {
-			__hip_atomic_store(stV + chunk, SCAN_UPTO | (beforeV + ownV), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			__hip_atomic_store(stT + chunk, SCAN_UPTO | (beforeT + ownT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			s_before[0] = beforeV; s_before[1] = beforeT;
-			if (chunk == gridDim.x - 1) { ctr->totV = beforeV + ownV; ctr->totT = beforeT + ownT; }
-		}
-	}
-	__syncthreads();
-	uint32_t ev = (uint32_t)s_before[0] + iv - v, et = (uint32_t)s_before[1] + it - t;
 	for (uint32_t k = 0; k < wv; k++) { ev += sv[k]; et += st[k]; }
 #pragma unroll
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
@@ -1902,7 +1826,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 					const uint32_t it = g * 64u + lane;
 					const uint32_t r = it / EV_W, ck = it - r * EV_W;
 					const bool need = it < NITEM && (info[g] >> 31) && ck <= ((info[g] >> 16) & 3u);
-					if (need) {  // (unconditional loads from a safe address for the other lanes were tried: 4 % slower on ushort grids)
+					// (unconditional loads from a safe address for the other lanes were tried: 4 % slower on ushort grids; so were loads
+					// through a buffer descriptor with those lanes aimed past its end - the hardware answers zeros, no branch, no
+					// registers to clear, 54 vector instructions less in the kernel - 112 -> 115 us at C3, 501 -> 525 at C5: a lane that is
+					// switched off costs the memory pipeline nothing, a lane that is refused does)
+					if (need) {
 						const char *addr = plane0 + (uint64_t)r * pitchB + (uint64_t)((info[g] & 0xFFFFu) + ck) * 16u;
 						q0 = *(const uint4 *)addr;
 						q1 = *(const uint4 *)(addr + sliceB);
@@ -2503,7 +2431,7 @@ static int ensure_workspaces(mc33hip_ctx *c) {
 		(void)hipFree(c->bsV);
 		c->bsV = c->bsT = nullptr;
 		c->bs_cap = 0;
-		HIP_TRY(hipMalloc(&c->bsV, 2 * nb * 8));  // (k_scan: the states of the two sums, one after the other)
+		HIP_TRY(hipMalloc(&c->bsV, 2 * (nb + scan_groups(nb)) * 8));  // chunk sums V, T; then group sums V, T
 		c->bsT = c->bsV + nb;
 		c->bs_cap = nb;
 	}
@@ -2801,7 +2729,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	}
 	ca.lc = c->lc;
 	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK)), dim3(256), 0, st, L.slice_hdr, lane_part(L, false), lane_part(L, true),
-	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr, c->lc, (unsigned long long *)c->bsV, (uint32_t)(2 * c->bs_cap));
+	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr, c->lc, (unsigned long long *)(c->bsV + 2 * c->bs_cap), (uint32_t)(2 * scan_groups(c->bs_cap)));
 	L.tail_pending = false;  // k_slots has read this epoch's partial sums and cleared the half of the next one
 	hipLaunchKernelGGL(k_cells, dim3((uint32_t)g.cell_blocks), dim3(256), 0, st, ca);
 	SlowArgs sa;
@@ -2817,14 +2745,9 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	hipLaunchKernelGGL(k_slow_count, dim3(slow_blocks), dim3(256), 0, st, sa);
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
 	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
-#ifdef MC33_DEV
-	if (env_u32("MC33_HIP_TWO_PASS_SCAN", 0)) {  // (the scan of rounds 1 and 2, for A/B timing)
-		hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT);
-		hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, c->seg_base, c->ghost_segs, c->d_ctr);
-	} else
-#endif
-	hipLaunchKernelGGL(k_scan, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, (unsigned long long *)c->bsV, (unsigned long long *)c->bsT,
-	                   c->seg_base, c->ghost_segs, c->d_ctr);
+	uint64_t *grV = nb >= SCAN_GROUPED_FROM ? c->bsV + 2 * c->bs_cap : nullptr, *grT = grV ? grV + scan_groups(c->bs_cap) : nullptr;
+	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, grV, grT);
+	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, grV, grT, c->seg_base, c->ghost_segs, c->d_ctr);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
