@@ -86,6 +86,8 @@ struct Counters {
 	uint32_t batch_cursor;  // batches of <= 64 records of one slice slot (BatchDesc) the emit passes walk
 	uint32_t emit_skipped;  // set by the emit kernels when they refused to run (capacity / overflow)
 	uint32_t count_pending; // set by k_slow_plan when a record waits for k_slow_count
+	uint32_t live_cursor;   // slice slots with cut cells listed by k_slots for k_cells (k_scan_apply, the last kernel of a tail, clears it)
+	uint32_t pad_;
 	uint64_t totV, totT;    // totals over all classified slices (ghost included)
 	uint64_t ghostV, ghostT;
 	uint32_t debug[8];      // (-DMC33_DEV: what a guarded kernel found wrong)
@@ -143,7 +145,7 @@ __host__ __device__ inline uint64_t slice_slot(uint32_t dz, uint32_t yt, uint32_
 	return ((((uint64_t)yt * d.nseg + seg) * d.nZG + (dz >> 2)) << 2) | (dz & 3u);
 #endif
 }
-// the inverse for a group of four: block of k_cells -> (z group, y tile, row segment)
+// the inverse for a group of four slots (slot >> 2) -> (z group, y tile, row segment)
 __device__ inline void slot_group_coords(uint32_t b, const SlotDims &d, uint32_t &zq, uint32_t &yt, uint32_t &seg) {
 #if MC33_SLOT_ORDER == 0
 	seg = b % d.nseg; const uint32_t t = b / d.nseg; yt = t % d.nYT; zq = t / d.nYT;
@@ -890,8 +892,9 @@ struct ChunkMap {  // per block, in LDS: exclusive prefix sums of the group coun
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const unsigned long long *part, unsigned long long *part_next,
                                                uint32_t part_cap, uint32_t epoch, uint64_t nslots, uint2 *slot_base, Counters *ctr, ListChunks lc,
-                                               unsigned long long *scan_state, uint32_t scan_words) {
+                                               unsigned long long *scan_state, uint32_t scan_words, uint32_t *live_list) {
 	__shared__ unsigned long long s_red[256];
+	__shared__ uint32_t s_live[256], s_live_base;
 	const uint32_t c = blockIdx.x, t = threadIdx.x;
 	for (uint32_t q = c * 256u + t; q < scan_words; q += gridDim.x * 256u) scan_state[q] = 0;  // the group sums of this extraction's scan (k_scan_reduce adds to them)
 	if (t == 0) part_next[c] = 0;  // the partial sums of the NEXT extraction live in the other half: cleared here
@@ -924,13 +927,29 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 		cells[k] = valid ? h.y : 0u; rows[k] = (cells[k] + 63u) >> 6;  // (second sum: batches of 64 records, as the sweep added them)
 		mine += (unsigned long long)rows[k] << 32 | cells[k];
 	}
-	s_red[t] = mine;
+	uint32_t nlive = 0;  // slots of this thread with cut cells
+#pragma unroll
+	for (uint32_t k = 0; k < PER; k++) nlive += cells[k] ? 1u : 0u;
+	s_red[t] = mine; s_live[t] = nlive;
 	__syncthreads();
 	for (uint32_t d = 1; d < 256; d <<= 1) {  // inclusive scan over the threads
 		const unsigned long long v = t >= d ? s_red[t - d] : 0ull;
+		const uint32_t w = t >= d ? s_live[t - d] : 0u;
 		__syncthreads();
-		s_red[t] += v;
+		s_red[t] += v; s_live[t] += w;
 		__syncthreads();
+	}
+	// The slots with cut cells, listed for k_cells (a third of the slots of a smooth field: a wave per SLOT spent 88 us at
+	// 1024^3 mostly being launched - 69 632 waves at the 870 per microsecond this GPU starts them at, two thirds of them to
+	// find their slice empty; round 3).  The list's order is whatever order the blocks of this kernel arrive in: it decides
+	// which wave of k_cells takes which slice and nothing else - where a slice's records go is slot_base.
+	if (t == 255) s_live_base = s_live[255] ? atomicAdd(&ctr->live_cursor, s_live[255]) : 0u;
+	__syncthreads();
+	{
+		uint32_t at = s_live_base + s_live[t] - nlive;
+#pragma unroll
+		for (uint32_t k = 0; k < PER; k++)
+			if (cells[k]) live_list[at++] = (uint32_t)(s0 + k);
 	}
 	unsigned long long run = base + s_red[t] - mine;
 #pragma unroll
@@ -965,6 +984,14 @@ struct alignas(32) BatchDesc {
 	uint32_t pad_[2];
 };
 
+// A row segment's counts in seg_cnt: {vertices: 12 bits, triangles: 12 bits, tag: 8 bits}.  The tag names the tail (k_slots ...
+// k_scan_apply) that wrote the word, 1 .. 255 in turn; a word with another tag counts as zero.  So nobody writes the counts of
+// the row segments that hold nothing - k_cells only looks at slices with cut cells (round 3) - and nobody clears the array
+// between extractions (every 255 tails the host does).  A segment of 256 cells has at most 256 x 9 vertices (a row of the
+// y = 0, z = 0 edge of the grid, every edge of every cell cut) and 256 x 12 triangles.
+constexpr uint32_t SEG_TAGS = 255u;
+__host__ __device__ inline uint32_t seg_tagged(uint32_t nv, uint32_t nt, uint32_t tag) { return nv | nt << 12 | tag << 24; }
+__host__ __device__ inline uint32_t seg_counts(uint32_t word, uint32_t tag) { return (word >> 24) == tag ? (word & 0xFFFFFFu) : 0u; }  // nv | nt << 12
 struct CellsArgs {
 	uint32_t dev;            // (-DMC33_DEV: MC33_HIP_CELLS_DEV experiments)
 	uint32_t pack;           // samples per lane and load of the sweep that made the records (lane_of_column)
@@ -973,6 +1000,9 @@ struct CellsArgs {
 	const uint4 *fast;       // per sign index: record words of a FAST cell (fast_record_table)
 	uint32_t ze;
 	SlotDims sd;
+	const uint32_t *live_list;  // slots with cut cells (k_slots)
+	uint32_t seg_tag;           // seg_tagged
+	uint32_t live_cap;
 	const SliceHeader *slice_hdr;
 	const uint4 *slice_bits;
 	const uint8_t *plane_fmt;
@@ -1039,19 +1069,23 @@ __device__ __forceinline__ uint2 corner_look(const GridView<sample_t> &G, real_t
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_cells(const CellsArgs a) {  // (4 waves per SIMD is what its LDS allows: keep the registers of the rare test code from costing one)
-	const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	__shared__ uint4 s_fast[256];
 	__shared__ CellsLds s_w[4];
 	s_fast[threadIdx.x] = a.fast[threadIdx.x];
-	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	const uint32_t lane = threadIdx.x & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	CellsLds &L = s_w[wv];
 	const Params &P = a.P;
-	// block -> 4 consecutive slices of one tile column (slice_slot order)
-	const uint64_t slot = (uint64_t)blockIdx.x * 4 + wv;
+	// As many waves as the GPU holds (the host sizes the grid), each taking slices off k_slots' list of slots with cut cells:
+	// nobody is launched to find a slice empty.
+	const uint32_t nlive = min(a.ctr->live_cursor, a.live_cap);
+	__syncthreads();  // s_fast
+	for (uint32_t item = blockIdx.x * 4u + wv; item < nlive; item += gridDim.x * 4u) {
+	const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+	const uint64_t slot = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.live_list[item]);
 	uint32_t seg, yt, zq;
-	slot_group_coords(blockIdx.x, a.sd, zq, yt, seg);
+	slot_group_coords((uint32_t)(slot >> 2), a.sd, zq, yt, seg);
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
-	const uint32_t z = P.zs + zq * 4u + wv;
+	const uint32_t z = P.zs + zq * 4u + (uint32_t)(slot & 3u);
 	const uint32_t y = y0 + lane;
 	const bool in_grid = seg < P.nseg && z < a.ze;
 	SliceHeader h;
@@ -1075,14 +1109,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 		du = ((const uint32_t *)(a.slice_bits + slot_up * 128u))[lane];
 		fmt_l = a.plane_fmt[slot]; fmt_u = a.plane_fmt[slot_up];
 	}
-	__syncthreads();  // s_fast
 	const bool live = in_grid && slice_valid(h.flags, a.epoch);  // wave-uniform
 	const bool rowvalid = lane < 63u && y < P.ny;
 	const uint64_t sidx = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y;  // storage order [z][segment][y]
-	if (!live) {  // no cut cell in the slice: zero counts for its row segments
-		if (in_grid && rowvalid) a.seg_cnt[sidx] = 0u;
-		return;
-	}
+	if (!live) continue;  // (cannot be: the slot is on the list.  The counts of row segments nobody writes are zero: k_scan_apply leaves them so)
 	uint64_t prev[4], cur[4], act[4];
 	{
 		const bool raw_l = __builtin_amdgcn_readfirstlane((int)fmt_l) != (int)PLANE_COMPACT, raw_u = __builtin_amdgcn_readfirstlane((int)fmt_u) != (int)PLANE_COMPACT;
@@ -1230,11 +1260,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 			if (kin + 1u == rowcnt || lane == 63u) L.run[r] = off + val;  // last cell of the row in this batch
 		}
 	}
-	if (rowvalid && !cnt) a.seg_cnt[sidx] = 0u;  // every row segment of the range is written: no clearing pass
 	if (rowvalid && cnt) {
 		const bool dirty = (L.slowrow[lane] & 2u) != 0;
 		const uint32_t run = L.run[lane];
-		a.seg_cnt[sidx] = dirty ? 0u : seg_pack(run & 0xFFFFu, run >> 16);
+		if (!dirty) a.seg_cnt[sidx] = seg_tagged(run & 0xFFFFu, run >> 16, a.seg_tag);  // (a row with slow cells: k_seg_fix)
 		const uint32_t nf = cnt | (dirty ? SEG_DIRTY : 0u);
 		// one 64-byte line per row; only the words that hold cells are written (a lookup reads the word of an ACTIVE
 		// cell), and word 0 of a row with slow cells (k_seg_fix takes the record range from it): the few cut cells of
@@ -1256,10 +1285,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 			if (dirtylane && at < a.entry_cap) a.dirty_list[at] = (uint32_t)sidx;
 		}
 	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the wave's LDS record is written again for its next slice)
 	if (a.trace && lane == 0) {
 		unsigned long long *tr = a.trace + 4ull * slot;
 		tr[0] = t_start; tr[1] = t_bits; tr[2] = t_rows; tr[3] = __builtin_amdgcn_s_memrealtime();
+#ifdef MC33_TRACE_XCC  // (developer builds: which XCD and CU ran the wave, in place of the second stamp - HW_REG_XCC_ID, HW_REG_HW_ID)
+		tr[1] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32;
+#endif
 	}
+	}  // slices of this wave
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1284,6 +1318,7 @@ struct SlowArgs {
 	const uint32_t *entry_seg;
 	const uint32_t *slow_list;
 	uint32_t *seg_cnt;
+	uint32_t seg_tag;
 	const SegDir *seg_dir;
 	const uint32_t *dirty_list;
 	ListChunks lc;
@@ -1387,7 +1422,7 @@ __global__ __launch_bounds__(256) void k_seg_fix(const SlowArgs a) {
 			nv += entrya_nnew(*e);
 			nt += entrya_ntri(*e);
 		}
-		a.seg_cnt[s] = seg_pack(nv, nt);
+		a.seg_cnt[s] = seg_tagged(nv, nt, a.seg_tag);
 	}
 }
 
@@ -1418,7 +1453,7 @@ struct SweepWalk {
 // The records are stored [z][segment][y]; the scan runs over them in sweep order [z][y][segment]: a chunk of
 // SCAN_CHUNK consecutive sweep positions is the same set of records whatever the order inside it only
 // when it covers whole (y, all segments) groups - so the mapping is applied per element.
-__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, uint64_t n, Params P, uint64_t *bsV, uint64_t *bsT, uint64_t *grV, uint64_t *grT) {
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, uint32_t tag, uint64_t n, Params P, uint64_t *bsV, uint64_t *bsT, uint64_t *grV, uint64_t *grT) {
 	__shared__ uint64_t sv[4], st[4];
 	const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
 	uint64_t v = 0, t = 0;
@@ -1426,7 +1461,7 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, ui
 	const uint64_t q0 = base + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
 	SweepWalk walk(P, q0);
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
-		if (q0 + k < n) { const uint32_t c = seg_cnt[walk.store()]; v += c & 0xFFFFu; t += c >> 16; }
+		if (q0 + k < n) { const uint32_t c = seg_counts(seg_cnt[walk.store()], tag); v += c & 0xFFFu; t += c >> 12; }
 		walk.next();
 	}
 	v = wave_sum(v); t = wave_sum(t);
@@ -1451,7 +1486,7 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, ui
 // in one 64-bit word per sum, agent-scope atomics, chunks by ticket - was written and is correct and slower: 41 us against
 // 10 + 9 at 1024^3, 116 against 76 at 2048 x 2048 x 1024: a state crosses from one XCD's L2 to another's through memory,
 // and the chain of running sums is as long as the launch has rounds of blocks.)
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uint64_t n, Params P, const uint64_t *bsV, const uint64_t *bsT, const uint64_t *grV, const uint64_t *grT,
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uint32_t tag, uint64_t n, Params P, const uint64_t *bsV, const uint64_t *bsT, const uint64_t *grV, const uint64_t *grT,
                                                     SegBase *seg_base, uint64_t ghost_segs, Counters *ctr) {
 	__shared__ uint32_t sv[4], st[4];
 	__shared__ uint64_t s_bv[4], s_bt[4];
@@ -1472,10 +1507,11 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uin
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
 		st_idx[k] = (q0 + k < n) ? walk.store() : 0;
 		walk.next();
-		const uint32_t c = (q0 + k < n) ? seg_cnt[st_idx[k]] : 0u;
-		cv[k] = c & 0xFFFFu; ct[k] = c >> 16;
+		const uint32_t c = (q0 + k < n) ? seg_counts(seg_cnt[st_idx[k]], tag) : 0u;
+		cv[k] = c & 0xFFFu; ct[k] = c >> 12;
 		v += cv[k]; t += ct[k];
 	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) ctr->live_cursor = 0u;  // the last kernel of a tail leaves the cursor of k_slots' list zero for the next
 	uint32_t iv = v, it = t;
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -1958,9 +1994,13 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	// has finished: they are final, and every emit kernel decides `emit_skipped` alike): the call's one synchronisation then
 	// finds them there, without a device-to-host copy command of 100 bytes behind the last kernel.
 	if (a.host_ctr && blockIdx.x == 0 && threadIdx.x == 0) {
-		Counters out = ctr;
-		out.emit_skipped = ok ? 0u : 1u;
-		*a.host_ctr = out;
+		// (word by word from memory to memory: a private copy of the struct put scratch memory into the kernel - every wave's
+		// launch pays for that - as soon as the struct grew by two words: 90 -> 122 us at 1024^3, round 3)
+		static_assert(sizeof(Counters) % 4 == 0, "Counters in words");
+		const volatile uint32_t *src = (const volatile uint32_t *)a.ctr;
+		volatile uint32_t *dst = (volatile uint32_t *)a.host_ctr;
+		for (uint32_t k = 0; k < sizeof(Counters) / 4; k++) dst[k] = src[k];
+		a.host_ctr->emit_skipped = ok ? 0u : 1u;
 	}
 	if (!ok) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
@@ -2064,6 +2104,9 @@ struct mc33hip_ctx {
 	IsoLane lanes[MC33_LANES]; // what a sweep leaves behind, per isovalue (lane 0: the single-isovalue calls)
 	uint2 *slot_base;
 	uint64_t slot_base_cap;
+	uint32_t *live_list;     // [slot_base_cap]: slots with cut cells, k_slots -> k_cells
+	uint32_t cells_blocks;   // blocks of k_cells the GPU holds at once
+	uint32_t tail_serial;    // tails enqueued (seg_tagged)
 	uint32_t epoch_wrap;      // the stamps start over at this count (2^30; MC33_HIP_EPOCH_WRAP for the test that crosses it)
 	IsoLane *cur_lane;        // the lane the last count used (its epoch is what the emit pass needs)
 	bool lane_presweeped;     // ... and it had been filled by mc33hip_sweep_many
@@ -2200,6 +2243,7 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 		CREATE_TRY(hipMemcpy(c->d_pat, pat, sizeof pat, hipMemcpyHostToDevice));
 	}
 	CREATE_TRY(hipMalloc(&c->d_ctr, sizeof(Counters)));
+	CREATE_TRY(hipMemset(c->d_ctr, 0, sizeof(Counters)));  // (live_cursor: every tail leaves it zero for the next)
 	CREATE_TRY(hipMalloc(&c->list_cnt, 2 * LIST_CHUNKS * sizeof(uint32_t)));
 	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
 	for (int k = 0; k < 4; k++) CREATE_TRY(hipEventCreate(&c->ev[k]));
@@ -2231,7 +2275,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.plane_fmt); (void)hipFree(L.slot_part); (void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
 	}
 	(void)hipFree(c->d_tiles);
-	(void)hipFree(c->slot_base);
+	(void)hipFree(c->slot_base); (void)hipFree(c->live_list);
 	(void)hipFree(c->d_bounds);
 	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
 	(void)hipFree(c->d_ctr); (void)hipFree(c->list_cnt);
@@ -2422,6 +2466,7 @@ static int ensure_workspaces(mc33hip_ctx *c) {
 		c->seg_cnt = nullptr; c->seg_dir = nullptr; c->seg_base = nullptr;
 		c->seg_cap = 0;
 		HIP_TRY(hipMalloc(&c->seg_cnt, c->nsegs * 4));
+		c->tail_serial = 0;  // (the first tail clears the new array)
 		HIP_TRY(hipMalloc(&c->seg_dir, c->nsegs * sizeof(SegDir)));
 		HIP_TRY(hipMalloc(&c->seg_base, c->nsegs * sizeof(SegBase)));
 		c->seg_cap = c->nsegs;
@@ -2673,9 +2718,10 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	hipStream_t st = c->stream;
 	const uint32_t ze = c->range.z_end;
 	if (c->slot_base_cap < g.nslots) {
-		(void)hipFree(c->slot_base);
-		c->slot_base = nullptr; c->slot_base_cap = 0;
+		(void)hipFree(c->slot_base); (void)hipFree(c->live_list);
+		c->slot_base = nullptr; c->live_list = nullptr; c->slot_base_cap = 0;
 		HIP_TRY(hipMalloc(&c->slot_base, g.nslots * sizeof(uint2)));
+		HIP_TRY(hipMalloc(&c->live_list, g.nslots * sizeof(uint32_t)));
 		c->slot_base_cap = g.nslots;
 	}
 	{  // batch descriptors: every 64 records one, plus at most one partly filled batch per slice slot
@@ -2706,6 +2752,12 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	ca.P = P; ca.fast = c->d_fast; ca.pat = c->d_pat;
 	ca.ze = ze; ca.sd = g.sd;
 	ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.plane_fmt = L.plane_fmt; ca.slot_base = c->slot_base;
+	// the tag of this tail's row-segment counts; the array is cleared whenever the tags start over
+	if (c->tail_serial % SEG_TAGS == 0) HIP_TRY(hipMemsetAsync(c->seg_cnt, 0, c->seg_cap * 4, st));
+	const uint32_t seg_tag = c->tail_serial % SEG_TAGS + 1u;
+	c->tail_serial++;
+	ca.seg_tag = seg_tag;
+	ca.live_list = c->live_list; ca.live_cap = (uint32_t)std::min<uint64_t>(g.nslots, 0xFFFFFFFFull);
 	ca.epoch = L.epoch;
 	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir;
 	ca.entries_a = c->entries_a; ca.entries_b = c->entries_b; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
@@ -2729,15 +2781,23 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	}
 	ca.lc = c->lc;
 	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK)), dim3(256), 0, st, L.slice_hdr, lane_part(L, false), lane_part(L, true),
-	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr, c->lc, (unsigned long long *)(c->bsV + 2 * c->bs_cap), (uint32_t)(2 * scan_groups(c->bs_cap)));
+	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr, c->lc, (unsigned long long *)(c->bsV + 2 * c->bs_cap), (uint32_t)(2 * scan_groups(c->bs_cap)), c->live_list);
 	L.tail_pending = false;  // k_slots has read this epoch's partial sums and cleared the half of the next one
-	hipLaunchKernelGGL(k_cells, dim3((uint32_t)g.cell_blocks), dim3(256), 0, st, ca);
+	if (!c->cells_blocks) {
+		int per_cu = 0, cus = 0;
+		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cells, 256, 0));
+		HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+		c->cells_blocks = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, cus);
+	}
+	// (four times what the GPU holds at once: slices differ in length, and a block that starts late evens the waves out -
+	// 76 -> 66 us at 1024^3; a block per group of four slots, as until round 3, is 17 408 blocks there)
+	hipLaunchKernelGGL(k_cells, dim3((uint32_t)std::min<uint64_t>(g.cell_blocks, env_u32("MC33_HIP_CELLS_BLOCKS", 4u * c->cells_blocks))), dim3(256), 0, st, ca);
 	SlowArgs sa;
 	sa.G = a.G; sa.P = P;
 	sa.tab.lut = c->d_lut; sa.tab.rule_words = c->d_rules; sa.tab.rule_index = c->d_rule_index;
 	sa.z_emit = c->range.z_begin;
 	sa.entries_a = c->entries_a; sa.entries_b = c->entries_b; sa.entries_c = c->entries_c; sa.fast_b = c->d_fast_b; sa.entry_seg = c->entry_seg; sa.slow_list = c->slow_list;
-	sa.seg_cnt = c->seg_cnt; sa.seg_dir = c->seg_dir; sa.dirty_list = c->dirty_list;
+	sa.seg_cnt = c->seg_cnt; sa.seg_tag = seg_tag; sa.seg_dir = c->seg_dir; sa.dirty_list = c->dirty_list;
 	sa.lc = c->lc; sa.slot_base = c->slot_base;
 	sa.entry_cap = (uint32_t)c->entry_cap; sa.ctr = c->d_ctr;
 	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);  // (blocks beyond the list end at once)
@@ -2746,8 +2806,8 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
 	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
 	uint64_t *grV = nb >= SCAN_GROUPED_FROM ? c->bsV + 2 * c->bs_cap : nullptr, *grT = grV ? grV + scan_groups(c->bs_cap) : nullptr;
-	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, grV, grT);
-	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, c->nsegs, P, c->bsV, c->bsT, grV, grT, c->seg_base, c->ghost_segs, c->d_ctr);
+	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, seg_tag, c->nsegs, P, c->bsV, c->bsT, grV, grT);
+	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, seg_tag, c->nsegs, P, c->bsV, c->bsT, grV, grT, c->seg_base, c->ghost_segs, c->d_ctr);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }

@@ -129,6 +129,36 @@ def test_one_context_many_extractions_of_different_extent(reflibs):
             g2.close()
 
 
+def test_segment_count_tags_start_over(reflibs):
+    """The counts of the row segments carry the number of the tail that wrote them (1 .. 255 in turn; a word with another
+    number counts as zero, so the rows of slices without cut cells are never written and nothing is cleared between
+    extractions); when the numbers start over the host clears the array.  600 extractions of one context, isovalues and
+    z ranges changing so that most row segments hold something from SOME earlier call: every one must equal the first
+    computation of its kind."""
+    import torch
+    from mc33_c_library_amd import DeviceGrid, Range
+    data = fx.noise_quant(40, 11)  # samples in {-2 .. 2}: slow cells and dirty row segments too
+    r0, d = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+    nz = data.shape[0] - 1
+    t = torch.from_numpy(data).cuda()
+    g = DeviceGrid(t, r0=r0, d=d)
+    kinds = [(0.0, None), (0.5, None), (-1.0, (5, 20)), (1.5, (0, 3)), (9.0, None), (0.0, (30, nz))]
+    first = {}
+    for step in range(600):
+        iso, zr = kinds[step % len(kinds)]
+        rng = None if zr is None else Range(zr[0], zr[1], 1 if zr[0] else 0, 0)
+        V, N, T, cnt = g.extract(iso) if rng is None else g.extract(iso, rng)
+        got = (cnt.nV, cnt.nT, T.cpu().numpy().tobytes(), V.cpu().numpy().tobytes(), N.cpu().numpy().tobytes())
+        if step < len(kinds):
+            first[step] = got
+            if zr is None:
+                ref = reflibs["f32"].isosurface(data, iso, r0, d)
+                assert (cnt.nV, cnt.nT) == (ref.nV, ref.nT) and np.array_equal(T.cpu().numpy().view(np.uint32), ref.T) and beq(V.cpu().numpy(), ref.V)
+        else:
+            assert got == first[step % len(kinds)], (step, iso, zr)
+    g.close()
+
+
 @pytest.mark.parametrize("dtype", ["f32", "u16", "u16mix", "u8"])
 def test_sweep_many_equals_single_sweeps(reflibs, dtype):
     """mc33hip_sweep_many classifies up to 8 isovalues per pass over the grid (4 per kernel launch); the extractions
