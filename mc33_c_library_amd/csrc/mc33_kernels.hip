@@ -15,7 +15,7 @@
 //                   (mc33hip_sweep_many), each with its own "lane" of output buffers; ZM: how a sample is classified.
 //   k_boundary    - the slice between two z-tiles of k_sweep, from the edge planes both left behind.
 //   k_slots       - exclusive sums of (cut cells, batches of 64 of them) over the slice slots in storage order.
-//   k_cells       - one wave per cut slice, 64 cut cells per step: sign index from the bit planes; fast cells (interior,
+//   k_cells       - the waves take cut slices off a list k_slots made, 64 cut cells per step: sign index from the bit planes; fast cells (interior,
 //                   no test needed, no sample == iso) finished from a 256-entry table, cells whose sign index needs the
 //                   face / interior tests tested here (TESTED records), the rest queued for k_slow_plan; one 8-byte work
 //                   record per cut cell, contiguous in the reference's visiting order, (#new vertices, #triangles) per
@@ -888,7 +888,8 @@ struct ChunkMap {  // per block, in LDS: exclusive prefix sums of the group coun
 // k_slots: exclusive prefix sums of (cut cells, batches of 64 of them) over the slice slots in slot order = the
 // work-record range and the range of batch descriptors of every slice.  The sweep has already added every slice
 // into the partial sum of its chunk of SLOT_CHUNK slots; block c sums the partials below c and scans its
-// own chunk.  Record order is therefore a function of the grid alone (no allocation atomics).
+// own chunk.  Record order is therefore a function of the grid alone (no allocation atomics).  The slots with cut cells
+// are also listed, for k_cells.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const unsigned long long *part, unsigned long long *part_next,
                                                uint32_t part_cap, uint32_t epoch, uint64_t nslots, uint2 *slot_base, Counters *ctr, ListChunks lc,
@@ -965,7 +966,8 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_cells: turns the slice records of the sweep into work records; one wave per slice, waves independent.
+// k_cells: turns the slice records of the sweep into work records; a wave per slice at a time (the waves take the slices
+// with cut cells off k_slots' list), waves independent.
 // Lane = row for the bookkeeping (activity masks, per-row counts, directory); for the cells themselves the
 // wave takes 64 cells at a time in record order (row, then x): lane g finds its row by a search in the
 // prefix sums of the row counts, its cell as the n-th set bit of the row's activity mask, reads the 8
@@ -1076,7 +1078,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 	CellsLds &L = s_w[wv];
 	const Params &P = a.P;
 	// As many waves as the GPU holds (the host sizes the grid), each taking slices off k_slots' list of slots with cut cells:
-	// nobody is launched to find a slice empty.
+	// nobody is launched to find a slice empty.  (The list entry of the wave's NEXT slice fetched one slice ahead through the
+	// scalar cache, so that a slice starts with one round trip instead of two: no change, 67.6 us either way - with the empty
+	// waves gone the kernel is within a quarter of what its 32 M vector instructions take.)
 	const uint32_t nlive = min(a.ctr->live_cursor, a.live_cap);
 	__syncthreads();  // s_fast
 	for (uint32_t item = blockIdx.x * 4u + wv; item < nlive; item += gridDim.x * 4u) {
