@@ -23,12 +23,16 @@ else:
     iso = 128.5
 gb = t.numel() * t.element_size() / 1e9
 for b in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["4"]):
+    dbg = "0"
+    if ":" in b:  # blocks:debug bits (developer builds)
+        b, dbg = b.split(":")
     os.environ["MC33_HIP_SWEEP_BLOCKS_PER_CU"] = b
+    os.environ["MC33_HIP_DEBUG"] = dbg
     g = api.DeviceGrid(t)
     ts = []
     for _ in range(12):
         g.count(iso)
         ts.append(g.timing().sweep_ms)
     ts.sort()
-    print("%s blocks/CU %s: sweep min %.3f median %.3f ms  %.0f GB/s" % (which, b, ts[0], ts[len(ts) // 2], gb / ts[0] * 1e3))
+    print("%s debug %s blocks/CU %s: sweep min %.3f median %.3f ms  %.0f GB/s" % (which, dbg, b, ts[0], ts[len(ts) // 2], gb / ts[0] * 1e3))
     del g
