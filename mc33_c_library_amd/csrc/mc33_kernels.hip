@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(256) void k_seg_fix(const SlowArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // prefix sums over the row segments (sweep order)
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t SCAN_PER_THREAD = 8, SCAN_CHUNK = 256 * SCAN_PER_THREAD, SCAN_GROUP = 32, SCAN_GROUPED_FROM = 12288;
+constexpr uint32_t SCAN_PER_THREAD = 8, SCAN_CHUNK = 256 * SCAN_PER_THREAD, SCAN_GROUP = 32, SCAN_GROUPED_FROM = 4096;
 __host__ __device__ inline uint64_t scan_groups(uint64_t nchunks) { return (nchunks + SCAN_GROUP - 1) / SCAN_GROUP; }
 
 
@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, ui
 		const uint64_t cv = sv[0] + sv[1] + sv[2] + sv[3], ct = st[0] + st[1] + st[2] + st[3];
 		bsV[blockIdx.x] = cv; bsT[blockIdx.x] = ct;
 		// ... and into the sum of the chunk's group of SCAN_GROUP chunks (cleared by k_slots): k_scan_apply then adds up the groups
-		// before its own and the chunks of its own group before it - a few hundred values instead of up to 32 724 (2048 x 2048 x 1024)
+		// before its own and the chunks of its own group before it - a few dozen values instead of up to 8 181 (2048 x 2048 x 1024)
 		// (grV == nullptr: not worth its atomics - 4 us at 1024^3 - below SCAN_GROUPED_FROM chunks)
 		if (grV && cv) atomicAdd((unsigned long long *)grV + blockIdx.x / SCAN_GROUP, (unsigned long long)cv);
 		if (grV && ct) atomicAdd((unsigned long long *)grT + blockIdx.x / SCAN_GROUP, (unsigned long long)ct);
@@ -1485,8 +1485,8 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, ui
 // Second pass: every block first adds up what lies before its chunk - the sums of the groups of SCAN_GROUP chunks before its
 // own group and of the chunks of its group before it (a few hundred values, resident in L2; cheaper than a separate
 // one-block scan kernel between the two passes) - then scans its chunk.  The last block also knows the totals.
-// (Until round 3 a block added up ALL chunk sums before its own: 8 180 chunks at 1024^3, 32 724 at 2048 x 2048 x 1024 -
-// half a megabyte per block there.  One pass with a decoupled look-back - chunk states {nothing / own sum / running sum}
+// (Until round 3 a block added up ALL chunk sums before its own: 2 045 chunks at 1024^3, 8 181 at 2048 x 2048 x 1024 -
+// 128 KB per block there.  One pass with a decoupled look-back - chunk states {nothing / own sum / running sum}
 // in one 64-bit word per sum, agent-scope atomics, chunks by ticket - was written and is correct and slower: 41 us against
 // 10 + 9 at 1024^3, 116 against 76 at 2048 x 2048 x 1024: a state crosses from one XCD's L2 to another's through memory,
 // and the chain of running sums is as long as the launch has rounds of blocks.)
