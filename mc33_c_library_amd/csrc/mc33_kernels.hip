@@ -2804,7 +2804,10 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	sa.seg_cnt = c->seg_cnt; sa.seg_tag = seg_tag; sa.seg_dir = c->seg_dir; sa.dirty_list = c->dirty_list;
 	sa.lc = c->lc; sa.slot_base = c->slot_base;
 	sa.entry_cap = (uint32_t)c->entry_cap; sa.ctr = c->d_ctr;
-	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);  // (blocks beyond the list end at once)
+	// (blocks beyond the lists end at once.  A grid sized from the last extraction's counts - 69 blocks instead of 1024 at 1024^3,
+	// whose 8 820 slow cells are 35 blocks' worth - changes nothing: 13.5 / 6 / 8.7 us either way.  What these kernels take is
+	// the chain of dependent loads of the cells that ARE slow, not their empty blocks; round 3)
+	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);
 	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks), dim3(256), 0, st, sa);
 	hipLaunchKernelGGL(k_slow_count, dim3(slow_blocks), dim3(256), 0, st, sa);
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
