@@ -1646,8 +1646,11 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 // Window of a sample row in the LDS image: EV_W 16-byte chunks from the chunk that holds the first sample the batch needs of
 // that row.  A row that needs more (a long run of records along x, or records far apart: noise) is not staged; the
 // records that read it load for themselves - which is cheap exactly then, many lanes of a load sharing a row.
+// (Measured per width, round 3: float 1024^3 2 / 3 / 4 chunks 176 / 119 / 143 us; ushort 2048 x 2048 x 1024 2 / 3 / 4 chunks
+// 459 / 428 / 510 us per isovalue - three it is for both; a narrower window sends rows to the lanes' own loads, a wider one
+// costs a block per CU.)
 #ifndef MC33_EV_W
-#define MC33_EV_W (sizeof(sample_t) == 8 ? 4u : sizeof(sample_t) == 4 ? 3u : 2u)
+#define MC33_EV_W (sizeof(sample_t) == 8 ? 4u : sizeof(sample_t) >= 2 ? 3u : 2u)
 #endif
 constexpr uint32_t EV_W = MC33_EV_W;
 constexpr uint32_t EV_ROWS = 65;         // sample rows 0..64 of a tile (63 cell rows, y + 2 above the last)
@@ -1708,7 +1711,7 @@ __device__ __forceinline__ BatchInfo load_batch(const BatchDesc *batches, uint32
 // waves per SIMD the LDS image allows (4 blocks of 35 KiB with 2-chunk windows, 3 of 47 KiB with 3, 2 of 60 KiB with 4): the
 // kernel may use the registers that leaves it, and no more
 #ifndef MC33_EV_WAVES
-#define MC33_EV_WAVES (MC33_SAMPLE_BYTES <= 2 ? 4 : MC33_SAMPLE_BYTES == 8 ? 2 : 3)
+#define MC33_EV_WAVES (MC33_SAMPLE_BYTES == 1 ? 4 : MC33_SAMPLE_BYTES == 8 ? 2 : 3)
 #endif
 template <int MODE>  // the vertex store (Params::store_mode): one kernel per store, see store_vertex
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAVES, MC33_EV_WAVES))) void k_emit_vertices(const EmitArgs a) {
