@@ -2114,6 +2114,7 @@ struct mc33hip_ctx {
 	uint32_t *live_list;     // [slot_base_cap]: slots with cut cells, k_slots -> k_cells
 	uint32_t cells_blocks;   // blocks of k_cells the GPU holds at once
 	uint32_t tail_serial;    // tails enqueued (seg_tagged)
+	uint32_t records_hint;   // work records of the last extraction whose counters were read (grid of the triangle pass)
 	uint32_t epoch_wrap;      // the stamps start over at this count (2^30; MC33_HIP_EPOCH_WRAP for the test that crosses it)
 	IsoLane *cur_lane;        // the lane the last count used (its epoch is what the emit pass needs)
 	bool lane_presweeped;     // ... and it had been filled by mc33hip_sweep_many
@@ -2945,7 +2946,10 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	// own copy; a caller's device buffer may have any pitch: its records then load for themselves)
 	a.stage_rows = ((uintptr_t)c->d_grid % 16u) == 0 && (c->pitch * sizeof(sample_t)) % 16u == 0 && (c->slice * sizeof(sample_t)) % 16u == 0 &&
 	               !env_u32("MC33_HIP_NO_STAGE", 0);
-	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 256u * 64u);
+	// The triangle pass is fastest with a thread per record (C5, 14.4 M records: 16 384 / 32 768 / 65 536 blocks 392 / 363 /
+	// 352 us; C3, 3.9 M: 2 048 / 4 096 / 8 192 / 16 384 blocks 106 / 98 / 93 / 88 us).  How many records this extraction has is
+	// on the device only: the grid follows the last extraction whose counters were read, 16 384 blocks at least.
+	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", std::max(256u * 64u, std::min(1u << 20, ((c->records_hint + 255u) / 256u + 7u) & ~7u)));
 	if (!c->cus) HIP_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, c->device));
 	// The three emit passes are independent (V/N vs T, fast vs slow records).  While each of them waited through a chain of
 	// dependent loads (rounds 1 and most of 2) running them side by side on three streams paid on large grids (0.15 instead
@@ -3002,6 +3006,7 @@ static int fetch_counters(mc33hip_ctx *c) {
 	if (!c->ctr_published) HIP_TRY(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
 	c->ctr_published = false;
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->records_hint = c->h_ctr->entry_cursor == 0xFFFFFFFFu ? 0u : c->h_ctr->entry_cursor;
 	if (getenv("MC33_HIP_VERBOSE"))
 		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, record batches %u)\n", c->h_ctr->entry_cursor,
 		        c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->batch_cursor);
