@@ -1648,7 +1648,9 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 // records that read it load for themselves - which is cheap exactly then, many lanes of a load sharing a row.
 // (Measured per width, round 3: float 1024^3 2 / 3 / 4 chunks 176 / 119 / 143 us; ushort 2048 x 2048 x 1024 2 / 3 / 4 chunks
 // 459 / 428 / 510 us per isovalue - three it is for both; a narrower window sends rows to the lanes' own loads, a wider one
-// costs a block per CU.)
+// costs a block per CU.  And an image of fewer ROWS - 48 / 40 / 32 from the row of the batch's first record on, rows beyond
+// it to the lanes' own loads; 4 blocks per CU instead of 3, three load groups instead of four: float 120 -> 117 / 119 / 124 us,
+// ushort 422 -> 451 / 461 / 521 us per isovalue: more resident waves do not pay for the rows that fall out.)
 #ifndef MC33_EV_W
 #define MC33_EV_W (sizeof(sample_t) == 8 ? 4u : sizeof(sample_t) >= 2 ? 3u : 2u)
 #endif
