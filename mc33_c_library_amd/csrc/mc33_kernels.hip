@@ -720,8 +720,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 				// eight processes each way, and again in round 3: 0.73 -> 0.77 - 0.81 - and keeps the raw form.  These 17 MB (1024^3, two records per tile) cost the float
 				// sweep 0.065 of its 0.73 ms - the first plane's 0.045, the last one's 0.02 - and three times what the 25 MB of the
 				// slices handed on cost; it is the two 1 KiB stores, not the header; holding the first plane's record back in registers
-				// for 1 - 8 planes by tile number, or to the tile's end, or storing it nontemporal, changes nothing (round 3,
-				// profiles/r03_sweep_parts.txt))
+				// for 1 - 8 planes by tile number, or to the tile's end, or storing it nontemporal, changes nothing - and with the
+				// slices handed on, as in every real extraction, the sweep WITHOUT edge records is no faster at all: 0.72 - 0.75 ->
+				// 0.75 - 0.78 ms; the costs of the sweep's stores do not add (round 3, profiles/r03_sweep_parts.txt))
 				uint32_t fmt = PLANE_RAW;
 				uint4 *rec = L.edge_bits + ((uint64_t)wtile * 2u + which) * 128u;
 				if constexpr (NI >= 2) fmt = store_plane_record<S>(rec, cur[q]);
