@@ -2017,10 +2017,11 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	const XcdWalk w(ctr.entry_cursor);
 	for (uint32_t e = w.first; e < w.end; e += w.stride) {
 		const uint32_t seg = c.entry_seg[e];
-		const EntryA ea = c.entries_a[e];
+		const EntryA2 pair = entry_pair(c.entries_a + (e ? e - 1u : 0u));  // the record and the one before it (the owner of two of its edges, mostly)
+		const EntryA ea = e ? pair.hi : pair.lo;
 		asm volatile("" ::"v"(seg), "v"(ea.a0));
 		const Entry en = entry_join(ea, ctx_half_b(c, ea, e));
-		if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, seg, e, ids);
+		if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, pair.lo, seg, e, ids);
 	}
 }
 
@@ -2461,7 +2462,7 @@ static int alloc_entries(mc33hip_ctx *c, uint64_t cap) {
 	c->entries_a = nullptr; c->entries_b = nullptr; c->entries_c = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr;
 	c->entry_cap = 0;
 	if (cap > 0xFFFFFF00ull) cap = 0xFFFFFF00ull;
-	HIP_TRY(hipMalloc(&c->entries_a, cap * sizeof(EntryA)));
+	HIP_TRY(hipMalloc(&c->entries_a, (cap + 2) * sizeof(EntryA)));  // (+ 2: the triangle pass reads records in pairs)
 	HIP_TRY(hipMalloc(&c->entries_b, cap * sizeof(EntryB)));  // (touched for tested and slow records only)
 	HIP_TRY(hipMalloc(&c->entries_c, cap * sizeof(EntryC)));  // (... for slow records only)
 	HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));

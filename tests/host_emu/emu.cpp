@@ -173,12 +173,15 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	memset(out->T, 0xFF, nT * 12);
 	c.V = out->V; c.N = out->N; c.Tri = out->T;
 	c.v_skip = gV; c.t_skip = gT; c.id_delta = id_base - gV;
-	for (size_t k = 0; k < ea.size(); k++) {
+	const size_t nrec = ea.size();
+	ea.push_back(EntryA{0u, 0u}); ea.push_back(EntryA{0u, 0u});  // (the triangle pass reads records in pairs: as the device's array, two more)
+	c.entries_a = ea.data();
+	for (size_t k = 0; k < nrec; k++) {
 		if (ea[k].a0 & ENTRYA_SLOW) emit_cell(c, (uint32_t)k, v, w, ids);
 		else {
 			const Entry en = load_entry(ea.data(), eb.data(), fast_b, (uint32_t)k);
 			emit_fast_vertices(c, en, entry_seg[k]);
-			emit_fast_triangles(c, en, entry_seg[k], (uint32_t)k, ids);
+			emit_fast_triangles(c, en, ea[k ? k - 1 : 0], entry_seg[k], (uint32_t)k, ids);
 		}
 	}
 	return 0;
