@@ -1280,6 +1280,12 @@ MC33_HD EntryA2 entry_pair(const EntryA *p) {
 	r.lo = p[0]; r.hi = p[1];
 	return r;
 }
+struct SegBase2 { SegBase lo, hi; };  // ... and so the bases of the row segments y - 1 and y
+MC33_HD SegBase2 seg_base_pair(const SegBase *p) {
+	SegBase2 r;
+	r.lo = p[0]; r.hi = p[1];
+	return r;
+}
 // (before: the record before this one in the array, o1 when x - 1 is wanted - the caller has it from the load of `en` itself)
 template <typename T>
 MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const EntryA &before, uint32_t s, uint32_t self_index, const URef &ids) {
@@ -1292,7 +1298,9 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const Ent
 	const bool cut7 = MC33_SIDE(4) != MC33_SIDE(7), cut11 = MC33_SIDE(3) != MC33_SIDE(7), cut8 = MC33_SIDE(0) != MC33_SIDE(4);
 #undef MC33_SIDE
 	const bool need[6] = {cut0, cut1 || cut2, cut3, cut4 || cut9, cut7 || cut11, cut8};
-	const SegBase sb = c.seg_base[s];
+	// the bases of this row segment and of the one before it (y - 1: segment B) in one load
+	const SegBase2 sp = seg_base_pair(c.seg_base + (s ? s - 1u : 0u));
+	const SegBase sb = s ? sp.hi : sp.lo;
 	Entry oe[6];
 	uint32_t ovb[6];
 	if (xl != 0) {
@@ -1304,10 +1312,13 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const Ent
 		const uint64_t gs[3] = {(uint64_t)s - (needseg[0] ? dz : 0ull), (uint64_t)s - (needseg[1] ? 1ull : 0ull), (uint64_t)s - (needseg[2] ? dz + 1ull : 0ull)};
 		DirWord sd[3];
 		uint32_t svb[3];
-		for (int g = 0; g < 3; g++) {  // round trip 1: one 16-byte directory word and the base per segment ...
-			sd[g] = dir_word(c, gs[g], xl);
-			svb[g] = c.seg_base[gs[g]].vbase;
-		}
+		for (int g = 0; g < 3; g++) sd[g] = dir_word(c, gs[g], xl);  // round trip 1: one 16-byte directory word per segment ...
+		// ... and the bases: B's came with this segment's; A's (y, z-1) and C's (y-1, z-1) are neighbours too
+		const uint64_t sa = (uint64_t)s - ((needseg[0] || needseg[2]) ? dz : 0ull);
+		const SegBase2 ap = seg_base_pair(c.seg_base + (sa ? sa - 1ull : 0ull));
+		svb[0] = sa ? ap.hi.vbase : ap.lo.vbase;
+		svb[1] = needseg[1] ? sp.lo.vbase : sb.vbase;
+		svb[2] = ap.lo.vbase;  // (looked at only when C is wanted: y >= 1 then, and sa - 1 is C)
 		EntryA oa[6];
 		uint32_t oi[6];
 		oi[1] = need[1] ? self_index - 1 : self_index;  // o1: the cell x-1 is active whenever needed ...

@@ -2480,7 +2480,7 @@ static int ensure_workspaces(mc33hip_ctx *c) {
 		HIP_TRY(hipMalloc(&c->seg_cnt, c->nsegs * 4));
 		c->tail_serial = 0;  // (the first tail clears the new array)
 		HIP_TRY(hipMalloc(&c->seg_dir, c->nsegs * sizeof(SegDir)));
-		HIP_TRY(hipMalloc(&c->seg_base, c->nsegs * sizeof(SegBase)));
+		HIP_TRY(hipMalloc(&c->seg_base, (c->nsegs + 1) * sizeof(SegBase)));  // (+ 1: the triangle pass reads bases in pairs)
 		c->seg_cap = c->nsegs;
 	}
 	const uint64_t nb = (c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK;

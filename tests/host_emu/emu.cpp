@@ -55,7 +55,7 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 	std::vector<uint32_t> seg_cnt(nsegs, 0);
 	std::vector<SegDir> seg_dir(nsegs, SegDir{});
 	std::vector<uint32_t> seg_first(nsegs, 0), seg_nent(nsegs, 0);
-	std::vector<SegBase> seg_base(nsegs);
+	std::vector<SegBase> seg_base(nsegs + 1);  // (+ 1: the triangle pass reads bases in pairs)
 	std::vector<uint64_t> seg_mask(4 * nsegs, 0ull);
 	uint32_t fast[256];
 	build_fast_table(mc33_lut, fast);
