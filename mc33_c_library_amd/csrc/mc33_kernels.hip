@@ -628,6 +628,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 		else return (real_t)((dd[rr] >> (8 * k)) & 0xFFu);
 	};
 
+	// Packed narrow samples against an isovalue without converting them (ZM 1, 2): F > iso is F > floor(iso) in integers -
+	// one compare on the halfword / byte where it sits in the loaded dword instead of a conversion and a compare (the
+	// 4-isovalue pass over ushort samples is bound by its instructions).  iso_gt: floor(iso) held to [-1, largest sample]
+	// (a NaN isovalue: nothing is greater); iso_eq: the isovalue when it is a sample value, else a word no sample equals.
+	int32_t iso_gt[NI];
+	uint32_t iso_eq[NI];
+	if constexpr (S >= 2 && ZM != 0) {
+		constexpr real_t top = S == 2 ? (real_t)65535 : (real_t)255;
+#pragma unroll
+		for (int q = 0; q < NI; q++) {
+			const real_t v = iso[q], fl = __builtin_floorf((float)v);
+			iso_gt[q] = !(v == v) ? 0x7FFFFFFF : fl < 0 ? -1 : fl >= top ? (int32_t)top : (int32_t)fl;
+			iso_eq[q] = (v == fl && fl >= 0 && fl <= top) ? (uint32_t)fl : 0xFFFFFFFFu;
+		}
+	}
+	auto raw_sample = [&](const raw_t (&dd)[16], int rr, int k) -> uint32_t {  // (S >= 2) the sample as it was loaded
+		if constexpr (S == 2) return ((uint32_t)dd[rr * 2 + (k >> 1)] >> (16 * (k & 1))) & 0xFFFFu;
+		else if constexpr (S == 4) return ((uint32_t)dd[rr] >> (8 * k)) & 0xFFu;
+		else return 0u;
+	};
 	real_t halo = 0;  // lane r: halo sample of row r of the plane being assembled
 	auto process = [&](const raw_t (&dd)[16], const real_t &hv, uint32_t p, uint32_t bi) {
 		const uint32_t r = bi * (uint32_t)RB;
@@ -650,6 +670,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 						bb ^= __ballot(d != d);  // NaN sample: the sign the reference sees is the NaN's own (see iso_diff)
 #endif
 						zmin[q] = real_min(zmin[q], real_abs(d));
+					} else if constexpr (S >= 2) {
+						const uint32_t ri = raw_sample(dd, rr, k);
+						bb = __ballot((int32_t)ri > iso_gt[q]);
+						if constexpr (ZM == 1) zeq[q] |= __ballot(ri == iso_eq[q]);
 					} else {
 						bb = __ballot(f[k] > iso[q]);                         // = the sign bit of iso - F for an integer sample
 						if constexpr (ZM == 1) zeq[q] |= __ballot(f[k] == iso[q]);

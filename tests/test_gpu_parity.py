@@ -365,6 +365,24 @@ def test_uchar_and_uint_grids(products, reflibs, seed):
         check(products, reflibs, "u32", data, iso, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0), label="u32")
 
 
+def test_integer_grids_with_isovalues_outside_the_sample_range(products, reflibs):
+    """The sweep classifies packed ushort / uchar samples by integer compares against floor(iso) held to the sample range
+    (k_sweep, iso_gt / iso_eq): isovalues below zero, above the largest sample, exactly on the range's ends, halfway between two
+    sample values, not finite - every one must give the reference's surface (mostly an empty one, or everything on one side)."""
+    inf = float("inf")
+    rows = 256 + 40  # (a packed row: the sweep loads dwords)
+    u16 = fx.noise_u16(0, 5, shape=(9, 20, rows))
+    u16.reshape(-1)[::97] = 65535
+    u16.reshape(-1)[::89] = 0
+    for iso in (-5.0, -1.0, -0.5, 0.0, 0.5, 65534.5, 65535.0, 65535.5, 70000.0, 1e30, -1e30, inf, -inf, float("nan")):
+        check(products, reflibs, "u16", u16, iso, label="u16 iso %r" % iso)
+    u8 = fx.noise_u8(0, 6, shape=(7, 18, rows))
+    u8.reshape(-1)[::53] = 255
+    u8.reshape(-1)[::47] = 0
+    for iso in (-3.0, -0.5, 0.0, 0.5, 254.5, 255.0, 255.5, 300.0, inf, -inf, float("nan")):
+        check(products, reflibs, "u8", u8, iso, label="u8 iso %r" % iso)
+
+
 @pytest.mark.parametrize("seed", [1, 3])
 def test_double_grids(products, reflibs, seed):
     """GRD_TYPE_SIZE 8 library (reference marching_cubes_33.h:80-82): double samples, double tests / interpolation /
