@@ -273,7 +273,8 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True):
     state = {"step": 0, "counts": None, "b": 0}
 
     def step(record):
-        """all isovalues of the config once; returns (nV, nT) summed over the isovalues, this rank"""
+        """all isovalues of the config once; returns (nV, nT) summed over the isovalues, this rank.  record: 0 warm-up, 1 the
+        timed steps (host clock per step kept), 2 the steps with the library's events on (kernel split kept)"""
         nV = nT = 0
         t0 = time.perf_counter()
         if sweep_many:  # iso sweep: the volume is streamed once per 4 isovalues, the calls below find their sweep made
@@ -282,7 +283,7 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True):
             if not multi:
                 c, ok = grid.extract_into(iso, V, N, T, slab.range())
                 assert ok
-                if record:
+                if record == 2:
                     t = grid.timing()
                     sweep_ms.append(t.sweep_ms); scan_ms.append(t.scan_ms); emit_ms.append(t.emit_ms)
             else:
@@ -293,11 +294,11 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True):
                 state["step"] += 1
                 counts, c = extract_slab(grid, slab, ex, iso, b, async_op=overlap)
                 state["counts"], state["b"] = counts, b
-                if record:
+                if record == 2:
                     t = grid.timing()
                     sweep_ms.append(t.sweep_ms); scan_ms.append(t.scan_ms)
             nV += c.nV; nT += c.nT
-        if record:
+        if record == 1:
             step_ms.append((time.perf_counter() - t0) * 1e3)
         return nV, nT
 
@@ -317,18 +318,16 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True):
             dist.barrier()
         return time.perf_counter() - t0, last
 
-    # The timed region: the library's per-pass hipEvents are RECORDED on the stream (timing level 2: nobody waits for them,
-    # not even the passes of the iso sweep any more) - they are what `roofline` is computed from, live, over these very steps.
+    # The timed region = K steps of the library as a caller gets it: no event in the stream (MC33_HIP_TIMING=0, the library's
+    # default) - `value` and `ms_per_step` are these steps.  Then the same K steps once more with the library's per-pass
+    # hipEvents RECORDED on the stream (timing level 2: nobody waits for them): the kernel split and `roofline` are computed
+    # from those, live, and their step time is reported beside (`with_event_records`: 1 - 2 % slower).
     for _ in range(warmup):
-        step(False)
-    dt, last = timed(steps, True)
-    # ... and the same K steps once more with no event at all in the library (MC33_HIP_TIMING=0, the production setting):
-    # informational, `value` stays the line with the events in it
-    dt_plain = None
-    if not multi:
-        grid.set_timing(0)
-        dt_plain, _ = timed(steps, False)
-        grid.set_timing(2)
+        step(0)
+    grid.set_timing(0)
+    dt, last = timed(steps, 1)
+    grid.set_timing(2)
+    dt_events, _ = timed(steps, 2)
 
     if multi and (os.environ.get("MC33_BENCH_VERIFY", "0") == "1" or os.environ.get("MC33_BENCH_DUMP")):
         # the exchanged surface of the LAST isovalue (checked before anything below reuses the buffers): concatenation in
@@ -465,11 +464,10 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True):
                           "parallelism": "z-slab x%d" % world if multi else "single GPU"},
                "mtris_per_s": nT_all / (dt / steps) / 1e6,
                "ms_per_isovalue": ms_step / nis,
-               "timed_region": "per-pass hipEvents recorded on the stream (none waited for)",
+               "timed_region": "K steps with the library's default settings (no event records); roofline / kernel_ms from the same K steps run again with per-pass hipEvents recorded on the stream (none waited for)",
                "roofline": roof}
-        if dt_plain is not None:
-            res["without_event_records"] = {"ms_per_step": dt_plain / steps * 1e3, "value": cells_all * nis / (dt_plain / steps) / 1e6,
-                                            "note": "the same %d steps again with MC33_HIP_TIMING=0 (the library's default)" % steps}
+        res["with_event_records"] = {"ms_per_step": dt_events / steps * 1e3, "value": cells_all * nis / (dt_events / steps) / 1e6,
+                                     "note": "the same %d steps again with MC33_HIP_TIMING=2 (what roofline / kernel_ms were measured in)" % steps}
         if multi:
             res["gather"] = {"mode": args.gather, "overlapped_with_next_extraction": bool(overlap), "alone": gather_info,
                              "xgmi_inbound_peak_GBps": 76.8 * (world - 1),
@@ -558,7 +556,7 @@ def main():
         r = c5["roofline"]
         res["c5"] = {"workload": c5["config"]["workload"], "value": c5["value"], "unit": c5["unit"], "steps": c5["steps"], "ms_per_step": c5["ms_per_step"],
                      "ms_per_isovalue": c5["ms_per_isovalue"], "vertices": c5["config"]["vertices"], "triangles": c5["config"]["triangles"],
-                     "mtris_per_s": c5["mtris_per_s"], "dtype": c5["dtype"], "without_event_records": c5.get("without_event_records"),
+                     "mtris_per_s": c5["mtris_per_s"], "dtype": c5["dtype"], "with_event_records": c5.get("with_event_records"),
                      "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "isovalues_per_launch",
                                                    "launch_ms", "kernel_ms", "step_bytes_moved", "step_device_ms", "step_frac", "whole_call_reference_equivalent")},
                      "cpu_baseline": c5.get("cpu_baseline"), "vs_cpu_baseline": c5.get("vs_cpu_baseline")}

@@ -136,7 +136,7 @@ def test_bench_single_gpu_lines(launcher):
         assert res["config"]["name"] == name and res["n_gpus"] == 1 and res["vs_baseline"] is None
         assert res["roofline"]["bound"] == "hbm" and res["roofline"]["frac"] > 0 and res["roofline"]["traffic"] is None
         assert res["cpu_baseline"]["kind"] == "reference" and res["cpu_baseline"]["cores"] == 1 and res["cpu_baseline"]["value"] > 0
-        assert res["without_event_records"]["ms_per_step"] > 0 and res["roofline"]["step_bytes_moved"] > res["roofline"]["algorithmic_bytes_per_launch"]
+        assert res["with_event_records"]["ms_per_step"] > 0 and res["roofline"]["step_bytes_moved"] > res["roofline"]["algorithmic_bytes_per_launch"]
         if name == "c3":  # the configs[4] workload rides on the default line as a compact object
             c5 = res["c5"]
             assert c5["dtype"] == "u16" and c5["value"] > 0 and c5["roofline"]["isovalues_per_launch"] == 4 and c5["roofline"]["frac"] > 0
