@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -172,6 +173,11 @@ struct SweepLane {
 	uint4 *edge_hdr;         // ... their halo-column bits and "a sample equals the isovalue" flag
 	uint32_t epoch;          // number of this extraction (stamped into the slice headers)
 	real_t iso;
+	// the isovalue as integers, for packed narrow samples classified without a conversion (k_sweep, ZM 1 / 2; sweep_iso_words):
+	// wave-uniform, so they belong in SGPRs - computed on the host, they arrive there with the kernel arguments (computed in
+	// the kernel they sat in 8 VGPRs of a form that has none to spare, and spilled: round 3)
+	int32_t iso_gt;          // F > iso  <=>  (int)F > iso_gt: floor(iso) held to [-1, largest sample]; nothing is greater than a NaN
+	uint32_t iso_eq;         // the isovalue when it is a sample value, else a word no sample equals
 };
 
 struct SweepArgs {
@@ -392,25 +398,62 @@ __device__ __forceinline__ bool encode_plane(const uint64_t (&w)[4], uint32_t &d
 	desc = (uint32_t)(w[0] & 1ull) | n << 1 | p1 << 8 | p2 << 16;
 	return true;
 }
+// Stores of the sweep's hand-over go through buffer descriptors: the record's address is wave-uniform (SGPRs), the lanes
+// differ by 4 or 16 bytes - one 32-bit offset register for every store of the kernel.  As plain global stores each of them
+// had a 64-bit per-lane address, the loop-invariant ones (the edge records of the tile, per isovalue and form) were hoisted
+// out of the plane loop, and the 4-isovalue forms - which sit at the register limit of 3 waves per SIMD - spilled them:
+// 176 - 192 bytes of scratch per lane in k_sweep<2,4,*> (round 3's VERDICT; tests/test_code_objects.py now checks).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// A loop over 0 .. N-1 whose index is a compile-time constant in the body: `#pragma unroll` is a request the compiler turns
+// down when the body is large (k_sweep<4,4,*>: the plane work of four isovalues over packed uchar samples - its per-isovalue
+// arrays were then indexed at run time and lived in 320 - 736 bytes of scratch memory per lane, rounds 2 - 3).
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+	if constexpr (N > 0) {
+		static_for<N - 1>(f);
+		f(std::integral_constant<int, N - 1>{});
+	}
+}
+// ... only where FORCE says so; otherwise the ordinary unrolled loop (which the optimizer sees rolled first: the forms that
+// fitted their registers that way keep it - the double-precision sweep over four isovalues spilled 16 registers when forced)
+template <int N, bool FORCE, typename F>
+__device__ __forceinline__ void unrolled_for(F &&f) {
+	if constexpr (FORCE) static_for<N>(f);
+	else {
+#pragma unroll
+		for (int i = 0; i < N; i++) f(i);
+	}
+}
+// The lane's number, computed where it is asked for.  Everything derived from `threadIdx.x & 63` is loop-invariant, and the
+// compiler keeps every such value (lane * 4, lane * 16, LDS addresses) in a register of its own across the sweep's whole loop
+// for the one use per plane; the 4-isovalue form has no registers for that.  (All lanes enabled where this is called.)
+__device__ __forceinline__ uint32_t fresh_lane() {
+	uint32_t l;
+	asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+	return l;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t record_rsrc(const void *base, uint32_t bytes) {
+	return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
 // writes the record at `rec` (2 KiB reserved) in the form that fits; returns the form
 template <int S>
-__device__ __forceinline__ uint32_t store_plane_record(uint4 *rec, const uint64_t (&w)[4]) {
-	const uint32_t lane = threadIdx.x & 63u;
+__device__ __forceinline__ uint32_t store_plane_record(uint4 *rec, const uint64_t (&w)[4], uint32_t lane) {
+	const __amdgpu_buffer_rsrc_t rs = record_rsrc(rec, 2048u);
 	uint32_t desc;
 	if (encode_plane<S>(w, desc)) {
-		((uint32_t *)rec)[lane] = desc;
+		__builtin_amdgcn_raw_buffer_store_b32(desc, rs, lane * 4u, 0u, 0);
 		return PLANE_COMPACT;
 	}
 	uint64_t o[4];
 	to_standard<S>(w, o);
-	rec[lane] = uint4{(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)};
-	rec[64 + lane] = uint4{(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)};
+	__builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)}, rs, lane * 16u, 0u, 0);
+	__builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)}, rs, lane * 16u, 1024u, 0);
 	return PLANE_RAW;
 }
 template <int S>
-__device__ __forceinline__ void store_plane(const SweepLane &a, uint64_t plane_slot, const uint64_t (&w)[4]) {
-	const uint32_t fmt = store_plane_record<S>(a.slice_bits + plane_slot * 128u, w);
-	if ((threadIdx.x & 63u) == 0) a.plane_fmt[plane_slot] = (uint8_t)fmt;
+__device__ __forceinline__ void store_plane(const SweepLane &a, uint64_t plane_slot, const uint64_t (&w)[4], uint32_t lane) {
+	const uint32_t fmt = store_plane_record<S>(a.slice_bits + plane_slot * 128u, w, lane);
+	if (lane == 0) a.plane_fmt[plane_slot] = (uint8_t)fmt;
 }
 
 // (slot: of the slice; slot_up: of the slice above = the slot of the upper plane; write_prev / write_cur: the
@@ -418,13 +461,12 @@ __device__ __forceinline__ void store_plane(const SweepLane &a, uint64_t plane_s
 template <int S>
 __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slot, uint64_t slot_up, const uint64_t (&prev)[4],
                                                 const uint64_t (&cur)[4], bool write_prev, bool write_cur, uint64_t bp, uint64_t bc,
-                                                uint64_t zrows, uint64_t zcols, const uint64_t (&act)[4], uint32_t dev = 0) {
-	const uint32_t lane = threadIdx.x & 63u;
+                                                uint64_t zrows, uint64_t zcols, const uint64_t (&act)[4], uint32_t lane, uint32_t dev = 0) {
 #ifdef MC33_DEV  // MC33_HIP_DEBUG 32: no bit-plane stores, no header; 128: the bit-plane stores alone (the later passes see nothing)
 	if (dev & 32u) { write_prev = write_cur = false; }
 #endif
-	if (write_prev) store_plane<S>(a, slot, prev);  // (prev, cur: layout S)
-	if (write_cur) store_plane<S>(a, slot_up, cur);
+	if (write_prev) store_plane<S>(a, slot, prev, lane);  // (prev, cur: layout S)
+	if (write_cur) store_plane<S>(a, slot_up, cur, lane);
 #ifdef MC33_DEV
 	if (dev & (32u | 128u)) return;
 #endif
@@ -434,13 +476,13 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 	for (int dlt = 32; dlt; dlt >>= 1) ncell += __shfl_xor(ncell, dlt);
 	const uint32_t nbatch = (ncell + 63u) >> 6;  // the records of a slice are handed to the emit passes 64 at a time (BatchDesc)
 	if (lane == 0) {
-		SliceHeader h;
-		h.flags = a.epoch << 2 | SLICE_VALID | (zrows ? SLICE_HAS_ISO : 0u);
-		h.prevh_lo = (uint32_t)bp; h.prevh_hi = (uint32_t)(bp >> 32);
-		h.curh_lo = (uint32_t)bc; h.curh_hi = (uint32_t)(bc >> 32);
-		h.cells = ncell; h.zr_lo = (uint32_t)zrows; h.zr_hi = (uint32_t)(zrows >> 32);
-		h.zc_lo = (uint32_t)zcols; h.zc_hi = (uint32_t)(zcols >> 32); h.pad_[0] = h.pad_[1] = 0;
-		a.slice_hdr[slot] = h;
+		// (word by word, the padding left alone: as a struct copy the two zero words of the padding were a 64-bit zero that the
+		// 4-isovalue sweep kept in a register pair across its whole loop - and spilled)
+		uint32_t *h = (uint32_t *)(a.slice_hdr + slot);
+		static_assert(offsetof(SliceHeader, zc_hi) == 36, "SliceHeader words");
+		*(uint4 *)h = uint4{a.epoch << 2 | SLICE_VALID | (zrows ? SLICE_HAS_ISO : 0u), (uint32_t)bp, (uint32_t)(bp >> 32), (uint32_t)bc};
+		*(uint4 *)(h + 4) = uint4{(uint32_t)(bc >> 32), ncell, (uint32_t)zrows, (uint32_t)(zrows >> 32)};
+		*(uint2 *)(h + 8) = uint2{(uint32_t)zcols, (uint32_t)(zcols >> 32)};
 		atomicAdd(a.slot_part + slot / SLOT_CHUNK, (unsigned long long)nbatch << 32 | ncell);
 	}
 }
@@ -515,7 +557,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 		}
 	}
 	__shared__ uint64_t s_mail[2][4][NI][2];  // [plane parity][wave][isovalue]{column-0 bits of the rows, rows whose column-0 sample may equal the isovalue}
-	const bool from_right = grouped && (threadIdx.x >> 6) < 3u;  // this wave's halo bits come from the wave to its right
+	const bool from_right = grouped && (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) < 3u;  // this wave's halo bits come from the wave to its right
 	const unsigned long long t_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	const unsigned long long c_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
 	const uint32_t xbase = seg * SEG_CELLS, y0 = yt * 63u;
@@ -550,15 +592,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	constexpr bool PREV_LDS = NI >= 4;
 	__shared__ uint64_t s_prev[PREV_LDS ? NI : 1][4][PREV_LDS ? 256 : 1];
 	__shared__ uint64_t s_prevz[PREV_LDS ? NI : 1][2][4];  // ... and its 'sample equals the isovalue' row / lane masks, per wave
-	const uint32_t wv = threadIdx.x >> 6;
+	__shared__ uint32_t s_prevh[PREV_LDS ? NI : 1][PREV_LDS ? 256 : 1];  // ... and its halo-column bits
+	const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	uint64_t cur[NI][4], prev[PREV_LDS ? 1 : NI][4];
 	uint32_t c_lo[NI][4], c_hi[NI][4];
-	uint32_t cur_h[NI], prev_h[NI];
+	uint32_t cur_h[NI], prev_h[PREV_LDS ? 1 : NI];
 	uint64_t cur_zc[NI], prev_zc[PREV_LDS ? 1 : NI], zcacc[NI];  // ... and the lanes that loaded one
 	uint64_t cur_z[NI], prev_z[PREV_LDS ? 1 : NI], zacc[NI];  // sample rows of the plane that hold a sample equal to the isovalue (wave-uniform),
 	                                           // to the batch of RB rows: one compare per batch, not per row
-	real_t zmin[NI];  // min |iso - F| over the lane's samples of the batch being processed (ZM = 0)
-	uint64_t zeq[NI]; // lanes that loaded a sample equal to the isovalue in the batch being processed (ZM = 1; wave-uniform)
+	constexpr bool ZMIN_REG = !(sizeof(real_t) == 8 && NI >= 4);
+	real_t zmin[NI];  // min |iso - F| over the lane's samples of the batch being processed (ZM = 0, ZMIN_REG)
+	uint64_t zeq[NI]; // lanes that loaded a sample equal to the isovalue in the batch being processed (ZM = 1, or ZM = 0 without ZMIN_REG; wave-uniform)
 	bool cur_written[NI], prev_written[NI];  // the plane's bit rows are already in slice_bits
 	real_t iso[NI];
 #pragma unroll
@@ -568,8 +612,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 			if constexpr (PREV_LDS) s_prev[q][k][threadIdx.x] = 0; else prev[q][k] = 0;
 			c_lo[q][k] = c_hi[q][k] = 0;
 		}
-		cur_h[q] = prev_h[q] = 0; cur_z[q] = zacc[q] = 0; cur_zc[q] = zcacc[q] = 0;
-		if constexpr (PREV_LDS) { s_prevz[q][0][wv] = 0; s_prevz[q][1][wv] = 0; } else { prev_z[q] = 0; prev_zc[q] = 0; }
+		cur_h[q] = 0; cur_z[q] = zacc[q] = 0; cur_zc[q] = zcacc[q] = 0;
+		if constexpr (PREV_LDS) { s_prevz[q][0][wv] = 0; s_prevz[q][1][wv] = 0; s_prevh[q][threadIdx.x] = 0; } else { prev_z[q] = 0; prev_zc[q] = 0; prev_h[q] = 0; }
 		cur_written[q] = prev_written[q] = false; zmin[q] = 1; zeq[q] = 0;
 		iso[q] = a.lane[q].iso;
 	}
@@ -605,7 +649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	typedef typename std::conditional<S == 1, real_t, uint32_t>::type raw_t;  // what a load leaves in a register
 	// every batch is exactly 17 loads, whatever the position in the tile (the wait counts the compiler
 	// derives are then exact and the prefetched batch really stays in flight)
-	auto issue = [&](raw_t (&d)[16], real_t &hv, uint32_t p, uint32_t bi) {
+	auto issue = [&](raw_t (&d)[16], real_t &hv, uint32_t p, uint32_t bi) __attribute__((always_inline)) {
 		const sample_t *base = a.G.p + (uint64_t)(p - a.G.z0) * a.G.slice + (uint64_t)y0 * a.G.pitch;
 		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, tile_bytes, 0x00020000);
 		const uint32_t r = bi * (uint32_t)RB;
@@ -630,35 +674,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 
 	// Packed narrow samples against an isovalue without converting them (ZM 1, 2): F > iso is F > floor(iso) in integers -
 	// one compare on the halfword / byte where it sits in the loaded dword instead of a conversion and a compare (the
-	// 4-isovalue pass over ushort samples is bound by its instructions).  iso_gt: floor(iso) held to [-1, largest sample]
-	// (a NaN isovalue: nothing is greater); iso_eq: the isovalue when it is a sample value, else a word no sample equals.
-	int32_t iso_gt[NI];
-	uint32_t iso_eq[NI];
-	if constexpr (S >= 2 && ZM != 0) {
-		constexpr real_t top = S == 2 ? (real_t)65535 : (real_t)255;
-#pragma unroll
-		for (int q = 0; q < NI; q++) {
-			const real_t v = iso[q], fl = __builtin_floorf((float)v);
-			iso_gt[q] = !(v == v) ? 0x7FFFFFFF : fl < 0 ? -1 : fl >= top ? (int32_t)top : (int32_t)fl;
-			iso_eq[q] = (v == fl && fl >= 0 && fl <= top) ? (uint32_t)fl : 0xFFFFFFFFu;
-		}
-	}
+	// 4-isovalue pass over ushort samples is bound by its instructions).
+	// (the integer words come with the kernel arguments: SweepLane::iso_gt / iso_eq)
 	auto raw_sample = [&](const raw_t (&dd)[16], int rr, int k) -> uint32_t {  // (S >= 2) the sample as it was loaded
 		if constexpr (S == 2) return ((uint32_t)dd[rr * 2 + (k >> 1)] >> (16 * (k & 1))) & 0xFFFFu;
 		else if constexpr (S == 4) return ((uint32_t)dd[rr] >> (8 * k)) & 0xFFu;
 		else return 0u;
 	};
 	real_t halo = 0;  // lane r: halo sample of row r of the plane being assembled
-	auto process = [&](const raw_t (&dd)[16], const real_t &hv, uint32_t p, uint32_t bi) {
+	// (always_inline: the body is called twice, and in the largest forms - packed uchar samples, four isovalues, equality tests - the
+	// compiler made a real FUNCTION of it, every captured array behind a pointer into 1.5 KiB of scratch memory per lane)
+	auto process = [&](const raw_t (&dd)[16], const real_t &hv, uint32_t p, uint32_t bi) __attribute__((always_inline)) {
 		const uint32_t r = bi * (uint32_t)RB;
 		halo = (lane / (uint32_t)RB) == bi ? hv : halo;
-#pragma unroll
-		for (int rr = 0; rr < RB; rr++) {
+		unrolled_for<RB, (S >= 4)>([&](auto rc) __attribute__((always_inline)) {
+			const int rr = rc;
 			real_t f[4];
 #pragma unroll
 			for (int k = 0; k < 4; k++) f[k] = sample(dd, rr, k);
-#pragma unroll
-			for (int q = 0; q < NI; q++) {
+			static_for<NI>([&](auto qc) __attribute__((always_inline)) {
+				constexpr int q = decltype(qc)::value;
 				uint32_t m[8];
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
@@ -669,11 +704,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 #ifdef MC33_NAN_SAMPLES
 						bb ^= __ballot(d != d);  // NaN sample: the sign the reference sees is the NaN's own (see iso_diff)
 #endif
-						zmin[q] = real_min(zmin[q], real_abs(d));
+						// "equals the isovalue": a running minimum of |d| per lane, looked at once per batch (one instruction per sample) -
+						// except in the double-precision pass over four isovalues, which has no four register pairs for it: a compare
+						// per sample there, gathered in SGPRs
+						if constexpr (ZMIN_REG) zmin[q] = real_min(zmin[q], real_abs(d));
+						else zeq[q] |= __ballot(d == 0);
 					} else if constexpr (S >= 2) {
 						const uint32_t ri = raw_sample(dd, rr, k);
-						bb = __ballot((int32_t)ri > iso_gt[q]);
-						if constexpr (ZM == 1) zeq[q] |= __ballot(ri == iso_eq[q]);
+						bb = __ballot((int32_t)ri > a.lane[q].iso_gt);
+						if constexpr (ZM == 1) zeq[q] |= __ballot(ri == a.lane[q].iso_eq);
 					} else {
 						bb = __ballot(f[k] > iso[q]);                         // = the sign bit of iso - F for an integer sample
 						if constexpr (ZM == 1) zeq[q] |= __ballot(f[k] == iso[q]);
@@ -682,47 +721,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 				}
 				// park the bit row of sample row r+rr in lane r+rr: v_writelane takes its lane select from M0
 				// when the data operand is an SGPR too (one SGPR per VOP3 on gfx9-class encodings)
+				// (references and the row number named here: operands of an asm statement do not capture by themselves inside a generic lambda;
+				// the row number through readfirstlane - uniform anyway, but short of SGPRs the compiler moved the batch counter into
+				// a vector register and handed THAT to the "s" operand)
+				uint32_t &l0 = c_lo[q][0], &h0 = c_hi[q][0], &l1 = c_lo[q][1], &h1 = c_hi[q][1], &l2 = c_lo[q][2], &h2 = c_hi[q][2], &l3 = c_lo[q][3], &h3 = c_hi[q][3];
+				const uint32_t rowsel = (uint32_t)__builtin_amdgcn_readfirstlane((int)(r + (uint32_t)rr));
 				asm volatile(
 				    "s_mov_b32 m0, %16\n\t"
 				    "v_writelane_b32 %0, %8, m0\n\tv_writelane_b32 %1, %9, m0\n\t"
 				    "v_writelane_b32 %2, %10, m0\n\tv_writelane_b32 %3, %11, m0\n\t"
 				    "v_writelane_b32 %4, %12, m0\n\tv_writelane_b32 %5, %13, m0\n\t"
 				    "v_writelane_b32 %6, %14, m0\n\tv_writelane_b32 %7, %15, m0"
-				    : "+v"(c_lo[q][0]), "+v"(c_hi[q][0]), "+v"(c_lo[q][1]), "+v"(c_hi[q][1]), "+v"(c_lo[q][2]), "+v"(c_hi[q][2]), "+v"(c_lo[q][3]), "+v"(c_hi[q][3])
-				    : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), "s"(r + rr)
+				    : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2), "+v"(l3), "+v"(h3)
+				    : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), "s"(rowsel)
 				    : "m0");
-			}
-		}
-#pragma unroll
-		for (int q = 0; q < NI; q++) {  // a sample of these RB rows equals the isovalue: mark the rows
-			if constexpr (ZM == 2) continue;
-			const uint64_t zb = ZM == 0 ? __ballot(zmin[q] == 0) : zeq[q];
-			if (zb) { zacc[q] |= ((1ull << RB) - 1ull) << r; zcacc[q] |= zb; }
-			zmin[q] = 1; zeq[q] = 0;
-		}
+			});
+		});
+		if constexpr (ZM != 2)
+			static_for<NI>([&](auto qc) __attribute__((always_inline)) {  // a sample of these RB rows equals the isovalue: mark the rows
+				constexpr int q = decltype(qc)::value;
+				const uint64_t zb = (ZM == 0 && ZMIN_REG) ? __ballot(zmin[q] == 0) : zeq[q];
+				if (zb) { zacc[q] |= ((1ull << RB) - 1ull) << r; zcacc[q] |= zb; }
+				zmin[q] = 1; zeq[q] = 0;
+			});
 		if (bi != NB - 1) return;
 		// ---- the plane is complete ----
+		// (the forms over several isovalues sit at their register limit: the lane's number is computed afresh here - fresh_lane)
+		const uint32_t lp = NI >= 2 ? fresh_lane() : lane;
+		const uint32_t tid = NI >= 2 ? wv * 64u + lp : threadIdx.x;
 		const uint32_t par = (p - pl0) & 1u;
 		if (grouped) {  // (block-uniform) column 0 of this plane for the wave to the left; the right neighbour's for this wave
-#pragma unroll
-			for (int q = 0; q < NI; q++) {
+			static_for<NI>([&](auto qc) __attribute__((always_inline)) {
+				constexpr int q = decltype(qc)::value;
 				const uint64_t hb = __ballot((c_lo[q][0] & 1u) != 0u);  // (word 0 bit 0 is the segment's first sample in every layout S)
-				if (lane == 0) {
+				if (lp == 0) {
 					s_mail[par][wv][q][0] = hb;
 					s_mail[par][wv][q][1] = (ZM != 2 && (zcacc[q] & 1ull)) ? zacc[q] : 0ull;  // (lane 0 loaded column 0; rows to the batch: a superset is fine)
 				}
-			}
+			});
 			// (not __syncthreads(): that also waits for the prefetched batch's loads - only the mailbox's LDS writes must have landed)
 			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 		}
-#pragma unroll
-		for (int q = 0; q < NI; q++) {
+		static_for<NI>([&](auto qc) __attribute__((always_inline)) {
+			constexpr int q = decltype(qc)::value;
 			const SweepLane &L = a.lane[q];
 #pragma unroll
 			for (int k = 0; k < 4; k++) { cur[q][k] = u64(c_lo[q][k], c_hi[q][k]); c_lo[q][k] = c_hi[q][k] = 0; }
 			if (from_right) {  // (wave-uniform; the mailbox word is read here, per isovalue: held over the loop it cost the 4-isovalue form registers it does not have)
 				const uint64_t nb_bits = s_mail[par][wv + 1u][q][0], nb_zero = ZM != 2 ? s_mail[par][wv + 1u][q][1] : 0ull;
-				cur_h[q] = (uint32_t)((nb_bits >> lane) & 1ull);
+				cur_h[q] = (uint32_t)((nb_bits >> lp) & 1ull);
 				const uint64_t zh = nb_zero & (nrows >= 64u ? ~0ull : ((1ull << nrows) - 1ull));
 				cur_z[q] = zacc[q] | zh;
 				cur_zc[q] = zh ? ~0ull : zcacc[q];
@@ -733,12 +780,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 #ifdef MC33_NAN_SAMPLES
 				cur_h[q] ^= (uint32_t)(dh != dh);
 #endif
-				const uint64_t zh = __ballot(lane < nrows && dh == 0);  // (lanes past the tile never loaded a halo sample)
+				const uint64_t zh = __ballot(lp < nrows && dh == 0);  // (lanes past the tile never loaded a halo sample)
 				cur_z[q] = zacc[q] | zh;
 				cur_zc[q] = zh ? ~0ull : zcacc[q];  // (a halo sample: any column)
 				zacc[q] = zcacc[q] = 0;
 			}
-			auto leave_edge = [&](uint32_t which) {  // bit rows of this plane for k_boundary (a plane record like those of slice_bits)
+			auto leave_edge = [&](uint32_t which) __attribute__((always_inline)) {  // bit rows of this plane for k_boundary (a plane record like those of slice_bits)
 				// (in compact form where it fits only in the passes over several isovalues, which are bound by what they write:
 				// 2.26 -> 2.19 ms per 4-isovalue pass at C5; the single-isovalue pass lost with it - 0.789 -> 0.818 ms at C3,
 				// eight processes each way, and again in round 3: 0.73 -> 0.77 - 0.81 - and keeps the raw form.  These 17 MB (1024^3, two records per tile) cost the float
@@ -749,15 +796,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 				// 0.75 - 0.78 ms; the costs of the sweep's stores do not add (round 3, profiles/r03_sweep_parts.txt))
 				uint32_t fmt = PLANE_RAW;
 				uint4 *rec = L.edge_bits + ((uint64_t)wtile * 2u + which) * 128u;
-				if constexpr (NI >= 2) fmt = store_plane_record<S>(rec, cur[q]);
+				if constexpr (NI >= 2) fmt = store_plane_record<S>(rec, cur[q], lp);
 				else if (!(MC33_DEBUG_BITS(a) & 8192u)) {  // (developer builds: 8192 no record, 4096 no header)
 					uint64_t o[4];
 					to_standard<S>(cur[q], o);
-					rec[lane] = uint4{(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)};
-					rec[64 + lane] = uint4{(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)};
+					const __amdgpu_buffer_rsrc_t rs = record_rsrc(rec, 2048u);
+					__builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)}, rs, lp * 16u, 0u, 0);
+					__builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)}, rs, lp * 16u, 1024u, 0);
 				}
 				const uint64_t bh = __ballot(cur_h[q] != 0);
-				if (lane == 0 && !(MC33_DEBUG_BITS(a) & 4096u)) {
+				if (lp == 0 && !(MC33_DEBUG_BITS(a) & 4096u)) {
 					L.edge_hdr[((uint64_t)wtile * 2u + which) * 2u] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), (uint32_t)cur_z[q], (uint32_t)(cur_z[q] >> 32)};
 					L.edge_hdr[((uint64_t)wtile * 2u + which) * 2u + 1u] = uint4{(uint32_t)cur_zc[q], (uint32_t)(cur_zc[q] >> 32), fmt, 0u};
 				}
@@ -770,14 +818,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 					uint64_t act[4], pq[4];
 #pragma unroll
 					for (int k = 0; k < 4; k++) {
-						if constexpr (PREV_LDS) pq[k] = s_prev[q][k][threadIdx.x]; else pq[k] = prev[q][k];
+						if constexpr (PREV_LDS) pq[k] = s_prev[q][k][tid]; else pq[k] = prev[q][k];
 					}
-					active_cells<S>(pq, cur[q], prev_h[q], cur_h[q], valid, rowvalid, act);
+					uint32_t ph;
+					if constexpr (PREV_LDS) ph = s_prevh[q][tid]; else ph = prev_h[q];
+					active_cells<S>(pq, cur[q], ph, cur_h[q], valid, rowvalid, act);
 					if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull) && !(MC33_DEBUG_BITS(a) & 16u)) {  // wave-uniform: hand the slice to k_cells
 						uint64_t pz, pzc;
-						if constexpr (PREV_LDS) { pz = s_prevz[q][0][wv]; pzc = s_prevz[q][1][wv]; } else { pz = prev_z[q]; pzc = prev_zc[q]; }
+						if constexpr (PREV_LDS) { pz = readlane64(s_prevz[q][0][wv], 0); pzc = readlane64(s_prevz[q][1][wv], 0); }  // (wave-uniform: into SGPRs, not four registers held from an early LDS read to the header's store)
+						else { pz = prev_z[q]; pzc = prev_zc[q]; }
 						hand_over_slice<S>(L, slice_slot(p - 1 - P.zs, yt, seg, a.sd), slice_slot(p - P.zs, yt, seg, a.sd), pq, cur[q],
-						                   !prev_written[q], true, __ballot(prev_h[q] != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act,
+						                   !prev_written[q], true, __ballot(ph != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act, lp,
 						                   MC33_DEBUG_BITS(a));
 						cur_written[q] = true;
 					}
@@ -786,13 +837,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 			}
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
-				if constexpr (PREV_LDS) s_prev[q][k][threadIdx.x] = cur[q][k]; else prev[q][k] = cur[q][k];
+				if constexpr (PREV_LDS) s_prev[q][k][tid] = cur[q][k]; else prev[q][k] = cur[q][k];
 			}
-			prev_h[q] = cur_h[q];
+			if constexpr (PREV_LDS) s_prevh[q][tid] = cur_h[q]; else prev_h[q] = cur_h[q];
 			if constexpr (PREV_LDS) { s_prevz[q][0][wv] = cur_z[q]; s_prevz[q][1][wv] = cur_zc[q]; } else { prev_z[q] = cur_z[q]; prev_zc[q] = cur_zc[q]; }
 			prev_written[q] = cur_written[q];
 			cur_written[q] = false;
-		}
+			// (one isovalue's plane work at a time: interleaved by the scheduler, the four of them need more registers than 3 waves per SIMD leave)
+			if constexpr (NI >= 2) __builtin_amdgcn_sched_barrier(0);
+		});
 	};
 
 	raw_t dA[16], dB[16];
@@ -855,7 +908,7 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 	if (__ballot((act[0] | act[1] | act[2] | act[3]) != 0ull))
 		// (the two tiles may have written these planes for slices of their own: same bytes again)
 		hand_over_slice<1>(L, slice_slot(b.z - P.zs, b.yt, seg, a.sd), slice_slot(b.z + 1u - P.zs, b.yt, seg, a.sd), prev, cur,
-		                true, true, bp, bc, u64(hp.z, hp.w) | u64(hc.z, hc.w), u64(zp.x, zp.y) | u64(zc.x, zc.y), act);
+		                true, true, bp, bc, u64(hp.z, hp.w) | u64(hc.z, hc.w), u64(zp.x, zp.y) | u64(zc.x, zc.y), act, lane);
 }
 
 // Lists of the slow cells and of the row segments they make "dirty".  k_cells appends to them; ONE cursor for the whole
@@ -2105,6 +2158,7 @@ struct IsoLane {
 	bool tail_pending;        // a sweep has added this lane's slices into slot_part and no tail (k_slots) has consumed them yet
 	double iso;
 	mc33hip_range range;
+	uint32_t pack;            // samples per lane and load of the sweep that filled it (lane_of_column)
 	int many_pass, many_ni;   // which pass of mc33hip_sweep_many filled it (its events), and how many isovalues that pass classified
 };
 
@@ -2704,10 +2758,17 @@ static void sweep_args(mc33hip_ctx *c, const SlotGeom &g, SweepArgs &a) {
 	a.z_end = c->range.z_end;
 	a.trace = nullptr;
 	a.debug = 0;
-	for (int q = 0; q < SWEEP_MAXNI; q++) a.lane[q] = SweepLane{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, (real_t)0};
+	for (int q = 0; q < SWEEP_MAXNI; q++) a.lane[q] = SweepLane{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, (real_t)0, 0, 0xFFFFFFFFu};
+}
+// SweepLane::iso_gt / iso_eq of an isovalue for packed samples of `top` as their largest value
+static void sweep_iso_words(real_t v, real_t top, int32_t &gt, uint32_t &eq) {
+	const real_t fl = std::floor(v);
+	gt = !(v == v) ? 0x7FFFFFFF : fl < 0 ? -1 : fl >= top ? (int32_t)top : (int32_t)fl;
+	eq = (v == fl && fl >= 0 && fl <= top) ? (uint32_t)fl : 0xFFFFFFFFu;
 }
 static void set_lane(SweepArgs &a, int q, const IsoLane &L, double iso) {
-	a.lane[q] = SweepLane{L.slice_hdr, L.slice_bits, L.plane_fmt, lane_part(L, false), L.edge_bits, L.edge_hdr, L.epoch, (real_t)iso};
+	a.lane[q] = SweepLane{L.slice_hdr, L.slice_bits, L.plane_fmt, lane_part(L, false), L.edge_bits, L.edge_hdr, L.epoch, (real_t)iso, 0, 0xFFFFFFFFu};
+	if (SWEEP_PACK > 1) sweep_iso_words((real_t)iso, SWEEP_PACK == 2 ? (real_t)65535 : (real_t)255, a.lane[q].iso_gt, a.lane[q].iso_eq);
 }
 
 // narrow samples are loaded as dwords when every row of the grid starts on a dword boundary (always true for the
@@ -2718,14 +2779,23 @@ static bool sweep_packed(const mc33hip_ctx *c) {
 }
 
 // one k_sweep launch over NI = 1, 2 or 4 lanes that begin_lane has prepared
+// (all return the samples per lane and load of the form that was launched: k_cells needs it - lane_of_column)
 template <int NI, int ZM>
-static void launch_sweep_zm(mc33hip_ctx *c, const SweepArgs &a, hipStream_t st) {
+static uint32_t launch_sweep_zm(mc33hip_ctx *c, const SweepArgs &a, hipStream_t st) {
 	const uint64_t blocks = (c->ntiles + 3) / 4;
-	if (sweep_packed(c)) hipLaunchKernelGGL((k_sweep<SWEEP_PACK, NI, ZM>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
-	else hipLaunchKernelGGL((k_sweep<1, NI, ZM>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
+	// (packed narrow samples, four isovalues, classified by subtraction - an isovalue of -0.0 among the four: the conversions of
+	// a batch and four sets of bit rows do not fit the registers of 3 waves per SIMD - 468 bytes of scratch per lane for uchar,
+	// 20 for ushort; that corner takes the unpacked form, which has none)
+	constexpr bool packed_form = !(SWEEP_PACK >= 2 && NI == 4 && ZM == 0);
+	if (packed_form && sweep_packed(c)) {
+		hipLaunchKernelGGL((k_sweep<packed_form ? SWEEP_PACK : 1, NI, ZM>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
+		return (uint32_t)SWEEP_PACK;
+	}
+	hipLaunchKernelGGL((k_sweep<1, NI, ZM>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
+	return 1u;
 }
 template <int NI>
-static void launch_sweep_ni(mc33hip_ctx *c, const SweepArgs &a, hipStream_t st) {
+static uint32_t launch_sweep_ni(mc33hip_ctx *c, const SweepArgs &a, hipStream_t st) {
 #ifdef MC33_INT_SAMPLES
 	// which classification the isovalues of this pass allow (k_sweep's ZM)
 	bool negzero = false, can_equal = false;
@@ -2739,12 +2809,11 @@ static void launch_sweep_ni(mc33hip_ctx *c, const SweepArgs &a, hipStream_t st) 
 	subtract |= env_u32("MC33_HIP_SWEEP_SUBTRACT", 0) != 0;  // (A/B of the two forms; same results)
 #endif
 	if (!subtract) {
-		if (can_equal) launch_sweep_zm<NI, 1>(c, a, st);
-		else launch_sweep_zm<NI, 2>(c, a, st);
-		return;
+		if (can_equal) return launch_sweep_zm<NI, 1>(c, a, st);
+		return launch_sweep_zm<NI, 2>(c, a, st);
 	}
 #endif
-	launch_sweep_zm<NI, 0>(c, a, st);
+	return launch_sweep_zm<NI, 0>(c, a, st);
 }
 
 // everything after the sweep for the slices lane L holds: tile boundaries, record ranges, cell records, slow-cell
@@ -2779,7 +2848,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 		hipLaunchKernelGGL(k_boundary, dim3((uint32_t)((c->nbounds + 3) / 4)), dim3(256), 0, st, a, c->d_bounds, (uint32_t)c->nbounds, 0u);
 	L.boundary_done = true;  // (its slices are in the partial sums now: a repeated tail - more room for records - must not add them again)
 	CellsArgs ca;
-	ca.pack = sweep_packed(c) ? (uint32_t)SWEEP_PACK : 1u;
+	ca.pack = L.pack ? L.pack : 1u;
 	ca.dev = 0;
 #ifdef MC33_DEV
 	ca.dev = env_u32("MC33_HIP_CELLS_DEV", 0);
@@ -2904,7 +2973,7 @@ static int enqueue_count(mc33hip_ctx *c, bool rerun = false) {
 		}
 		// nothing is cleared between extractions: headers carry the epoch, k_slots resets the counters and the
 		// partial sums of the next call, k_cells writes every row segment count of the range
-		launch_sweep_ni<1>(c, a, st);
+		L->pack = launch_sweep_ni<1>(c, a, st);
 		L->tail_pending = true;
 		HIP_TRY(hipGetLastError());
 	}
@@ -2935,14 +3004,12 @@ static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n) {
 		// (events around the pass are only recorded; read_timing asks for the elapsed time when the lane is consumed)
 		const bool timed = c->timing_level > 0 && pass < MC33_MANY_PASSES;
 		if (timed) HIP_TRY(hipEventRecord(c->ev_many[pass][0], st));
-		if (ni == 4) launch_sweep_ni<4>(c, a, st);
-		else if (ni == 2) launch_sweep_ni<2>(c, a, st);
-		else launch_sweep_ni<1>(c, a, st);
+		const uint32_t pack = ni == 4 ? launch_sweep_ni<4>(c, a, st) : ni == 2 ? launch_sweep_ni<2>(c, a, st) : launch_sweep_ni<1>(c, a, st);
 		HIP_TRY(hipGetLastError());
 		if (timed) HIP_TRY(hipEventRecord(c->ev_many[pass][1], st));
 		for (int q = 0; q < ni; q++) {
 			IsoLane &L = c->lanes[k + q];
-			L.swept = true; L.tail_pending = true; L.iso = isos[k + q]; L.range = c->range;
+			L.swept = true; L.tail_pending = true; L.iso = isos[k + q]; L.range = c->range; L.pack = pack;
 			L.many_pass = timed ? pass : -1; L.many_ni = ni;
 		}
 		k += ni;
