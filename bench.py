@@ -52,6 +52,8 @@ def parse():
                     help="planes (c5) / points per axis (c3) of the sub-grid the CPU reference is timed on")
     ap.add_argument("--with-c5", choices=("auto", "on", "off"), default=os.environ.get("MC33_BENCH_WITH_C5", "auto"),
                     help="append the configs[4] workload (2048x2048x1024 ushort, 8 isovalues) to the default c3 line as a compact \"c5\" object")
+    ap.add_argument("--no-c-api", action="store_true", default=os.environ.get("MC33_BENCH_NO_C_API", "0") == "1",
+                    help="leave out the `c_api` object (host walls of create_MC33 / calculate_isosurface through libMC33_f32.so)")
     ap.add_argument("--c5-points", type=int, default=int(os.environ.get("MC33_BENCH_C5_POINTS", "0")), help="points along z of the appended c5 grid (default 1024)")
     ap.add_argument("--c5-steps", type=int, default=int(os.environ.get("MC33_BENCH_C5_STEPS", "5")))
     ap.add_argument("--rank-timeout", type=int, default=int(os.environ.get("MC33_BENCH_RANK_TIMEOUT", "1500")),
@@ -187,6 +189,47 @@ def cpu_baseline(dtype, field_cpu, r0, d, isos, sample):
             "host_cores_available": os.cpu_count(), "cpu": model, "mtris_per_s": nT / best / 1e6}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# What the reference's callers time (GLUT_example/TestMC33_glut.c:441-446): the walls of the C API itself, through
+# libMC33_f32.so exactly as a C program gets them - create_MC33 (the one-time upload of _GRD.F) and calculate_isosurface
+# INCLUDING the copy of the surface into the caller's malloc blocks.  PCIe-inclusive: reported beside `value`, never as it.
+# ---------------------------------------------------------------------------------------------------------
+def c_api_walls(field, r0, d, iso, calls=6):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mc33_capi import MC33Lib, product_path   # (the ctypes view of marching_cubes_33.h; here on the PRODUCT library)
+    host = field.cpu().numpy()
+    lib = MC33Lib(product_path("f32"), "f32")
+    G, keep = lib.make_grid(host, r0, d)
+    t0 = time.perf_counter()
+    M = lib.lib.create_MC33(G)
+    create_ms = (time.perf_counter() - t0) * 1e3
+    if not M:
+        return {"error": "create_MC33 returned NULL"}
+    walls, frees, nV, nT = [], [], 0, 0
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        S = lib.lib.calculate_isosurface(M, C.c_float(iso))
+        t1 = time.perf_counter()
+        nV, nT = S.contents.nV, S.contents.nT
+        lib.lib.free_surface_memory(S)
+        frees.append((time.perf_counter() - t1) * 1e3)
+        walls.append((t1 - t0) * 1e3)
+    lib.lib.free_MC33(M)
+    lib.lib.free_memory_grd(G)
+    cells = (host.shape[0] - 1) * (host.shape[1] - 1) * (host.shape[2] - 1)
+    steady = sorted(walls[1:])[len(walls[1:]) // 2]
+    surf_bytes = nV * 28 + nT * 12  # V, N, color + T into the caller's malloc blocks
+    return {"library": "libMC33_f32.so", "create_MC33_ms": create_ms, "grid_bytes_uploaded": int(host.nbytes),
+            "upload_GBps": host.nbytes / (create_ms * 1e-3) / 1e9,
+            "calculate_isosurface_first_ms": walls[0], "calculate_isosurface_steady_ms": steady, "calls": calls,
+            "free_surface_memory_ms": sorted(frees)[len(frees) // 2],
+            "surface_bytes_to_host": surf_bytes, "d2h_inclusive_GBps": surf_bytes / (steady * 1e-3) / 1e9,
+            "Mvoxels_per_s_pcie_inclusive": cells / (steady * 1e-3) / 1e6, "vertices": nV, "triangles": nT,
+            "note": "host walls of the reference's own API on this workload: create_MC33 = upload of _GRD.F; calculate_isosurface = extraction + "
+                    "device-to-host copy of V, N, T, color into malloc blocks (first call: fresh pages; steady: median of the rest, blocks recycled by "
+                    "free_surface_memory).  PCIe-inclusive - never `value`"}
+
+
 def spread(a):
     if not a:
         return None
@@ -199,7 +242,7 @@ class Env:
     pass
 
 
-def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True):
+def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True, capi=False):
     """One workload on this process's GPU (all ranks run it together when world > 1).  Returns the result object on rank 0
     (None elsewhere).  cfg: "c3" | "c5"."""
     import torch
@@ -350,6 +393,13 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True):
                 print("[rank %d] slab concatenation (%s) equals whole-volume result: %s (nV %d nT %d)" % (rank, args.gather, ok, cw.nV, cw.nT), file=sys.stderr)
                 assert ok
     # ---- outside the timed region ---------------------------------------------------------------------------
+    # the sweep's rate "of peak" AND "of a measured read ceiling" - a plain read-only kernel over the same
+    # resident buffer, in this process (where the buffer lies physically decides 5 - 8 % of any read stream: DESIGN.md App. B)
+    read_ceiling = None
+    if not multi:
+        best_ms, med_ms, nbytes = grid.probe_read(10)
+        read_ceiling = {"GBps": nbytes / (best_ms * 1e-3) / 1e9, "GBps_median": nbytes / (med_ms * 1e-3) / 1e9, "ms_best": best_ms, "bytes": nbytes,
+                        "what": "mc33hip_probe_read: every 16-byte chunk of the resident grid read once (nontemporal), nothing written; best of 10 launches, hipEvents"}
     gather_info = None
     extract_only_ms = None
     rank_sweep = None
@@ -428,6 +478,8 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True):
                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": (grid_bytes_alg / (launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if sw else None,
                 "traffic": None, "traffic_source": None,
+                "read_ceiling": read_ceiling,
+                "frac_of_ceiling": (grid_bytes_alg / (launch_ms * 1e-3) / 1e9 / read_ceiling["GBps"]) if (sw and read_ceiling) else None,
                 "algorithmic_bytes_per_launch": grid_bytes_alg,
                 "isovalues_per_launch": per_launch,
                 "launch_ms": launch_ms,
@@ -491,6 +543,8 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True):
                                                    "%dx%dx%d-point slab (the first %d planes) of the same grid, all 8 isovalues" % (npx, npy, m, m))
             if res["cpu_baseline"]:
                 res["vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+        if capi and cfg == "c3" and not multi:
+            res["c_api"] = c_api_walls(field, r0, dd, isos[0])
     grid.close()
     del grid, field, V, N, T, ex
     torch.cuda.empty_cache()
@@ -540,26 +594,34 @@ def main():
             dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
     E.all_reduce = all_reduce
 
-    t_start = time.perf_counter()
-    res = run_config(args, args.config, E, points=args.points)
-    took = time.perf_counter() - t_start
+    plain = not E.multi and args.config == "c3" and not args.points   # the invocation the driver makes
+    res = run_config(args, args.config, E, points=args.points, capi=plain and not args.no_c_api)
     # The ushort / 8-isovalue workload of BASELINE configs[4] rides on the default line as a compact object, so that the
     # driver's `bench.py --gpus 1` carries it: on by default when this is the plain single-GPU c3 run, the c3 part was quick
     # and the device has room for the 8 GiB grid and its lanes.
-    with_c5 = args.with_c5
+    # (deterministic: `auto` = on for exactly that invocation, and a run that leaves it out says why)
+    with_c5, why_not = args.with_c5, None
     if with_c5 == "auto":
         free = torch.cuda.mem_get_info(E.dev)[0]
-        with_c5 = "on" if (not E.multi and args.config == "c3" and not args.points and took < 20.0 + (30.0 if not args.no_cpu_baseline else 0.0)
-                           and free >= (32 << 30)) else "off"
+        if not plain:
+            with_c5, why_not = "off", "not the plain single-GPU c3 invocation (--gpus / --config / --points given)"
+        elif free < (32 << 30):
+            with_c5, why_not = "off", "less than 32 GiB of device memory free (%.1f GiB) for the 8 GiB grid and its lanes" % (free / 2.0 ** 30)
+        else:
+            with_c5 = "on"
+    elif with_c5 == "off":
+        why_not = "--with-c5 off"
     if with_c5 == "on" and not E.multi and args.config == "c3" and res is not None:
         c5 = run_config(args, "c5", E, points=args.c5_points, steps=args.c5_steps, warmup=2)
         r = c5["roofline"]
         res["c5"] = {"workload": c5["config"]["workload"], "value": c5["value"], "unit": c5["unit"], "steps": c5["steps"], "ms_per_step": c5["ms_per_step"],
                      "ms_per_isovalue": c5["ms_per_isovalue"], "vertices": c5["config"]["vertices"], "triangles": c5["config"]["triangles"],
                      "mtris_per_s": c5["mtris_per_s"], "dtype": c5["dtype"], "with_event_records": c5.get("with_event_records"),
-                     "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "isovalues_per_launch",
+                     "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "read_ceiling", "frac_of_ceiling", "algorithmic_bytes_per_launch", "isovalues_per_launch",
                                                    "launch_ms", "kernel_ms", "step_bytes_moved", "step_device_ms", "step_frac", "whole_call_reference_equivalent")},
                      "cpu_baseline": c5.get("cpu_baseline"), "vs_cpu_baseline": c5.get("vs_cpu_baseline")}
+    elif res is not None and args.config == "c3":
+        res["c5"] = {"skipped": why_not or "multi-GPU run"}
     if E.rank == 0 and res is not None:
         print(json.dumps(res), flush=True)
     if E.multi:

@@ -35,7 +35,7 @@ class Timing(C.Structure):
 HIP_API = ["mc33hip_set_id_base", "mc33hip_create", "mc33hip_destroy", "mc33hip_last_error", "mc33hip_upload_rows",
            "mc33hip_upload_contiguous", "mc33hip_adopt_device", "mc33hip_set_stream", "mc33hip_count",
            "mc33hip_emit", "mc33hip_extract", "mc33hip_last_timing", "mc33hip_download",
-           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many", "mc33hip_set_normal_neg", "mc33hip_sweep_many", "mc33hip_set_timing"]
+           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many", "mc33hip_set_normal_neg", "mc33hip_sweep_many", "mc33hip_set_timing", "mc33hip_probe_read"]
 REFERENCE_API = ["create_MC33", "calculate_isosurface", "size_of_isosurface", "free_MC33", "free_surface_memory",
                  "adjustvectorlenght_s", "DefaultColorMC", "free_memory_grd", "alloc_F", "grid_from_data_pointer",
                  "generate_grid_from_fn", "_multTSA_bf", "_multA_bf", "mult_Abf",
@@ -91,6 +91,7 @@ def load_library(dtype="f32"):
     lib.mc33hip_set_normal_neg.argtypes = [V, C.c_int]
     lib.mc33hip_sweep_many.argtypes = [V, P(C.c_double), C.c_int, P(Range)]
     lib.mc33hip_set_timing.argtypes = [V, C.c_int]
+    lib.mc33hip_probe_read.argtypes = [V, C.c_int, P(C.c_float), P(C.c_float), P(C.c_ulonglong)]
     _libs[dtype] = lib
     return lib
 
@@ -129,10 +130,8 @@ class DeviceGrid:
         self.desc = desc
         self.ctx = C.c_void_p()
         _check(self.lib, self.lib.mc33hip_create(C.byref(self.ctx), C.byref(desc)))
-        # per-pass hipEvent timing for timing(): events are recorded on the stream, never waited for (off by default in
-        # the library; MC33_HIP_TIMING in the environment overrides)
-        if "MC33_HIP_TIMING" not in os.environ:
-            self.set_timing(2)
+        # (per-pass hipEvent timing is off, as in the library: a caller that wants timing() says set_timing(2) first -
+        # the event records cost ~20 us per call; MC33_HIP_TIMING in the environment sets the level a context starts with)
         _check(self.lib, self.lib.mc33hip_adopt_device(self.ctx, C.c_void_p(tensor.data_ptr()), pitch, tensor.stride(0)))
         self.device = tensor.device
         self.use_stream(torch.cuda.current_stream(self.device))
@@ -207,6 +206,12 @@ class DeviceGrid:
                                                C.c_void_p(T.data_ptr()), V.shape[0], T.shape[0]))
         self.stream.synchronize()
         return V[:cnt.nV], N[:cnt.nV], T[:cnt.nT], cnt
+
+    def probe_read(self, reps=10):
+        """A plain read of the resident grid (nothing to do with an extraction): (best ms, median ms, bytes)."""
+        best, med, nbytes = C.c_float(), C.c_float(), C.c_ulonglong()
+        _check(self.lib, self.lib.mc33hip_probe_read(self.ctx, int(reps), C.byref(best), C.byref(med), C.byref(nbytes)))
+        return best.value, med.value, nbytes.value
 
     def timing(self):
         t = Timing()

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	// The halo column (the first sample of the next row segment, one per row) used to be a load of its own: RB lanes of a
 	// batch each touching a different line for ONE sample - 8 % of the sweep's fabric reads at 1024^3 float, 15 % on the
 	// ushort grid of configs[4], two thirds of them missing L2 (the main loads are non-temporal), 6 % of the float sweep's
-	// time (tools/halo_cost.sh, profiles/r03_halo_cost.txt).  When the four waves of a block are the four segments of one
+	// time (tools/halo_cost.sh, profiles/r03_halo_cost_before.txt / r03_halo_cost_after.txt).  When the four waves of a block are the four segments of one
 	// 1024-sample group over the same rows and planes (the plan makes them so wherever the grid allows), wave k gets the bit
 	// from wave k + 1, which has just classified that very sample: every wave posts the column-0 bits of the plane it has
 	// completed (one ballot) in an LDS mailbox, one block barrier per PLANE (the four waves run in step anyway: a plane is
@@ -971,7 +971,7 @@ struct ChunkMap {  // per block, in LDS: exclusive prefix sums of the group coun
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const unsigned long long *part, unsigned long long *part_next,
                                                uint32_t part_cap, uint32_t epoch, uint64_t nslots, uint2 *slot_base, Counters *ctr, ListChunks lc,
-                                               unsigned long long *scan_state, uint32_t scan_words, uint32_t *live_list) {
+                                               unsigned long long *scan_state, uint32_t scan_words, uint32_t *live_list, uint32_t live_cap) {
 	__shared__ unsigned long long s_red[256];
 	__shared__ uint32_t s_live[256], s_live_base;
 	const uint32_t c = blockIdx.x, t = threadIdx.x;
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const uns
 		uint32_t at = s_live_base + s_live[t] - nlive;
 #pragma unroll
 		for (uint32_t k = 0; k < PER; k++)
-			if (cells[k]) live_list[at++] = (uint32_t)(s0 + k);
+			if (cells[k]) { if (at < live_cap) live_list[at] = (uint32_t)(s0 + k); at++; }  // (bounded: the cursor is only as clean as the tail before left it)
 	}
 	unsigned long long run = base + s_red[t] - mine;
 #pragma unroll
@@ -1070,6 +1070,7 @@ struct alignas(32) BatchDesc {
 // between extractions (every 255 tails the host does).  A segment of 256 cells has at most 256 x 9 vertices (a row of the
 // y = 0, z = 0 edge of the grid, every edge of every cell cut) and 256 x 12 triangles.
 constexpr uint32_t SEG_TAGS = 255u;
+static_assert(SEG_CELLS * 9u + 4u < 4096u && SEG_CELLS * 12u < 4096u, "a row segment's vertex / triangle counts must fit the 12-bit fields of seg_tagged");
 __host__ __device__ inline uint32_t seg_tagged(uint32_t nv, uint32_t nt, uint32_t tag) { return nv | nt << 12 | tag << 24; }
 __host__ __device__ inline uint32_t seg_counts(uint32_t word, uint32_t tag) { return (word >> 24) == tag ? (word & 0xFFFFFFu) : 0u; }  // nv | nt << 12
 struct CellsArgs {
@@ -1194,7 +1195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 	const bool live = in_grid && slice_valid(h.flags, a.epoch);  // wave-uniform
 	const bool rowvalid = lane < 63u && y < P.ny;
 	const uint64_t sidx = ((uint64_t)(z - P.zs) * P.nseg + seg) * P.ny + y;  // storage order [z][segment][y]
-	if (!live) continue;  // (cannot be: the slot is on the list.  The counts of row segments nobody writes are zero: k_scan_apply leaves them so)
+	if (!live) continue;  // (cannot be: the slot is on the list.  The counts of row segments nobody writes count as zero: their tag is an older tail's, seg_counts)
 	uint64_t prev[4], cur[4], act[4];
 	{
 		const bool raw_l = __builtin_amdgcn_readfirstlane((int)fmt_l) != (int)PLANE_COMPACT, raw_u = __builtin_amdgcn_readfirstlane((int)fmt_u) != (int)PLANE_COMPACT;
@@ -2196,6 +2197,7 @@ struct mc33hip_ctx {
 	uint32_t *live_list;     // [slot_base_cap]: slots with cut cells, k_slots -> k_cells
 	uint32_t cells_blocks;   // blocks of k_cells the GPU holds at once
 	uint32_t tail_serial;    // tails enqueued (seg_tagged)
+	bool tail_incomplete;    // a tail was begun and did not reach its last launch: Counters::live_cursor may not be zero
 	uint32_t records_hint;   // work records of the last extraction whose counters were read (grid of the triangle pass)
 	uint32_t epoch_wrap;      // the stamps start over at this count (2^30; MC33_HIP_EPOCH_WRAP for the test that crosses it)
 	IsoLane *cur_lane;        // the lane the last count used (its epoch is what the emit pass needs)
@@ -2885,15 +2887,19 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 		c->lc = ListChunks{c->list_cnt, c->list_cnt + LIST_CHUNKS, (uint32_t)((g.nslots + (1ull << shift) - 1) >> shift), shift};
 	}
 	ca.lc = c->lc;
-	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK)), dim3(256), 0, st, L.slice_hdr, lane_part(L, false), lane_part(L, true),
-	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr, c->lc, (unsigned long long *)(c->bsV + 2 * c->bs_cap), (uint32_t)(2 * scan_groups(c->bs_cap)), c->live_list);
-	L.tail_pending = false;  // k_slots has read this epoch's partial sums and cleared the half of the next one
-	if (!c->cells_blocks) {
+	if (!c->cells_blocks) {  // (asked before anything of the tail is launched: nothing below can return between k_slots and k_scan_apply)
 		int per_cu = 0, cus = 0;
 		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cells, 256, 0));
 		HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
 		c->cells_blocks = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, cus);
 	}
+	// k_slots appends to live_list from Counters::live_cursor on, and k_scan_apply - the last kernel of a tail - leaves the
+	// cursor zero for the next.  A tail that was cut short (a launch error) leaves it wherever it was: the next one starts clean.
+	if (c->tail_incomplete) HIP_TRY(hipMemsetAsync(&c->d_ctr->live_cursor, 0, sizeof(uint32_t), st));
+	c->tail_incomplete = true;
+	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK)), dim3(256), 0, st, L.slice_hdr, lane_part(L, false), lane_part(L, true),
+	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr, c->lc, (unsigned long long *)(c->bsV + 2 * c->bs_cap), (uint32_t)(2 * scan_groups(c->bs_cap)), c->live_list, ca.live_cap);
+	L.tail_pending = false;  // k_slots has read this epoch's partial sums and cleared the half of the next one
 	// (four times what the GPU holds at once: slices differ in length, and a block that starts late evens the waves out -
 	// 76 -> 66 us at 1024^3; a block per group of four slots, as until round 3, is 17 408 blocks there)
 	hipLaunchKernelGGL(k_cells, dim3((uint32_t)std::min<uint64_t>(g.cell_blocks, env_u32("MC33_HIP_CELLS_BLOCKS", 4u * c->cells_blocks))), dim3(256), 0, st, ca);
@@ -2917,6 +2923,7 @@ static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
 	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, seg_tag, c->nsegs, P, c->bsV, c->bsT, grV, grT);
 	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, seg_tag, c->nsegs, P, c->bsV, c->bsT, grV, grT, c->seg_base, c->ghost_segs, c->d_ctr);
 	HIP_TRY(hipGetLastError());
+	c->tail_incomplete = false;
 	return 0;
 }
 
@@ -2972,7 +2979,7 @@ static int enqueue_count(mc33hip_ctx *c, bool rerun = false) {
 			if (c->timing_level > 0) HIP_TRY(hipEventRecord(c->ev[0], st));
 		}
 		// nothing is cleared between extractions: headers carry the epoch, k_slots resets the counters and the
-		// partial sums of the next call, k_cells writes every row segment count of the range
+		// partial sums of the next call, the counts of the row segments carry the tag of the tail that wrote them (seg_tagged)
 		L->pack = launch_sweep_ni<1>(c, a, st);
 		L->tail_pending = true;
 		HIP_TRY(hipGetLastError());
@@ -3105,7 +3112,6 @@ static int fetch_counters(mc33hip_ctx *c) {
 	if (getenv("MC33_HIP_VERBOSE"))
 		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, record batches %u)\n", c->h_ctr->entry_cursor,
 		        c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->batch_cursor);
-	if (c->h_ctr->debug[0] == 3u) { set_err("k_scan: the sum of a chunk never arrived"); return MC33HIP_ERUNTIME; }
 	if (c->h_ctr->debug[0])
 		fprintf(stderr, "[mc33hip] DEBUG words %u: first %u count %u z %u y0 %u xbase %u batch %u of %u\n", c->h_ctr->debug[0], c->h_ctr->debug[1], c->h_ctr->debug[2],
 		        c->h_ctr->debug[3], c->h_ctr->debug[4], c->h_ctr->debug[5], c->h_ctr->debug[6], c->h_ctr->debug[7]);
@@ -3272,6 +3278,53 @@ extern "C" int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t) {
 		c->emit_pending = false;
 	}
 	*t = c->timing;
+	return MC33HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mc33hip_probe_read: what a plain read of the resident grid reaches on this device, in this process, on this buffer -
+// the ceiling the sweep's `roofline.frac` is set beside ("of peak" and "of a measured read ceiling").
+// Every 16-byte chunk once, nontemporal, four loads in flight per lane; nothing is written.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_probe_read(const u32x4_t *p, uint64_t n16, uint32_t *sink) {
+	const uint64_t stride = (uint64_t)gridDim.x * 256u;
+	uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+	u32x4_t acc = {0u, 0u, 0u, 0u};
+	for (; i + 3u * stride < n16; i += 4u * stride) {
+		const u32x4_t a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
+		const u32x4_t c = __builtin_nontemporal_load(p + i + 2u * stride), d = __builtin_nontemporal_load(p + i + 3u * stride);
+		acc ^= a ^ b ^ c ^ d;
+	}
+	for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(p + i);
+	if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u && sink) atomicAdd(sink, 1u);  // (keeps the loads; the word is as likely as any other)
+}
+
+extern "C" int mc33hip_probe_read(mc33hip_ctx *c, int reps, float *ms_best, float *ms_median, unsigned long long *bytes) {
+	if (!c || reps < 1 || reps > 64 || !c->d_grid) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	const uint64_t nbytes = ((uint64_t)c->slice * c->desc.npz_resident * sizeof(sample_t)) & ~(uint64_t)15;
+	const u32x4_t *p = (const u32x4_t *)(((uintptr_t)c->d_grid + 15u) & ~(uintptr_t)15);
+	const uint64_t n16 = (nbytes - ((uintptr_t)p - (uintptr_t)c->d_grid)) / 16;
+	if (!c->cus) HIP_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, c->device));
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	std::vector<float> t;
+	for (int k = 0; k < reps + 1; k++) {  // (the first launch is a warm-up)
+		(void)hipEventRecord(e0, c->stream);
+		hipLaunchKernelGGL(k_probe_read, dim3((uint32_t)std::max(1, c->cus) * 8u), dim3(256), 0, c->stream, p, n16, (uint32_t *)&c->d_ctr->debug[7]);
+		(void)hipEventRecord(e1, c->stream);
+		if (hipEventSynchronize(e1) != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); set_err("k_probe_read failed"); return MC33HIP_ERUNTIME; }
+		float ms = 0.f;
+		(void)hipEventElapsedTime(&ms, e0, e1);
+		if (k) t.push_back(ms);
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	std::sort(t.begin(), t.end());
+	if (ms_best) *ms_best = t.front();
+	if (ms_median) *ms_median = t[t.size() / 2];
+	if (bytes) *bytes = n16 * 16ull;
 	return MC33HIP_OK;
 }
 

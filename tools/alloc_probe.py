@@ -2,6 +2,7 @@
 """Developer tool: does the sweep time depend on WHERE the grid was allocated?  Times k_sweep (hipEvents of
 the library) on several freshly allocated copies of the 1024^3 field inside one process, under the
 environment settings given as arguments (e.g. "MC33_HIP_DEBUG=4")."""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 

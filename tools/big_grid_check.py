@@ -5,6 +5,7 @@ two z-slab extractions (ghost slice, id base), every triangle index is below nV,
 the grid boundary (every interior edge is shared by exactly two triangles - checked on a sample of the triangles
 by counting directed edges), and the counts follow the 1024^3 result by the expected factor (area ~ n^2).
 usage (GPU box): python tools/big_grid_check.py [n]"""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 

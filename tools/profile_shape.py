@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: repeated extraction of one cos-field shape, to be run under rocprofv3 --kernel-trace --stats.
 usage: python tools/profile_shape.py NZ NY NX [f32|u16|u8] [reps]"""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 

@@ -2,6 +2,7 @@
 """Developer tool: does the distance between planes (a power of two for 1024 x 1024 floats: 4 MiB) decide which of its
 two speeds k_sweep runs at?  The same field in buffers whose planes are padded by a few rows, several fresh allocations
 each, in one process.  usage (GPU box): python tools/stride_probe.py"""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 

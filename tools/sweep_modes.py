@@ -4,6 +4,7 @@ buffers, same plan); per launch, from the per-wave stamps of MC33_HIP_TRACE_FILE
 100 MHz clock (s_memrealtime), the shader-clock cycles the waves counted meanwhile (s_memtime) and hence the clock the
 shader engines actually ran at during that launch, next to the hipEvent time of the launch.
 usage (GPU box): python tools/sweep_modes.py [launches] > profiles/rNN_sweep_modes.txt"""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 import time

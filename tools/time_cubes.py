@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: extraction time of cos-field cubes from 32^3 to 1024^3 points (device time of the passes and
 wall time of the whole call with its one synchronisation).  usage (GPU box): python tools/time_cubes.py"""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 import time

@@ -4,6 +4,7 @@ MRI case of the reference's file readers) against a half-integer one: how much s
 vertices?  With `u8` the field is 128 + 40 (cos x + cos y + cos z) in unsigned chars: so coarse that samples repeat along
 every axis (plateaus), and an integer isovalue has whole sheets of samples equal to it.
 usage (GPU box): python tools/time_integer_iso.py [n] [u16|u8]"""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 

@@ -3,6 +3,7 @@
 share of cells that need the generic path (ambiguous MC33 cases) and the time grow with the noise amplitude.
 usage (GPU box): python tools/time_noisy.py [n] [amplitude ...]
 (one amplitude + MC33_HIP_NO_FORK=1 under `rocprofv3 --kernel-trace --stats` gives the split by kernel)"""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: extraction time for extents around the tiling's edges (row segments of 256 samples, groups of 1024,
 y tiles of 63 rows) - looks for performance cliffs, not for correctness.  usage (GPU box): python tools/time_shapes.py"""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 

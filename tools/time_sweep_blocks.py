@@ -2,6 +2,7 @@
 """Developer tool: sweep time against the number of sweep blocks per CU (MC33_HIP_SWEEP_BLOCKS_PER_CU; tiles = waves = 4 x blocks x CUs),
 contexts made one after the other over the SAME device buffer (the placement of the grid, which decides a sweep's speed, is
 the same for all).    python tools/time_sweep_blocks.py f32|u16c5|u8 2,3,4,2,3,4"""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 

@@ -2,6 +2,7 @@
 """Developer tool (-DMC33_DEV build in tools/_dev): sweep time per sample type with the developer switches of k_sweep
 (MC33_HIP_DEBUG=2: the read stream alone; 16: stream + cut-cell test, nothing handed on; 64: no halo-column load).
     python tools/time_sweep_dev.py f32|u16|u16c5|u8 0,64,0,64"""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: sweep / whole-call timings per sample type on cos fields resident in HBM.
 usage (GPU box): python tools/time_types.py"""
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 

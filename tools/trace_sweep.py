@@ -5,6 +5,7 @@ Prints how long waves live, when they start and finish relative to the kernel, a
 (block index mod 8), to see whether the kernel is bound by a tail of late waves.
 usage (GPU box): python tools/trace_sweep.py [n]
 """
+import os as _os; _os.environ.setdefault("MC33_HIP_TIMING", "2")  # per-pass hipEvents for timing(): DeviceGrid starts without them
 import os
 import sys
 
