@@ -161,6 +161,12 @@ __device__ inline void slot_group_coords(uint32_t b, const SlotDims &d, uint32_t
 // at once (NI lanes): an iso sweep over the resident grid (calculate_isosurfaces, BASELINE.json configs[4]) then reads
 // the volume once per NI isovalues instead of once per isovalue.
 constexpr int SWEEP_MAXNI = 4;
+// The kernels of a tail (k_boundary ... k_scan_apply) work for up to SWEEP_MAXNI isovalues in ONE launch: the argument set
+// of isovalue q is A.a[q], a block's isovalue is blockIdx.y (wave-uniform: the set is read through scalar loads from the
+// kernel argument segment).  An iso sweep (mc33hip_sweep_many) then needs a launch of each kernel per PASS over the grid
+// instead of one per isovalue; a single extraction launches with gridDim.y = 1.
+template <typename T>
+struct PerLane { T a[SWEEP_MAXNI]; };
 struct SweepLane {
 	SliceHeader *slice_hdr;  // [slice_slot]
 	uint4 *slice_bits;       // [slice_slot of the PLANE][half][lane]: {word 2*half lo, hi, word 2*half+1 lo, hi} of the plane's bit
@@ -507,6 +513,9 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 // below is put together by k_boundary from the bit rows both tiles leave behind (2 KiB each) - re-reading that
 // plane instead cost 1/depth of the traffic (6 % at depth 16).
 // ---------------------------------------------------------------------------------------------------
+#ifndef MC33_EDGE_COMPACT
+#define MC33_EDGE_COMPACT 0  // (developer A/B: the edge records of the single-isovalue pass in compact form too - leave_edge)
+#endif
 #if defined(MC33_GRD_U16)
 constexpr int SWEEP_PACK = 2;  // samples per dword
 #elif defined(MC33_GRD_U8)
@@ -796,7 +805,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 				// 0.75 - 0.78 ms; the costs of the sweep's stores do not add (round 3, profiles/r03_sweep_parts.txt))
 				uint32_t fmt = PLANE_RAW;
 				uint4 *rec = L.edge_bits + ((uint64_t)wtile * 2u + which) * 128u;
-				if constexpr (NI >= 2) fmt = store_plane_record<S>(rec, cur[q], lp);
+				if constexpr (NI >= 2 || MC33_EDGE_COMPACT) fmt = store_plane_record<S>(rec, cur[q], lp);
 				else if (!(MC33_DEBUG_BITS(a) & 8192u)) {  // (developer builds: 8192 no record, 4096 no header)
 					uint64_t o[4];
 					to_standard<S>(cur[q], o);
@@ -882,8 +891,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 // ---------------------------------------------------------------------------------------------------
 struct TileBoundary { uint32_t below, above, z, yt, seg, pad_[3]; };  // tile (wave) indices of k_sweep; slice z
 
-__global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileBoundary *bounds, uint32_t nbounds, uint32_t lane_no) {
-	const SweepLane &L = a.lane[lane_no];
+__global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileBoundary *bounds, uint32_t nbounds) {
+	const SweepLane &L = a.lane[blockIdx.y];  // (the isovalue lanes of the sweep that left the edge records)
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t bi = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	if (bi >= nbounds) return;
@@ -969,9 +978,30 @@ struct ChunkMap {  // per block, in LDS: exclusive prefix sums of the group coun
 // own chunk.  Record order is therefore a function of the grid alone (no allocation atomics).  The slots with cut cells
 // are also listed, for k_cells.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_slots(const SliceHeader *hdr, const unsigned long long *part, unsigned long long *part_next,
-                                               uint32_t part_cap, uint32_t epoch, uint64_t nslots, uint2 *slot_base, Counters *ctr, ListChunks lc,
-                                               unsigned long long *scan_state, uint32_t scan_words, uint32_t *live_list, uint32_t live_cap) {
+struct SlotsArgs {
+	const SliceHeader *hdr;
+	const unsigned long long *part;
+	unsigned long long *part_next;
+	uint32_t part_cap, epoch;
+	uint2 *slot_base;
+	Counters *ctr;
+	ListChunks lc;
+	unsigned long long *scan_state;
+	uint32_t scan_words;
+	uint32_t *live_list;
+	uint32_t live_cap;
+};
+__global__ __launch_bounds__(256) void k_slots(const PerLane<SlotsArgs> A, uint64_t nslots) {
+	const SlotsArgs &sa = A.a[blockIdx.y];
+	const SliceHeader *hdr = sa.hdr;
+	const unsigned long long *part = sa.part;
+	unsigned long long *part_next = sa.part_next;
+	const uint32_t part_cap = sa.part_cap, epoch = sa.epoch, scan_words = sa.scan_words, live_cap = sa.live_cap;
+	uint2 *slot_base = sa.slot_base;
+	Counters *ctr = sa.ctr;
+	const ListChunks lc = sa.lc;
+	unsigned long long *scan_state = sa.scan_state;
+	uint32_t *live_list = sa.live_list;
 	__shared__ unsigned long long s_red[256];
 	__shared__ uint32_t s_live[256], s_live_base;
 	const uint32_t c = blockIdx.x, t = threadIdx.x;
@@ -1149,7 +1179,8 @@ __device__ __forceinline__ uint2 corner_look(const GridView<sample_t> &G, real_t
 	return uint2{poff, pat[poff]};
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_cells(const CellsArgs a) {  // (4 waves per SIMD is what its LDS allows: keep the registers of the rare test code from costing one)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_cells(const PerLane<CellsArgs> A) {  // (4 waves per SIMD is what its LDS allows: keep the registers of the rare test code from costing one)
+	const CellsArgs &a = A.a[blockIdx.y];
 	__shared__ uint4 s_fast[256];
 	__shared__ CellsLds s_w[4];
 	s_fast[threadIdx.x] = a.fast[threadIdx.x];
@@ -1410,7 +1441,8 @@ struct SlowArgs {
 	Counters *ctr;
 };
 
-__global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
+__global__ __launch_bounds__(256) void k_slow_plan(const PerLane<SlowArgs> A) {
+	const SlowArgs &a = A.a[blockIdx.y];
 	__shared__ real_t s_v[8][256];
 	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
 	ChunkMap cm;
@@ -1454,7 +1486,8 @@ __global__ __launch_bounds__(256) void k_slow_plan(const SlowArgs a) {
 }
 
 // the triangles of the slow cells that have a corner equal to the isovalue, counted by vertex identity on the stored plans
-__global__ __launch_bounds__(256) void k_slow_count(const SlowArgs a) {
+__global__ __launch_bounds__(256) void k_slow_count(const PerLane<SlowArgs> A) {
+	const SlowArgs &a = A.a[blockIdx.y];
 	__shared__ real_t s_w[8][256];
 	__shared__ uint64_t s_key[12][256];
 	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
@@ -1487,7 +1520,8 @@ __global__ __launch_bounds__(256) void k_slow_count(const SlowArgs a) {
 }
 
 // one thread per row segment that holds slow cells: running offsets of its records, segment totals
-__global__ __launch_bounds__(256) void k_seg_fix(const SlowArgs a) {
+__global__ __launch_bounds__(256) void k_seg_fix(const PerLane<SlowArgs> A) {
+	const SlowArgs &a = A.a[blockIdx.y];
 	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
 	if (blockIdx.x * 256u >= a.ctr->dirty_cursor) return;  // (k_slow_plan left the total there)
 	ChunkMap cm;
@@ -1536,7 +1570,18 @@ struct SweepWalk {
 // The records are stored [z][segment][y]; the scan runs over them in sweep order [z][y][segment]: a chunk of
 // SCAN_CHUNK consecutive sweep positions is the same set of records whatever the order inside it only
 // when it covers whole (y, all segments) groups - so the mapping is applied per element.
-__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, uint32_t tag, uint64_t n, Params P, uint64_t *bsV, uint64_t *bsT, uint64_t *grV, uint64_t *grT) {
+struct ScanArgs {  // per isovalue
+	const uint32_t *seg_cnt;
+	uint32_t tag;
+	uint64_t *bsV, *bsT, *grV, *grT;
+	SegBase *seg_base;
+	Counters *ctr;
+};
+__global__ __launch_bounds__(256) void k_scan_reduce(const PerLane<ScanArgs> A, uint64_t n, Params P) {
+	const ScanArgs &sa = A.a[blockIdx.y];
+	const uint32_t *seg_cnt = sa.seg_cnt;
+	const uint32_t tag = sa.tag;
+	uint64_t *bsV = sa.bsV, *bsT = sa.bsT, *grV = sa.grV, *grT = sa.grT;
 	__shared__ uint64_t sv[4], st[4];
 	const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
 	uint64_t v = 0, t = 0;
@@ -1569,8 +1614,13 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *seg_cnt, ui
 // in one 64-bit word per sum, agent-scope atomics, chunks by ticket - was written and is correct and slower: 41 us against
 // 10 + 9 at 1024^3, 116 against 76 at 2048 x 2048 x 1024: a state crosses from one XCD's L2 to another's through memory,
 // and the chain of running sums is as long as the launch has rounds of blocks.)
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *seg_cnt, uint32_t tag, uint64_t n, Params P, const uint64_t *bsV, const uint64_t *bsT, const uint64_t *grV, const uint64_t *grT,
-                                                    SegBase *seg_base, uint64_t ghost_segs, Counters *ctr) {
+__global__ __launch_bounds__(256) void k_scan_apply(const PerLane<ScanArgs> A, uint64_t n, Params P, uint64_t ghost_segs) {
+	const ScanArgs &sa = A.a[blockIdx.y];
+	const uint32_t *seg_cnt = sa.seg_cnt;
+	const uint32_t tag = sa.tag;
+	const uint64_t *bsV = sa.bsV, *bsT = sa.bsT, *grV = sa.grV, *grT = sa.grT;
+	SegBase *seg_base = sa.seg_base;
+	Counters *ctr = sa.ctr;
 	__shared__ uint32_t sv[4], st[4];
 	__shared__ uint64_t s_bv[4], s_bt[4];
 	uint64_t bv = 0, bt = 0;  // vertices / triangles of all chunks before this one
@@ -2157,10 +2207,43 @@ struct IsoLane {
 	// a sweep made ahead of time by mc33hip_sweep_many, waiting for the count / extract call of its isovalue
 	bool swept, boundary_done;
 	bool tail_pending;        // a sweep has added this lane's slices into slot_part and no tail (k_slots) has consumed them yet
+	bool tail_done;           // ... and the tail (k_slots ... k_scan_apply) of that sweep has been enqueued too, into the lane's own
+	                          // TailSet: the count / extract call finds record ranges, records and prefix sums made
 	double iso;
 	mc33hip_range range;
 	uint32_t pack;            // samples per lane and load of the sweep that filled it (lane_of_column)
 	int many_pass, many_ni;   // which pass of mc33hip_sweep_many filled it (its events), and how many isovalues that pass classified
+};
+
+// Everything a tail (k_slots ... k_scan_apply) writes and the emit passes read, for ONE isovalue.  Lane k of the sweep buffers
+// works with set k.  A single extraction uses lane 0 and set 0; an iso sweep (mc33hip_sweep_many) fills the sets of all its
+// isovalues right behind each pass over the grid - one launch of every tail kernel for the up to four isovalues of the pass
+// (PerLane) - and the count / extract calls that follow only emit (round 4; until then the one set was shared and every
+// isovalue ran its nine tail launches by itself: 72 launches per 8-isovalue step, now 18).
+struct TailSet {
+	uint32_t *seg_cnt;
+	SegDir *seg_dir;
+	SegBase *seg_base;
+	uint64_t seg_cap;
+	uint64_t *bsV, *bsT;
+	uint64_t bs_cap;
+	EntryA *entries_a;
+	EntryB *entries_b;
+	EntryC *entries_c;
+	uint32_t *entry_seg, *slow_list, *dirty_list;
+	uint64_t entry_cap;
+	BatchDesc *batches;       // the records in batches of <= 64 of one slice slot (k_cells writes, the emit passes walk)
+	uint64_t batch_cap;
+	uint32_t *list_cnt;       // [2][LIST_CHUNKS] cursors of the slow / dirty list parts (ListChunks)
+	ListChunks lc;            // ... for the range last counted
+	uint2 *slot_base;
+	uint64_t slot_base_cap;
+	uint32_t *live_list;      // [slot_base_cap]: slots with cut cells, k_slots -> k_cells
+	uint32_t tail_serial;     // tails enqueued (seg_tagged)
+	bool tail_incomplete;     // a tail was begun and did not reach its last launch: Counters::live_cursor may not be zero
+	uint32_t records_hint;    // work records of the last extraction whose counters were read (grid of the triangle pass, first guess of a new set)
+	Counters *d_ctr, *h_ctr;
+	bool ctr_published;       // the emit pass enqueued last leaves the counters in h_ctr itself (k_emit_fast_triangles)
 };
 
 struct mc33hip_ctx {
@@ -2174,34 +2257,16 @@ struct mc33hip_ctx {
 	uint32_t *d_rules;
 	uint8_t *d_rule_index;
 	uint4 *d_fast;
-	uint32_t *seg_cnt;
-	SegDir *seg_dir;
-	SegBase *seg_base;
-	uint64_t seg_cap;
-	uint64_t *bsV, *bsT;
-	uint64_t bs_cap;
-	EntryA *entries_a;
-	EntryB *entries_b;
-	EntryC *entries_c;
 	EntryB *d_fast_b;
 	uint32_t *d_pat;
-	uint32_t *entry_seg, *slow_list, *dirty_list;
-	BatchDesc *batches;       // the records in batches of <= 64 of one slice slot (k_cells writes, the emit passes walk)
-	uint64_t batch_cap;
-	uint32_t *list_cnt;       // [2][LIST_CHUNKS] cursors of the slow / dirty list parts (ListChunks)
-	ListChunks lc;            // ... for the range last counted
-	uint64_t entry_cap;
 	IsoLane lanes[MC33_LANES]; // what a sweep leaves behind, per isovalue (lane 0: the single-isovalue calls)
-	uint2 *slot_base;
-	uint64_t slot_base_cap;
-	uint32_t *live_list;     // [slot_base_cap]: slots with cut cells, k_slots -> k_cells
+	TailSet ts[MC33_LANES];    // ... and what its tail leaves behind (set k belongs to lane k)
+	TailSet *w;                // the set of the lane the last count used: what emit and the counters refer to
 	uint32_t cells_blocks;   // blocks of k_cells the GPU holds at once
-	uint32_t tail_serial;    // tails enqueued (seg_tagged)
-	bool tail_incomplete;    // a tail was begun and did not reach its last launch: Counters::live_cursor may not be zero
-	uint32_t records_hint;   // work records of the last extraction whose counters were read (grid of the triangle pass)
 	uint32_t epoch_wrap;      // the stamps start over at this count (2^30; MC33_HIP_EPOCH_WRAP for the test that crosses it)
 	IsoLane *cur_lane;        // the lane the last count used (its epoch is what the emit pass needs)
 	bool lane_presweeped;     // ... and it had been filled by mc33hip_sweep_many
+	bool lane_pretailed;      // ... tail included
 	SweepTile *d_tiles;       // block plan of k_sweep for the current range
 	TileBoundary *d_bounds;   // pairs of tiles that meet in z (k_boundary)
 	uint64_t tiles_cap, ntiles, nbounds;
@@ -2209,10 +2274,8 @@ struct mc33hip_ctx {
 	uint32_t resident_blocks; // k_sweep blocks the device holds at once
 	int cus;                  // compute units of the device
 	int emit_v_blocks_per_cu; // blocks of k_emit_vertices a CU holds
-	Counters *d_ctr, *h_ctr;
-	bool ctr_published;       // the emit pass enqueued last leaves the counters in h_ctr itself (k_emit_fast_triangles)
 	hipEvent_t ev[4];
-	hipEvent_t ev_many[MC33_MANY_PASSES][2];  // mc33hip_sweep_many's passes: recorded around each, read in read_timing (nobody waits)
+	hipEvent_t ev_many[MC33_MANY_PASSES][3];  // mc33hip_sweep_many's passes: recorded before the sweep, behind it, behind the tails made ahead; read in read_timing (nobody waits)
 	hipStream_t aux, aux2;    // the triangle pass and the slow-record pass run beside the vertex pass
 	hipStream_t copy;         // mc33hip_download_concurrent
 	hipEvent_t ev_fork, ev_join, ev_join2;
@@ -2285,6 +2348,14 @@ static size_t own_pitch(size_t npx) {
 	return (npx + unit - 1) / unit * unit;
 }
 
+static void free_set(TailSet &w) {  // (everything of the set; it can be filled again by ensure_set)
+	(void)hipFree(w.seg_cnt); (void)hipFree(w.seg_dir); (void)hipFree(w.seg_base); (void)hipFree(w.bsV);
+	(void)hipFree(w.entries_a); (void)hipFree(w.entries_b); (void)hipFree(w.entries_c); (void)hipFree(w.entry_seg); (void)hipFree(w.slow_list); (void)hipFree(w.dirty_list);
+	(void)hipFree(w.batches); (void)hipFree(w.list_cnt); (void)hipFree(w.slot_base); (void)hipFree(w.live_list); (void)hipFree(w.d_ctr);
+	if (w.h_ctr) (void)hipHostFree(w.h_ctr);
+	w = TailSet{};
+}
+
 extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	if (!out || !d) return MC33HIP_EINVAL;
 	*out = nullptr;
@@ -2334,12 +2405,10 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 		CREATE_TRY(hipMalloc(&c->d_pat, sizeof pat));
 		CREATE_TRY(hipMemcpy(c->d_pat, pat, sizeof pat, hipMemcpyHostToDevice));
 	}
-	CREATE_TRY(hipMalloc(&c->d_ctr, sizeof(Counters)));
-	CREATE_TRY(hipMemset(c->d_ctr, 0, sizeof(Counters)));  // (live_cursor: every tail leaves it zero for the next)
-	CREATE_TRY(hipMalloc(&c->list_cnt, 2 * LIST_CHUNKS * sizeof(uint32_t)));
-	CREATE_TRY(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
+	c->w = &c->ts[0];  // (the sets get their memory when a range is known: ensure_set)
 	for (int k = 0; k < 4; k++) CREATE_TRY(hipEventCreate(&c->ev[k]));
-	for (int k = 0; k < MC33_MANY_PASSES; k++) { CREATE_TRY(hipEventCreate(&c->ev_many[k][0])); CREATE_TRY(hipEventCreate(&c->ev_many[k][1])); }
+	for (int k = 0; k < MC33_MANY_PASSES; k++)
+		for (int j = 0; j < 3; j++) CREATE_TRY(hipEventCreate(&c->ev_many[k][j]));
 	CREATE_TRY(pool_take(c->device, &c->aux));
 	CREATE_TRY(pool_take(c->device, &c->aux2));
 	CREATE_TRY(pool_take(c->device, &c->copy));
@@ -2359,25 +2428,21 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	else (void)hipDeviceSynchronize();
 	if (c->owns_grid) (void)hipFree(c->d_grid);
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_rules); (void)hipFree(c->d_rule_index); (void)hipFree(c->d_fast);
-	(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base);
-	(void)hipFree(c->bsV);
-	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->entries_c); (void)hipFree(c->d_fast_b); (void)hipFree(c->d_pat); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list); (void)hipFree(c->batches);
+	(void)hipFree(c->d_fast_b); (void)hipFree(c->d_pat);
+	for (int k = 0; k < MC33_LANES; k++) free_set(c->ts[k]);
 	for (int k = 0; k < MC33_LANES; k++) {
 		IsoLane &L = c->lanes[k];
 		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.plane_fmt); (void)hipFree(L.slot_part); (void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
 	}
 	(void)hipFree(c->d_tiles);
-	(void)hipFree(c->slot_base); (void)hipFree(c->live_list);
 	(void)hipFree(c->d_bounds);
 	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
-	(void)hipFree(c->d_ctr); (void)hipFree(c->list_cnt);
-	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	if (c->aux) (void)hipStreamSynchronize(c->aux);
 	if (c->aux2) (void)hipStreamSynchronize(c->aux2);
 	if (c->copy) (void)hipStreamSynchronize(c->copy);
 	for (int k = 0; k < 4; k++) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
 	for (int k = 0; k < MC33_MANY_PASSES; k++)
-		for (int j = 0; j < 2; j++) if (c->ev_many[k][j]) (void)hipEventDestroy(c->ev_many[k][j]);
+		for (int j = 0; j < 3; j++) if (c->ev_many[k][j]) (void)hipEventDestroy(c->ev_many[k][j]);
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
@@ -2386,7 +2451,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 }
 
 static void forget_sweeps(mc33hip_ctx *c) {  // the grid changed: sweeps made ahead of time are worthless
-	for (int k = 0; k < MC33_LANES; k++) c->lanes[k].swept = false;
+	for (int k = 0; k < MC33_LANES; k++) { c->lanes[k].swept = false; c->lanes[k].tail_done = false; }
 }
 
 extern "C" int mc33hip_set_stream(mc33hip_ctx *c, void *s) {
@@ -2537,53 +2602,61 @@ static uint32_t env_u32(const char *name, uint32_t dflt) {
 	return v > 0 ? (uint32_t)v : dflt;
 }
 
-static int alloc_entries(mc33hip_ctx *c, uint64_t cap) {
-	(void)hipFree(c->entries_a); (void)hipFree(c->entries_b); (void)hipFree(c->entries_c); (void)hipFree(c->entry_seg); (void)hipFree(c->slow_list); (void)hipFree(c->dirty_list);
-	c->entries_a = nullptr; c->entries_b = nullptr; c->entries_c = nullptr; c->entry_seg = nullptr; c->slow_list = nullptr; c->dirty_list = nullptr;
-	c->entry_cap = 0;
+static int alloc_entries(TailSet &w, uint64_t cap) {
+	(void)hipFree(w.entries_a); (void)hipFree(w.entries_b); (void)hipFree(w.entries_c); (void)hipFree(w.entry_seg); (void)hipFree(w.slow_list); (void)hipFree(w.dirty_list);
+	w.entries_a = nullptr; w.entries_b = nullptr; w.entries_c = nullptr; w.entry_seg = nullptr; w.slow_list = nullptr; w.dirty_list = nullptr;
+	w.entry_cap = 0;
 	if (cap > 0xFFFFFF00ull) cap = 0xFFFFFF00ull;
-	HIP_TRY(hipMalloc(&c->entries_a, (cap + 2) * sizeof(EntryA)));  // (+ 2: the triangle pass reads records in pairs)
-	HIP_TRY(hipMalloc(&c->entries_b, cap * sizeof(EntryB)));  // (touched for tested and slow records only)
-	HIP_TRY(hipMalloc(&c->entries_c, cap * sizeof(EntryC)));  // (... for slow records only)
-	HIP_TRY(hipMalloc(&c->entry_seg, cap * 4));
-	HIP_TRY(hipMalloc(&c->slow_list, cap * 4));
-	HIP_TRY(hipMalloc(&c->dirty_list, cap * 4));
-	c->entry_cap = cap;
+	HIP_TRY(hipMalloc(&w.entries_a, (cap + 2) * sizeof(EntryA)));  // (+ 2: the triangle pass reads records in pairs)
+	HIP_TRY(hipMalloc(&w.entries_b, cap * sizeof(EntryB)));  // (touched for tested and slow records only)
+	HIP_TRY(hipMalloc(&w.entries_c, cap * sizeof(EntryC)));  // (... for slow records only)
+	HIP_TRY(hipMalloc(&w.entry_seg, cap * 4));
+	HIP_TRY(hipMalloc(&w.slow_list, cap * 4));
+	HIP_TRY(hipMalloc(&w.dirty_list, cap * 4));
+	w.entry_cap = cap;
 	return 0;
 }
 
-static int ensure_workspaces(mc33hip_ctx *c) {
-	if (c->seg_cap < c->nsegs) {
-		(void)hipFree(c->seg_cnt); (void)hipFree(c->seg_dir); (void)hipFree(c->seg_base);
-		c->seg_cnt = nullptr; c->seg_dir = nullptr; c->seg_base = nullptr;
-		c->seg_cap = 0;
-		HIP_TRY(hipMalloc(&c->seg_cnt, c->nsegs * 4));
-		c->tail_serial = 0;  // (the first tail clears the new array)
-		HIP_TRY(hipMalloc(&c->seg_dir, c->nsegs * sizeof(SegDir)));
-		HIP_TRY(hipMalloc(&c->seg_base, (c->nsegs + 1) * sizeof(SegBase)));  // (+ 1: the triangle pass reads bases in pairs)
-		c->seg_cap = c->nsegs;
+// the buffers of set w for the current range (c->nsegs, c->P, c->range); hint: work records to make room for at first (0: a guess from the range)
+static int ensure_set(mc33hip_ctx *c, TailSet &w, uint64_t hint = 0) {
+	if (!w.d_ctr) {
+		HIP_TRY(hipMalloc(&w.d_ctr, sizeof(Counters)));
+		HIP_TRY(hipMemset(w.d_ctr, 0, sizeof(Counters)));  // (live_cursor: every tail leaves it zero for the next)
+		HIP_TRY(hipMalloc(&w.list_cnt, 2 * LIST_CHUNKS * sizeof(uint32_t)));
+		HIP_TRY(hipHostMalloc(&w.h_ctr, sizeof(Counters), hipHostMallocDefault));
+	}
+	if (w.seg_cap < c->nsegs) {
+		(void)hipFree(w.seg_cnt); (void)hipFree(w.seg_dir); (void)hipFree(w.seg_base);
+		w.seg_cnt = nullptr; w.seg_dir = nullptr; w.seg_base = nullptr;
+		w.seg_cap = 0;
+		HIP_TRY(hipMalloc(&w.seg_cnt, c->nsegs * 4));
+		w.tail_serial = 0;  // (the first tail clears the new array)
+		HIP_TRY(hipMalloc(&w.seg_dir, c->nsegs * sizeof(SegDir)));
+		HIP_TRY(hipMalloc(&w.seg_base, (c->nsegs + 1) * sizeof(SegBase)));  // (+ 1: the triangle pass reads bases in pairs)
+		w.seg_cap = c->nsegs;
 	}
 	const uint64_t nb = (c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK;
-	if (c->bs_cap < nb) {
-		(void)hipFree(c->bsV);
-		c->bsV = c->bsT = nullptr;
-		c->bs_cap = 0;
-		HIP_TRY(hipMalloc(&c->bsV, 2 * (nb + scan_groups(nb)) * 8));  // chunk sums V, T; then group sums V, T
-		c->bsT = c->bsV + nb;
-		c->bs_cap = nb;
+	if (w.bs_cap < nb) {
+		(void)hipFree(w.bsV);
+		w.bsV = w.bsT = nullptr;
+		w.bs_cap = 0;
+		HIP_TRY(hipMalloc(&w.bsV, 2 * (nb + scan_groups(nb)) * 8));  // chunk sums V, T; then group sums V, T
+		w.bsT = w.bsV + nb;
+		w.bs_cap = nb;
 	}
-	if (!c->entries_a) {
+	if (!w.entries_a) {
 		// first guess: one cell in 32 is cut (BASELINE fields: 0.4-6 % of the cells); grown on demand
 		const uint64_t cells = (uint64_t)c->P.nx * c->P.ny * (c->range.z_end - c->P.zs);
-		return alloc_entries(c, cells / 32 + 65536);
+		return alloc_entries(w, hint ? hint + hint / 4 + 65536 : cells / 32 + 65536);
 	}
 	return 0;
 }
+static int ensure_workspaces(mc33hip_ctx *c) { return ensure_set(c, c->ts[0]); }
 
-static int grow_entries(mc33hip_ctx *c, uint64_t need) {
+static int grow_entries(TailSet &w, uint64_t need) {
 	const uint64_t cap = need + need / 8 + 65536;
 	if (cap > 0xFFFFFF00ull) { set_err("more than 2^32 work records"); return MC33HIP_EOVERFLOW; }
-	return alloc_entries(c, cap);
+	return alloc_entries(w, cap);
 }
 
 // Block plan of k_sweep for cell slices [zs, ze): every (segment group, y tile) column is cut along z into
@@ -2818,112 +2891,137 @@ static uint32_t launch_sweep_ni(mc33hip_ctx *c, const SweepArgs &a, hipStream_t 
 	return launch_sweep_zm<NI, 0>(c, a, st);
 }
 
-// everything after the sweep for the slices lane L holds: tile boundaries, record ranges, cell records, slow-cell
-// planning, scans - on the context's stream, no synchronisation
-static int enqueue_tail(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g) {
-	const Params &P = c->P;
+// Parameters of the passes for the isovalue of one lane (fill_params made c->P for the call's own isovalue)
+static Params lane_params(const mc33hip_ctx *c, double iso) {
+	Params P = c->P;
+	P.iso = (real_t)iso;
+	P.negzero_iso = (P.iso == 0 && sign_of(P.iso)) ? 1 : 0;
+	return P;
+}
+
+// Everything after the sweep for the slices the lanes idx[0 .. n) hold (n <= SWEEP_MAXNI; lane idx[q] works into set sidx[q]): tile
+// boundaries, record ranges, cell records, slow-cell planning, scans - ONE launch of each kernel for all n isovalues
+// (PerLane, blockIdx.y), on the context's stream, no synchronisation.  isos[q]: the isovalue of lane idx[q].
+static int enqueue_tail(mc33hip_ctx *c, const int *idx, const int *sidx, const double *isos, int n, const SlotGeom &g) {
 	hipStream_t st = c->stream;
 	const uint32_t ze = c->range.z_end;
-	if (c->slot_base_cap < g.nslots) {
-		(void)hipFree(c->slot_base); (void)hipFree(c->live_list);
-		c->slot_base = nullptr; c->live_list = nullptr; c->slot_base_cap = 0;
-		HIP_TRY(hipMalloc(&c->slot_base, g.nslots * sizeof(uint2)));
-		HIP_TRY(hipMalloc(&c->live_list, g.nslots * sizeof(uint32_t)));
-		c->slot_base_cap = g.nslots;
-	}
-	{  // batch descriptors: every 64 records one, plus at most one partly filled batch per slice slot
-		const uint64_t need = c->entry_cap / 64 + g.nslots + 64;
-		if (c->batch_cap < need) {
-			(void)hipFree(c->batches);
-			c->batches = nullptr; c->batch_cap = 0;
-			HIP_TRY(hipMalloc(&c->batches, need * sizeof(BatchDesc)));
-			c->batch_cap = need;
-		}
-	}
 	SweepArgs a;
 	sweep_args(c, g, a);
-	set_lane(a, 0, L, P.iso);
 #ifdef MC33_DEV
 	a.debug = env_u32("MC33_HIP_DEBUG", 0);
 #endif
-	if (c->nbounds && !L.boundary_done && !(MC33_DEBUG_BITS(a) & 2u))
-		hipLaunchKernelGGL(k_boundary, dim3((uint32_t)((c->nbounds + 3) / 4)), dim3(256), 0, st, a, c->d_bounds, (uint32_t)c->nbounds, 0u);
-	L.boundary_done = true;  // (its slices are in the partial sums now: a repeated tail - more room for records - must not add them again)
-	CellsArgs ca;
-	ca.pack = L.pack ? L.pack : 1u;
-	ca.dev = 0;
-#ifdef MC33_DEV
-	ca.dev = env_u32("MC33_HIP_CELLS_DEV", 0);
-#endif
-	ca.G.p = c->d_grid; ca.G.pitch = (uint32_t)c->pitch; ca.G.z0 = c->desc.plane0; ca.G.slice = c->slice;
-	ca.P = P; ca.fast = c->d_fast; ca.pat = c->d_pat;
-	ca.ze = ze; ca.sd = g.sd;
-	ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.plane_fmt = L.plane_fmt; ca.slot_base = c->slot_base;
-	// the tag of this tail's row-segment counts; the array is cleared whenever the tags start over
-	if (c->tail_serial % SEG_TAGS == 0) HIP_TRY(hipMemsetAsync(c->seg_cnt, 0, c->seg_cap * 4, st));
-	const uint32_t seg_tag = c->tail_serial % SEG_TAGS + 1u;
-	c->tail_serial++;
-	ca.seg_tag = seg_tag;
-	ca.live_list = c->live_list; ca.live_cap = (uint32_t)std::min<uint64_t>(g.nslots, 0xFFFFFFFFull);
-	ca.epoch = L.epoch;
-	ca.seg_cnt = c->seg_cnt; ca.seg_dir = c->seg_dir;
-	ca.entries_a = c->entries_a; ca.entries_b = c->entries_b; ca.entry_seg = c->entry_seg; ca.slow_list = c->slow_list; ca.dirty_list = c->dirty_list;
-	ca.entry_cap = (uint32_t)c->entry_cap;
-	ca.batches = c->batches; ca.batch_cap = (uint32_t)std::min<uint64_t>(c->batch_cap, 0xFFFFFFFFull);
-	ca.ctr = c->d_ctr;
-	ca.trace = nullptr;
-	if (getenv("MC33_HIP_TRACE_CELLS")) {
-		(void)hipFree(c->trace_cells);
-		c->trace_cells = nullptr;
-		c->trace_cells_n = g.nslots;
-		HIP_TRY(hipMalloc(&c->trace_cells, g.nslots * 32));
-		HIP_TRY(hipMemsetAsync(c->trace_cells, 0, g.nslots * 32, st));
-		ca.trace = c->trace_cells;
-	}
-	const uint64_t nchunks = (L.slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;
-	{  // groups of slots for the slow / dirty lists: at most LIST_CHUNKS
-		uint32_t shift = 6;
-		while (((g.nslots + (1ull << shift) - 1) >> shift) > LIST_CHUNKS) shift++;
-		c->lc = ListChunks{c->list_cnt, c->list_cnt + LIST_CHUNKS, (uint32_t)((g.nslots + (1ull << shift) - 1) >> shift), shift};
-	}
-	ca.lc = c->lc;
+	PerLane<SlotsArgs> SA;
+	PerLane<CellsArgs> CA;
+	PerLane<SlowArgs> WA;
+	PerLane<ScanArgs> NA;
+	static_assert(sizeof(PerLane<CellsArgs>) <= 3584 && sizeof(PerLane<SlowArgs>) <= 3584, "kernel argument segment");
+	memset(&SA, 0, sizeof SA); memset(&CA, 0, sizeof CA); memset(&WA, 0, sizeof WA); memset(&NA, 0, sizeof NA);
 	if (!c->cells_blocks) {  // (asked before anything of the tail is launched: nothing below can return between k_slots and k_scan_apply)
 		int per_cu = 0, cus = 0;
 		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cells, 256, 0));
 		HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
 		c->cells_blocks = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, cus);
 	}
-	// k_slots appends to live_list from Counters::live_cursor on, and k_scan_apply - the last kernel of a tail - leaves the
-	// cursor zero for the next.  A tail that was cut short (a launch error) leaves it wherever it was: the next one starts clean.
-	if (c->tail_incomplete) HIP_TRY(hipMemsetAsync(&c->d_ctr->live_cursor, 0, sizeof(uint32_t), st));
-	c->tail_incomplete = true;
-	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK)), dim3(256), 0, st, L.slice_hdr, lane_part(L, false), lane_part(L, true),
-	                   (uint32_t)nchunks, L.epoch, g.nslots, c->slot_base, c->d_ctr, c->lc, (unsigned long long *)(c->bsV + 2 * c->bs_cap), (uint32_t)(2 * scan_groups(c->bs_cap)), c->live_list, ca.live_cap);
-	L.tail_pending = false;  // k_slots has read this epoch's partial sums and cleared the half of the next one
+	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
+	bool boundaries = false;
+	for (int q = 0; q < n; q++) {
+		IsoLane &L = c->lanes[idx[q]];
+		TailSet &w = c->ts[sidx[q]];
+		const Params P = lane_params(c, isos[q]);
+		if (w.slot_base_cap < g.nslots) {
+			(void)hipFree(w.slot_base); (void)hipFree(w.live_list);
+			w.slot_base = nullptr; w.live_list = nullptr; w.slot_base_cap = 0;
+			HIP_TRY(hipMalloc(&w.slot_base, g.nslots * sizeof(uint2)));
+			HIP_TRY(hipMalloc(&w.live_list, g.nslots * sizeof(uint32_t)));
+			w.slot_base_cap = g.nslots;
+		}
+		{  // batch descriptors: every 64 records one, plus at most one partly filled batch per slice slot
+			const uint64_t need = w.entry_cap / 64 + g.nslots + 64;
+			if (w.batch_cap < need) {
+				(void)hipFree(w.batches);
+				w.batches = nullptr; w.batch_cap = 0;
+				HIP_TRY(hipMalloc(&w.batches, need * sizeof(BatchDesc)));
+				w.batch_cap = need;
+			}
+		}
+		set_lane(a, q, L, isos[q]);
+		boundaries |= !L.boundary_done;
+		CellsArgs &ca = CA.a[q];
+		ca.pack = L.pack ? L.pack : 1u;
+		ca.dev = 0;
+#ifdef MC33_DEV
+		ca.dev = env_u32("MC33_HIP_CELLS_DEV", 0);
+#endif
+		ca.G.p = c->d_grid; ca.G.pitch = (uint32_t)c->pitch; ca.G.z0 = c->desc.plane0; ca.G.slice = c->slice;
+		ca.P = P; ca.fast = c->d_fast; ca.pat = c->d_pat;
+		ca.ze = ze; ca.sd = g.sd;
+		ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.plane_fmt = L.plane_fmt; ca.slot_base = w.slot_base;
+		// the tag of this tail's row-segment counts; the array is cleared whenever the tags start over
+		if (w.tail_serial % SEG_TAGS == 0) HIP_TRY(hipMemsetAsync(w.seg_cnt, 0, w.seg_cap * 4, st));
+		const uint32_t seg_tag = w.tail_serial % SEG_TAGS + 1u;
+		w.tail_serial++;
+		ca.seg_tag = seg_tag;
+		ca.live_list = w.live_list; ca.live_cap = (uint32_t)std::min<uint64_t>(g.nslots, 0xFFFFFFFFull);
+		ca.epoch = L.epoch;
+		ca.seg_cnt = w.seg_cnt; ca.seg_dir = w.seg_dir;
+		ca.entries_a = w.entries_a; ca.entries_b = w.entries_b; ca.entry_seg = w.entry_seg; ca.slow_list = w.slow_list; ca.dirty_list = w.dirty_list;
+		ca.entry_cap = (uint32_t)w.entry_cap;
+		ca.batches = w.batches; ca.batch_cap = (uint32_t)std::min<uint64_t>(w.batch_cap, 0xFFFFFFFFull);
+		ca.ctr = w.d_ctr;
+		ca.trace = nullptr;
+		if (n == 1 && getenv("MC33_HIP_TRACE_CELLS")) {
+			(void)hipFree(c->trace_cells);
+			c->trace_cells = nullptr;
+			c->trace_cells_n = g.nslots;
+			HIP_TRY(hipMalloc(&c->trace_cells, g.nslots * 32));
+			HIP_TRY(hipMemsetAsync(c->trace_cells, 0, g.nslots * 32, st));
+			ca.trace = c->trace_cells;
+		}
+		{  // groups of slots for the slow / dirty lists: at most LIST_CHUNKS
+			uint32_t shift = 6;
+			while (((g.nslots + (1ull << shift) - 1) >> shift) > LIST_CHUNKS) shift++;
+			w.lc = ListChunks{w.list_cnt, w.list_cnt + LIST_CHUNKS, (uint32_t)((g.nslots + (1ull << shift) - 1) >> shift), shift};
+		}
+		ca.lc = w.lc;
+		const uint64_t nchunks = (L.slice_cap + SLOT_CHUNK - 1) / SLOT_CHUNK;
+		SA.a[q] = SlotsArgs{L.slice_hdr, lane_part(L, false), lane_part(L, true), (uint32_t)nchunks, L.epoch, w.slot_base, w.d_ctr, w.lc,
+		                    (unsigned long long *)(w.bsV + 2 * w.bs_cap), (uint32_t)(2 * scan_groups(w.bs_cap)), w.live_list, ca.live_cap};
+		SlowArgs &sa = WA.a[q];
+		sa.G = ca.G; sa.P = P;
+		sa.tab.lut = c->d_lut; sa.tab.rule_words = c->d_rules; sa.tab.rule_index = c->d_rule_index;
+		sa.z_emit = c->range.z_begin;
+		sa.entries_a = w.entries_a; sa.entries_b = w.entries_b; sa.entries_c = w.entries_c; sa.fast_b = c->d_fast_b; sa.entry_seg = w.entry_seg; sa.slow_list = w.slow_list;
+		sa.seg_cnt = w.seg_cnt; sa.seg_tag = seg_tag; sa.seg_dir = w.seg_dir; sa.dirty_list = w.dirty_list;
+		sa.lc = w.lc; sa.slot_base = w.slot_base;
+		sa.entry_cap = (uint32_t)w.entry_cap; sa.ctr = w.d_ctr;
+		uint64_t *grV = nb >= SCAN_GROUPED_FROM ? w.bsV + 2 * w.bs_cap : nullptr, *grT = grV ? grV + scan_groups(w.bs_cap) : nullptr;
+		NA.a[q] = ScanArgs{w.seg_cnt, seg_tag, w.bsV, w.bsT, grV, grT, w.seg_base, w.d_ctr};
+		// k_slots appends to live_list from Counters::live_cursor on, and k_scan_apply - the last kernel of a tail - leaves the
+		// cursor zero for the next.  A tail that was cut short (a launch error) leaves it wherever it was: the next one starts clean.
+		if (w.tail_incomplete) HIP_TRY(hipMemsetAsync(&w.d_ctr->live_cursor, 0, sizeof(uint32_t), st));
+		w.tail_incomplete = true;
+		w.ctr_published = false;  // (the counters of THIS tail are on the device until somebody brings them over)
+	}
+	const uint32_t ny = (uint32_t)n;
+	if (c->nbounds && boundaries && !(MC33_DEBUG_BITS(a) & 2u))  // (the lanes of a call are all fresh, or it is one lane)
+		hipLaunchKernelGGL(k_boundary, dim3((uint32_t)((c->nbounds + 3) / 4), ny), dim3(256), 0, st, a, c->d_bounds, (uint32_t)c->nbounds);
+	for (int q = 0; q < n; q++) c->lanes[idx[q]].boundary_done = true;  // (its slices are in the partial sums now: a repeated tail - more room for records - must not add them again)
+	hipLaunchKernelGGL(k_slots, dim3((uint32_t)((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK), ny), dim3(256), 0, st, SA, g.nslots);
+	for (int q = 0; q < n; q++) c->lanes[idx[q]].tail_pending = false;  // k_slots has read this epoch's partial sums and cleared the half of the next one
 	// (four times what the GPU holds at once: slices differ in length, and a block that starts late evens the waves out -
 	// 76 -> 66 us at 1024^3; a block per group of four slots, as until round 3, is 17 408 blocks there)
-	hipLaunchKernelGGL(k_cells, dim3((uint32_t)std::min<uint64_t>(g.cell_blocks, env_u32("MC33_HIP_CELLS_BLOCKS", 4u * c->cells_blocks))), dim3(256), 0, st, ca);
-	SlowArgs sa;
-	sa.G = a.G; sa.P = P;
-	sa.tab.lut = c->d_lut; sa.tab.rule_words = c->d_rules; sa.tab.rule_index = c->d_rule_index;
-	sa.z_emit = c->range.z_begin;
-	sa.entries_a = c->entries_a; sa.entries_b = c->entries_b; sa.entries_c = c->entries_c; sa.fast_b = c->d_fast_b; sa.entry_seg = c->entry_seg; sa.slow_list = c->slow_list;
-	sa.seg_cnt = c->seg_cnt; sa.seg_tag = seg_tag; sa.seg_dir = c->seg_dir; sa.dirty_list = c->dirty_list;
-	sa.lc = c->lc; sa.slot_base = c->slot_base;
-	sa.entry_cap = (uint32_t)c->entry_cap; sa.ctr = c->d_ctr;
+	hipLaunchKernelGGL(k_cells, dim3((uint32_t)std::min<uint64_t>(g.cell_blocks, env_u32("MC33_HIP_CELLS_BLOCKS", 4u * c->cells_blocks)), ny), dim3(256), 0, st, CA);
 	// (blocks beyond the lists end at once.  A grid sized from the last extraction's counts - 69 blocks instead of 1024 at 1024^3,
 	// whose 8 820 slow cells are 35 blocks' worth - changes nothing: 13.5 / 6 / 8.7 us either way.  What these kernels take is
 	// the chain of dependent loads of the cells that ARE slow, not their empty blocks; round 3)
 	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);
-	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks), dim3(256), 0, st, sa);
-	hipLaunchKernelGGL(k_slow_count, dim3(slow_blocks), dim3(256), 0, st, sa);
-	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks), dim3(256), 0, st, sa);
-	const uint32_t nb = (uint32_t)((c->nsegs + SCAN_CHUNK - 1) / SCAN_CHUNK);
-	uint64_t *grV = nb >= SCAN_GROUPED_FROM ? c->bsV + 2 * c->bs_cap : nullptr, *grT = grV ? grV + scan_groups(c->bs_cap) : nullptr;
-	hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, c->seg_cnt, seg_tag, c->nsegs, P, c->bsV, c->bsT, grV, grT);
-	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, c->seg_cnt, seg_tag, c->nsegs, P, c->bsV, c->bsT, grV, grT, c->seg_base, c->ghost_segs, c->d_ctr);
+	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
+	hipLaunchKernelGGL(k_slow_count, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
+	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
+	hipLaunchKernelGGL(k_scan_reduce, dim3(nb, ny), dim3(256), 0, st, NA, c->nsegs, c->P);
+	hipLaunchKernelGGL(k_scan_apply, dim3(nb, ny), dim3(256), 0, st, NA, c->nsegs, c->P, c->ghost_segs);
 	HIP_TRY(hipGetLastError());
-	c->tail_incomplete = false;
+	for (int q = 0; q < n; q++) c->ts[sidx[q]].tail_incomplete = false;
 	return 0;
 }
 
@@ -2935,24 +3033,30 @@ static bool same_range(const mc33hip_range &x, const mc33hip_range &y) {
 }
 
 // enqueue sweep + cell records + slow-cell planning + scans on the context's stream (no synchronisation).  When
-// mc33hip_sweep_many has already classified this isovalue over this range, its lane is used and nothing is streamed.
+// mc33hip_sweep_many has already classified this isovalue over this range, its lane is used and nothing is streamed - and
+// when it has made the tail ahead as well (the lane's own TailSet), nothing is enqueued at all: the counters are waiting.
 static int enqueue_count(mc33hip_ctx *c, bool rerun = false) {
 	const Params &P = c->P;
-	c->ctr_published = false;  // (the counters of THIS count are on the device until somebody brings them over)
 	hipStream_t st = c->stream;
 	if (int rc = plan_sweep(c, P.zs, c->range.z_end)) return rc;
 	SlotGeom g;
 	if (int rc = slot_geometry(c, g)) return rc;
 	IsoLane *L = nullptr;
-	if (rerun && c->cur_lane && c->lane_presweeped) L = c->cur_lane;  // same call, more room for records: the sweep's result stands
+	bool tail_made = false;
+	if (rerun && c->cur_lane && c->lane_presweeped) L = c->cur_lane;  // same call, more room for records: the sweep's result stands, the tail is made again
 	else
 		for (int k = 0; k < MC33_LANES && !L; k++)
 			if (c->lanes[k].swept && same_bits((real_t)c->lanes[k].iso, P.iso) && same_range(c->lanes[k].range, c->range) &&
-			    c->lanes[k].slice_cap >= g.nslots && c->lanes[k].edge_cap >= c->ntiles)
+			    c->lanes[k].slice_cap >= g.nslots && c->lanes[k].edge_cap >= c->ntiles) {
 				L = &c->lanes[k];
+				tail_made = L->tail_done;
+			}
 	if (c->timing_level > 0) HIP_TRY(hipEventRecord(c->ev[0], st));
 	if (L) {
-		L->swept = false;  // used once
+		// a sweep made ahead is used once when its tail is made here (in the shared set 0, which the next isovalue overwrites); a
+		// lane whose tail was made ahead as well - in a set of its own - stays good for any number of count / emit calls until the
+		// next mc33hip_sweep_many or a change of the grid (slabs: count all isovalues, ONE exchange of counts, then the emits)
+		if (!tail_made) { L->swept = false; L->tail_done = false; }
 		c->lane_presweeped = true;
 	} else {
 		L = &c->lanes[0];
@@ -2985,19 +3089,46 @@ static int enqueue_count(mc33hip_ctx *c, bool rerun = false) {
 		HIP_TRY(hipGetLastError());
 	}
 	c->cur_lane = L;
+	c->lane_pretailed = tail_made;
+	const int li = (int)(L - c->lanes);
 	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[1], st));
-	if (int rc = enqueue_tail(c, *L, g)) return rc;
+	if (tail_made) c->w = &c->ts[li];  // (made behind its sweep pass, in the lane's own set)
+	else {
+		// a tail made here works in the lane's own set when it has one (a repeated tail of a lane that had been made ahead), in set 0 otherwise
+		const int si = (rerun && c->w == &c->ts[li]) ? li : 0;
+		c->w = &c->ts[si];
+		if (int rc = ensure_set(c, *c->w)) return rc;
+		const double iso = (double)P.iso;
+		if (int rc = enqueue_tail(c, &li, &si, &iso, 1, g)) return rc;
+		if (si == li && rerun && c->lane_presweeped) { L->swept = true; L->tail_done = true; }  // (made again in its own set: good for further calls, as before)
+	}
 	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[2], st));
 	return 0;
 }
 
-// Sweeps for n isovalues over one range, SWEEP_MAXNI isovalues per pass over the grid; the count / extract calls that
-// follow (same isovalue, same range) find their lane and go straight to the tail.
+// Sweeps for n isovalues over one range, SWEEP_MAXNI isovalues per pass over the grid, and - when every isovalue can have a
+// TailSet of its own - their tails right behind each pass, one launch of each tail kernel per pass; the count / extract calls
+// that follow (same isovalue, same range) find their lane and have nothing left to do but emit.  (MC33_HIP_TAILS_AHEAD=0, or
+// not enough device memory for the sets: sweeps only, the tails at the calls, in set 0 - as until round 4.)
 static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n) {
 	hipStream_t st = c->stream;
 	if (int rc = plan_sweep(c, c->P.zs, c->range.z_end)) return rc;
 	SlotGeom g;
 	if (int rc = slot_geometry(c, g)) return rc;
+	const char *ta = getenv("MC33_HIP_TAILS_AHEAD");
+	bool tails_ahead = !ta || atoi(ta) != 0;
+	if (tails_ahead) {
+		// records to make room for in a new set: what the last extraction of this context needed
+		uint64_t hint = 0;
+		for (int k = 0; k < MC33_LANES; k++) hint = std::max<uint64_t>(hint, c->ts[k].records_hint);
+		for (int k = 0; k < n && tails_ahead; k++)
+			if (ensure_set(c, c->ts[k], hint) != 0) {  // (out of device memory: no sets beyond the first, no tails ahead)
+				for (int j = 1; j <= k; j++) free_set(c->ts[j]);
+				(void)hipGetLastError();
+				tails_ahead = false;
+			}
+		if (!tails_ahead) { if (int rc = ensure_set(c, c->ts[0])) return rc; }
+	}
 	int k = 0, pass = 0;
 	while (k < n) {
 		const int ni = (n - k >= 4) ? 4 : (n - k >= 2) ? 2 : 1;
@@ -3014,11 +3145,18 @@ static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n) {
 		const uint32_t pack = ni == 4 ? launch_sweep_ni<4>(c, a, st) : ni == 2 ? launch_sweep_ni<2>(c, a, st) : launch_sweep_ni<1>(c, a, st);
 		HIP_TRY(hipGetLastError());
 		if (timed) HIP_TRY(hipEventRecord(c->ev_many[pass][1], st));
+		int idx[SWEEP_MAXNI];
 		for (int q = 0; q < ni; q++) {
 			IsoLane &L = c->lanes[k + q];
-			L.swept = true; L.tail_pending = true; L.iso = isos[k + q]; L.range = c->range; L.pack = pack;
+			L.swept = true; L.tail_pending = true; L.tail_done = false; L.iso = isos[k + q]; L.range = c->range; L.pack = pack;
 			L.many_pass = timed ? pass : -1; L.many_ni = ni;
+			idx[q] = k + q;
 		}
+		if (tails_ahead) {
+			if (int rc = enqueue_tail(c, idx, idx, isos + k, ni, g)) return rc;
+			for (int q = 0; q < ni; q++) c->lanes[k + q].tail_done = true;
+		}
+		if (timed) HIP_TRY(hipEventRecord(c->ev_many[pass][2], st));
 		k += ni;
 		pass++;
 	}
@@ -3030,20 +3168,20 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	a.c.tab.lut = c->d_lut; a.c.tab.rule_words = c->d_rules; a.c.tab.rule_index = c->d_rule_index;
 	a.c.P = c->P;
 	a.c.G.p = c->d_grid; a.c.G.pitch = (uint32_t)c->pitch; a.c.G.z0 = c->desc.plane0; a.c.G.slice = c->slice;
-	a.c.seg_base = c->seg_base; a.c.seg_dir = c->seg_dir;
-	a.c.entries_a = c->entries_a; a.c.entries_b = c->entries_b; a.c.entries_c = c->entries_c; a.c.fast_b = c->d_fast_b; a.c.fast_b_in_lds = false; a.c.entry_seg = c->entry_seg;
+	a.c.seg_base = c->w->seg_base; a.c.seg_dir = c->w->seg_dir;
+	a.c.entries_a = c->w->entries_a; a.c.entries_b = c->w->entries_b; a.c.entries_c = c->w->entries_c; a.c.fast_b = c->d_fast_b; a.c.fast_b_in_lds = false; a.c.entry_seg = c->w->entry_seg;
 	a.c.V = (real_t *)dV; a.c.N = (float *)dN; a.c.Tri = (uint32_t *)dT;
 	a.c.z_emit = c->range.z_begin; a.c.v_skip = a.c.t_skip = a.c.id_delta = 0;
-	a.ctr = c->d_ctr;
-	a.slow_list = c->slow_list;
-	a.lc = c->lc; a.slot_base = c->slot_base;
-	a.entry_cap = (uint32_t)c->entry_cap;
+	a.ctr = c->w->d_ctr;
+	a.slow_list = c->w->slow_list;
+	a.lc = c->w->lc; a.slot_base = c->w->slot_base;
+	a.entry_cap = (uint32_t)c->w->entry_cap;
 	a.capV = capV; a.capT = capT;
 	a.ghost_segs = c->ghost_segs;
 	a.id_base = c->range.id_base;
-	a.batches = c->batches; a.batch_cap = (uint32_t)std::min<uint64_t>(c->batch_cap, 0xFFFFFFFFull);
-	a.host_ctr = c->h_ctr;  // (hipHostMalloc'ed: the same address on the device)
-	c->ctr_published = true;
+	a.batches = c->w->batches; a.batch_cap = (uint32_t)std::min<uint64_t>(c->w->batch_cap, 0xFFFFFFFFull);
+	a.host_ctr = c->w->h_ctr;  // (hipHostMalloc'ed: the same address on the device)
+	c->w->ctr_published = true;
 	// rows may be staged in 16-byte chunks when every row of the grid starts on a 16-byte boundary (always so for the library's
 	// own copy; a caller's device buffer may have any pitch: its records then load for themselves)
 	a.stage_rows = ((uintptr_t)c->d_grid % 16u) == 0 && (c->pitch * sizeof(sample_t)) % 16u == 0 && (c->slice * sizeof(sample_t)) % 16u == 0 &&
@@ -3051,7 +3189,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	// The triangle pass is fastest with a thread per record (C5, 14.4 M records: 16 384 / 32 768 / 65 536 blocks 392 / 363 /
 	// 352 us; C3, 3.9 M: 2 048 / 4 096 / 8 192 / 16 384 blocks 106 / 98 / 93 / 88 us).  How many records this extraction has is
 	// on the device only: the grid follows the last extraction whose counters were read, 16 384 blocks at least.
-	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", std::max(256u * 64u, std::min(1u << 20, ((c->records_hint + 255u) / 256u + 7u) & ~7u)));
+	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", std::max(256u * 64u, std::min(1u << 20, ((c->w->records_hint + 255u) / 256u + 7u) & ~7u)));
 	if (!c->cus) HIP_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, c->device));
 	// The three emit passes are independent (V/N vs T, fast vs slow records).  While each of them waited through a chain of
 	// dependent loads (rounds 1 and most of 2) running them side by side on three streams paid on large grids (0.15 instead
@@ -3105,16 +3243,16 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 
 static int fetch_counters(mc33hip_ctx *c) {
 	// (after an emit pass the triangle kernel has already written them into h_ctr: only the wait is left)
-	if (!c->ctr_published) HIP_TRY(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
-	c->ctr_published = false;
+	if (!c->w->ctr_published) HIP_TRY(hipMemcpyAsync(c->w->h_ctr, c->w->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+	c->w->ctr_published = true;  // (h_ctr matches the set's counters until the next tail into this set: enqueue_tail)
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	c->records_hint = c->h_ctr->entry_cursor == 0xFFFFFFFFu ? 0u : c->h_ctr->entry_cursor;
+	c->w->records_hint = c->w->h_ctr->entry_cursor == 0xFFFFFFFFu ? 0u : c->w->h_ctr->entry_cursor;
 	if (getenv("MC33_HIP_VERBOSE"))
-		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, record batches %u)\n", c->h_ctr->entry_cursor,
-		        c->h_ctr->slow_cursor, c->h_ctr->dirty_cursor, c->h_ctr->batch_cursor);
-	if (c->h_ctr->debug[0])
-		fprintf(stderr, "[mc33hip] DEBUG words %u: first %u count %u z %u y0 %u xbase %u batch %u of %u\n", c->h_ctr->debug[0], c->h_ctr->debug[1], c->h_ctr->debug[2],
-		        c->h_ctr->debug[3], c->h_ctr->debug[4], c->h_ctr->debug[5], c->h_ctr->debug[6], c->h_ctr->debug[7]);
+		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, record batches %u)\n", c->w->h_ctr->entry_cursor,
+		        c->w->h_ctr->slow_cursor, c->w->h_ctr->dirty_cursor, c->w->h_ctr->batch_cursor);
+	if (c->w->h_ctr->debug[0])
+		fprintf(stderr, "[mc33hip] DEBUG words %u: first %u count %u z %u y0 %u xbase %u batch %u of %u\n", c->w->h_ctr->debug[0], c->w->h_ctr->debug[1], c->w->h_ctr->debug[2],
+		        c->w->h_ctr->debug[3], c->w->h_ctr->debug[4], c->w->h_ctr->debug[5], c->w->h_ctr->debug[6], c->w->h_ctr->debug[7]);
 	if (c->trace_cells && getenv("MC33_HIP_TRACE_CELLS")) {
 		void *h = malloc(c->trace_cells_n * 32);
 		if (h && hipMemcpy(h, c->trace_cells, c->trace_cells_n * 32, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -3135,7 +3273,7 @@ static int fetch_counters(mc33hip_ctx *c) {
 }
 
 static int finish_counts(mc33hip_ctx *c, mc33hip_counts *out) {
-	const Counters &h = *c->h_ctr;
+	const Counters &h = *c->w->h_ctr;
 	const uint64_t gV = c->ghost_segs ? h.ghostV : 0, gT = c->ghost_segs ? h.ghostT : 0;
 	c->counts.nV = h.totV - gV; c->counts.nT = h.totT - gT;
 	c->counts.nV_ghost = gV; c->counts.nT_ghost = gT;
@@ -3169,6 +3307,12 @@ static void read_timing(mc33hip_ctx *c, bool with_emit, unsigned launches) {
 			t.sweep_ms += ms;
 			t.total_ms += ms;
 		}
+		// ... and of the tails made behind that pass, one launch of each kernel for its NI isovalues
+		if (c->lane_pretailed && hipEventElapsedTime(&ms, c->ev_many[c->cur_lane->many_pass][1], c->ev_many[c->cur_lane->many_pass][2]) == hipSuccess) {
+			ms /= (float)c->cur_lane->many_ni;
+			t.scan_ms += ms;
+			t.total_ms += ms;
+		}
 	}
 }
 
@@ -3185,8 +3329,8 @@ extern "C" int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *ra
 		if ((rc = enqueue_count(c, launches > 0))) return rc;
 		launches++;
 		if ((rc = fetch_counters(c))) return rc;
-		if (c->h_ctr->entry_cursor <= c->entry_cap) break;
-		if ((rc = grow_entries(c, c->h_ctr->entry_cursor))) return rc;
+		if (c->w->h_ctr->entry_cursor <= c->w->entry_cap) break;
+		if ((rc = grow_entries(*c->w, c->w->h_ctr->entry_cursor))) return rc;
 	}
 	read_timing(c, false, launches);
 	if ((rc = finish_counts(c, out))) return rc;
@@ -3258,13 +3402,13 @@ extern "C" int mc33hip_extract(mc33hip_ctx *c, double iso, const mc33hip_range *
 		launches++;
 		if ((rc = enqueue_emit(c, dV, dN, dT, capV, capT))) return rc;  // checks capacities on the device
 		if ((rc = fetch_counters(c))) return rc;
-		if (c->h_ctr->entry_cursor <= c->entry_cap) break;
-		if ((rc = grow_entries(c, c->h_ctr->entry_cursor))) return rc;
+		if (c->w->h_ctr->entry_cursor <= c->w->entry_cap) break;
+		if ((rc = grow_entries(*c->w, c->w->h_ctr->entry_cursor))) return rc;
 	}
 	read_timing(c, true, launches);
 	if ((rc = finish_counts(c, out))) return rc;
 	c->counted = true;
-	if (c->h_ctr->emit_skipped) { set_err("output buffers too small: need %llu vertices, %llu triangles", c->counts.nV, c->counts.nT); return MC33HIP_ECAPACITY; }
+	if (c->w->h_ctr->emit_skipped) { set_err("output buffers too small: need %llu vertices, %llu triangles", c->counts.nV, c->counts.nT); return MC33HIP_ECAPACITY; }
 	return MC33HIP_OK;
 }
 
@@ -3313,7 +3457,7 @@ extern "C" int mc33hip_probe_read(mc33hip_ctx *c, int reps, float *ms_best, floa
 	std::vector<float> t;
 	for (int k = 0; k < reps + 1; k++) {  // (the first launch is a warm-up)
 		(void)hipEventRecord(e0, c->stream);
-		hipLaunchKernelGGL(k_probe_read, dim3((uint32_t)std::max(1, c->cus) * 8u), dim3(256), 0, c->stream, p, n16, (uint32_t *)&c->d_ctr->debug[7]);
+		hipLaunchKernelGGL(k_probe_read, dim3((uint32_t)std::max(1, c->cus) * 8u), dim3(256), 0, c->stream, p, n16, (uint32_t *)nullptr);
 		(void)hipEventRecord(e1, c->stream);
 		if (hipEventSynchronize(e1) != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); set_err("k_probe_read failed"); return MC33HIP_ERUNTIME; }
 		float ms = 0.f;
@@ -3332,7 +3476,7 @@ extern "C" int mc33hip_probe_read(mc33hip_ctx *c, int reps, float *ms_best, floa
 extern "C" int mc33hip_debug_words(mc33hip_ctx *c, unsigned int *out /*[8]*/) {  // what a guarded kernel found wrong (developer builds)
 	if (!c || !out) return MC33HIP_EINVAL;
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	HIP_TRY(hipMemcpy(out, (const char *)c->d_ctr + offsetof(Counters, debug), 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(out, (const char *)c->w->d_ctr + offsetof(Counters, debug), 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	return MC33HIP_OK;
 }
 #endif
