@@ -267,7 +267,7 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True, capi=F
     dist = E.dist
     from mc33_c_library_amd import DeviceGrid
     from mc33_c_library_amd.fields import cos_field_slab, cos_field_u16
-    from mc33_c_library_amd.slabs import Slab, SurfaceExchange, extract_slab
+    from mc33_c_library_amd.slabs import Slab, SurfaceExchange, extract_slab, extract_slab_many
     world, rank, dev, multi, rehearsal, all_reduce = E.world, E.rank, E.dev, E.multi, E.rehearsal, E.all_reduce
     steps = steps if steps is not None else args.steps
     warmup = warmup if warmup is not None else args.warmup
@@ -330,6 +330,8 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True, capi=F
 
     # c5 is an iso sweep over ONE resident grid: classify the 8 isovalues together (MC33_BENCH_SWEEP_MANY=0: eight independent calls)
     sweep_many = len(isos) > 1 and os.environ.get("MC33_BENCH_SWEEP_MANY", "1") != "0"
+    # N > 1: count all isovalues, exchange ALL counts in one collective, then emit (MC33_BENCH_COUNT_ALL=0: one count exchange per isovalue)
+    count_all = os.environ.get("MC33_BENCH_COUNT_ALL", "1") != "0"
     sweep_ms, scan_ms, emit_ms, step_ms = [], [], [], []
     state = {"step": 0, "counts": None, "b": 0}
 
@@ -338,6 +340,18 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True, capi=F
         timed steps (host clock per step kept), 2 the steps with the library's events on (kernel split kept)"""
         nV = nT = 0
         t0 = time.perf_counter()
+        if sweep_many and multi and count_all:
+            # z-slabs: the counts of all isovalues in ONE exchange per step, then the emits (slabs.extract_slab_many)
+            def kernel_split(i):
+                if record == 2:
+                    t = grid.timing()
+                    sweep_ms.append(t.sweep_ms); scan_ms.append(t.scan_ms)
+            res = extract_slab_many(grid, slab, ex, isos, b0=state["step"] % nbuf, async_op=overlap, on_emitted=kernel_split)
+            state["step"] += len(isos)
+            state["counts"], state["b"] = res[-1][0], (state["step"] - 1) % nbuf
+            if record == 1:
+                step_ms.append((time.perf_counter() - t0) * 1e3)
+            return sum(c.nV for _, c in res), sum(c.nT for _, c in res)
         if sweep_many:  # iso sweep: the volume is streamed once per 4 isovalues, the calls below find their sweep made
             grid.sweep_many(isos, slab.range())
         for iso in isos:

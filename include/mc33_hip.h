@@ -93,15 +93,21 @@ int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *range, mc33hi
 
 /* Iso sweep over the resident grid (BASELINE.json configs[4]; the caller of calculate_isosurfaces): classifies the
  * samples against n <= 8 isovalues while streaming the volume ONCE per 4 isovalues, instead of once per isovalue as n
- * separate calls do (the reference re-reads all of F for every isovalue, MC:1832-1868), and makes everything else a count
- * needs - record ranges, cell records, prefix sums - right behind each pass, one launch of every kernel for the 4 isovalues
- * of the pass, each isovalue into buffers of its own.  Nothing is returned: the mc33hip_count / mc33hip_extract calls that
- * follow with one of these isovalues and the same range find all of that made and only fetch the counters / emit - any
- * number of times, in any order (z-slabs: count all isovalues, exchange ALL counts at once, then emit each at its global id
- * base), until the next mc33hip_sweep_many or a change of the grid.  Asynchronous on the context's stream.
- * (MC33_HIP_TAILS_AHEAD=0 in the environment, or too little device memory for the per-isovalue buffers: only the sweeps are
- * made ahead, each is used by ONE count / extract call, which runs the remaining passes itself.) */
+ * separate calls do (the reference re-reads all of F for every isovalue, MC:1832-1868).  Nothing is returned: the
+ * mc33hip_count / mc33hip_extract calls that follow with one of these isovalues and the same range find the sweep
+ * already made and only run the passes after it.  A sweep made ahead is used once and is dropped when the grid changes.
+ * Asynchronous on the context's stream. */
 int mc33hip_sweep_many(mc33hip_ctx *c, const double *isos, int n, const mc33hip_range *range);
+
+/* The same, and everything else a count needs as well - record ranges, cell records, prefix sums - right behind each pass
+ * over the grid, one launch of every kernel for the 4 isovalues of the pass, each isovalue into buffers of its own.  The
+ * mc33hip_count calls that follow only fetch counters, mc33hip_emit / mc33hip_extract only emit - in any order, any number
+ * of times, until the next mc33hip_prepare_many / mc33hip_sweep_many or a change of the grid.  For callers that need the
+ * counts of ALL isovalues before the first emit: z-slabs over several GPUs exchange them in ONE collective per step and
+ * then emit every isovalue at its global id base (mc33_c_library_amd/slabs.py: extract_slab_many).  On one GPU
+ * mc33hip_sweep_many + mc33hip_extract per isovalue is faster: an emit right behind its own tail finds the records in the
+ * last-level cache.  Falls back to mc33hip_sweep_many when device memory does not allow the buffers. */
+int mc33hip_prepare_many(mc33hip_ctx *c, const double *isos, int n, const mc33hip_range *range);
 
 /* Global number of the first vertex of the range last counted (z-slab decomposition: known only after
  * the ranks have exchanged their counts).  Takes effect in the next mc33hip_emit. */

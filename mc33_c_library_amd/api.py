@@ -35,7 +35,7 @@ class Timing(C.Structure):
 HIP_API = ["mc33hip_set_id_base", "mc33hip_create", "mc33hip_destroy", "mc33hip_last_error", "mc33hip_upload_rows",
            "mc33hip_upload_contiguous", "mc33hip_adopt_device", "mc33hip_set_stream", "mc33hip_count",
            "mc33hip_emit", "mc33hip_extract", "mc33hip_last_timing", "mc33hip_download",
-           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many", "mc33hip_set_normal_neg", "mc33hip_sweep_many", "mc33hip_set_timing", "mc33hip_probe_read"]
+           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many", "mc33hip_set_normal_neg", "mc33hip_sweep_many", "mc33hip_set_timing", "mc33hip_probe_read", "mc33hip_prepare_many"]
 REFERENCE_API = ["create_MC33", "calculate_isosurface", "size_of_isosurface", "free_MC33", "free_surface_memory",
                  "adjustvectorlenght_s", "DefaultColorMC", "free_memory_grd", "alloc_F", "grid_from_data_pointer",
                  "generate_grid_from_fn", "_multTSA_bf", "_multA_bf", "mult_Abf",
@@ -91,6 +91,7 @@ def load_library(dtype="f32"):
     lib.mc33hip_set_normal_neg.argtypes = [V, C.c_int]
     lib.mc33hip_sweep_many.argtypes = [V, P(C.c_double), C.c_int, P(Range)]
     lib.mc33hip_set_timing.argtypes = [V, C.c_int]
+    lib.mc33hip_prepare_many.argtypes = [V, P(C.c_double), C.c_int, P(Range)]
     lib.mc33hip_probe_read.argtypes = [V, C.c_int, P(C.c_float), P(C.c_float), P(C.c_ulonglong)]
     _libs[dtype] = lib
     return lib
@@ -175,6 +176,13 @@ class DeviceGrid:
         rng = rng or self.full_range()
         arr = (C.c_double * len(isos))(*[float(x) for x in isos])
         _check(self.lib, self.lib.mc33hip_sweep_many(self.ctx, arr, len(isos), C.byref(rng)))
+
+    def prepare_many(self, isos, rng=None):
+        """sweep_many plus everything else a count needs, every isovalue into buffers of its own: count / emit_into for these
+        isovalues then run in any order, any number of times (slabs: all counts first, ONE exchange, then the emits)."""
+        rng = rng or self.full_range()
+        arr = (C.c_double * len(isos))(*[float(x) for x in isos])
+        _check(self.lib, self.lib.mc33hip_prepare_many(self.ctx, arr, len(isos), C.byref(rng)))
 
     def extract_into(self, iso, V, N, T, rng=None):
         """One extraction into caller-owned device tensors V, N [capV,3] float32 and T [capT,3] int32.

@@ -3089,34 +3089,42 @@ static int enqueue_count(mc33hip_ctx *c, bool rerun = false) {
 		HIP_TRY(hipGetLastError());
 	}
 	c->cur_lane = L;
-	c->lane_pretailed = tail_made;
+	if (!rerun) c->lane_pretailed = tail_made;  // (a repeated count of the same call: the lane still has its own set)
 	const int li = (int)(L - c->lanes);
 	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[1], st));
 	if (tail_made) c->w = &c->ts[li];  // (made behind its sweep pass, in the lane's own set)
 	else {
-		// a tail made here works in the lane's own set when it has one (a repeated tail of a lane that had been made ahead), in set 0 otherwise
-		const int si = (rerun && c->w == &c->ts[li]) ? li : 0;
+		// a tail made here works in the lane's own set when it has one (a repeated tail - more room for records - of a lane that had
+		// been made ahead), in set 0 otherwise
+		const int si = (rerun && c->lane_pretailed) ? li : 0;
 		c->w = &c->ts[si];
 		if (int rc = ensure_set(c, *c->w)) return rc;
 		const double iso = (double)P.iso;
 		if (int rc = enqueue_tail(c, &li, &si, &iso, 1, g)) return rc;
-		if (si == li && rerun && c->lane_presweeped) { L->swept = true; L->tail_done = true; }  // (made again in its own set: good for further calls, as before)
+		if (rerun && c->lane_pretailed) { L->swept = true; L->tail_done = true; }  // (made again in its own set: good for further calls, as before)
 	}
 	if (c->timing_level > 1) HIP_TRY(hipEventRecord(c->ev[2], st));
 	return 0;
 }
 
-// Sweeps for n isovalues over one range, SWEEP_MAXNI isovalues per pass over the grid, and - when every isovalue can have a
-// TailSet of its own - their tails right behind each pass, one launch of each tail kernel per pass; the count / extract calls
-// that follow (same isovalue, same range) find their lane and have nothing left to do but emit.  (MC33_HIP_TAILS_AHEAD=0, or
-// not enough device memory for the sets: sweeps only, the tails at the calls, in set 0 - as until round 4.)
-static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n) {
+// Sweeps for n isovalues over one range, SWEEP_MAXNI isovalues per pass over the grid; the count / extract calls that follow
+// (same isovalue, same range) find their lane and go straight to the tail.  tails_ahead (mc33hip_prepare_many): the tails
+// too, right behind each pass, one launch of each tail kernel per pass, every isovalue into a TailSet of its own - the calls
+// then have nothing left to do but fetch the counters / emit, in any order, any number of times (when there is not enough
+// device memory for the sets: sweeps only, as without the flag).
+// Measured (round 4, 2048 x 2048 x 1024 ushort, 8 isovalues, profiles/r04_tails_ahead.txt): the batched tails take 0.29 ms per
+// isovalue instead of 0.345 (k_cells 188 us per isovalue instead of 214, k_boundary 16 instead of 23; the scans gain nothing),
+// but the vertex pass of an isovalue whose records were written eight tails ago instead of just now takes 30 % longer (avg
+// 575 instead of 442 us: its per-batch chain of record and row-base fetches finds them in HBM instead of the 256 MB
+// last-level cache) - 14.2 ms per step against 13.2.  So a single GPU keeps tail and emit of an isovalue adjacent
+// (mc33hip_sweep_many), and the sets are for callers that need ALL counts before the first emit (z-slabs over several GPUs:
+// one exchange of counts per step instead of one per isovalue).
+static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n, bool tails_ahead) {
 	hipStream_t st = c->stream;
 	if (int rc = plan_sweep(c, c->P.zs, c->range.z_end)) return rc;
 	SlotGeom g;
 	if (int rc = slot_geometry(c, g)) return rc;
-	const char *ta = getenv("MC33_HIP_TAILS_AHEAD");
-	bool tails_ahead = !ta || atoi(ta) != 0;
+	if (const char *ta = getenv("MC33_HIP_TAILS_AHEAD")) tails_ahead = atoi(ta) != 0;  // (developer A/B of the two flows)
 	if (tails_ahead) {
 		// records to make room for in a new set: what the last extraction of this context needed
 		uint64_t hint = 0;
@@ -3346,7 +3354,18 @@ extern "C" int mc33hip_sweep_many(mc33hip_ctx *c, const double *isos, int n, con
 	c->counted = false;
 	fill_params(c, isos[0], range);
 	if ((rc = ensure_workspaces(c))) return rc;
-	return enqueue_sweep_many(c, isos, n);
+	return enqueue_sweep_many(c, isos, n, false);
+}
+
+extern "C" int mc33hip_prepare_many(mc33hip_ctx *c, const double *isos, int n, const mc33hip_range *range) {
+	if (!c || !isos || n < 1 || n > MC33_LANES) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	if ((rc = check_range(c, range))) return rc;
+	c->counted = false;
+	fill_params(c, isos[0], range);
+	if ((rc = ensure_workspaces(c))) return rc;
+	return enqueue_sweep_many(c, isos, n, true);
 }
 
 extern "C" int mc33hip_set_inclined(mc33hip_ctx *c, const double *grd_A, const double *grd_Ai, int triangular) {

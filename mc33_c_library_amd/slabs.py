@@ -82,6 +82,20 @@ class SurfaceExchange:
         c = self.counts_dev.view(self.world, 2).tolist()
         return [(int(a), int(b)) for a, b in c]
 
+    def exchange_counts_many(self, mine):
+        """mine: [(nV, nT)] of this rank for k isovalues -> per isovalue [(nV, nT)] of all ranks, in ONE collective (an iso sweep
+        over z-slabs then has one host-synchronised exchange per step instead of one per isovalue)."""
+        import torch
+        import torch.distributed as dist
+        k = len(mine)
+        dev = self.counts_dev.device
+        if getattr(self, "_many", None) is None or self._many.numel() != self.world * 2 * k:
+            self._many = torch.zeros(self.world * 2 * k, dtype=torch.int64, device=dev)
+        flat = torch.tensor([x for c in mine for x in c], dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(self._many, flat, group=None if self.host else self.count_group)
+        rows = self._many.view(self.world, k, 2).tolist()
+        return [[(int(rows[r][i][0]), int(rows[r][i][1])) for r in range(self.world)] for i in range(k)]
+
     @staticmethod
     def bases(counts, rank):
         return sum(c[0] for c in counts[:rank]), sum(c[1] for c in counts[:rank])
@@ -187,3 +201,27 @@ def extract_slab(grid, slab, exchange, iso, b=0, async_op=False):
     grid.emit_into(V, N, T, id_base)
     exchange.start(b, counts, async_op=async_op)
     return counts, c
+
+
+def extract_slab_many(grid, slab, exchange, isos, b0=0, async_op=False, on_emitted=None):
+    """An iso sweep over a z-slabbed volume on this rank (BASELINE configs[4] on N GPUs): the slab is streamed once per 4
+    isovalues and everything a count needs is made behind each pass (DeviceGrid.prepare_many), the counts of ALL isovalues
+    are exchanged in ONE collective, then every isovalue is emitted at its global vertex base and its surface arrays are
+    exchanged (buffer sets b0, b0 + 1, ... in turn; on_emitted(i) is called behind each isovalue's emit).  Returns [(counts of all ranks, this rank's Counts)] per isovalue."""
+    grid.prepare_many(isos, slab.range())
+    mine = [grid.count(iso, slab.range()) for iso in isos]           # (made already: these only fetch the counters)
+    allc = exchange.exchange_counts_many([(c.nV, c.nT) for c in mine])
+    out = []
+    for i, iso in enumerate(isos):
+        b = (b0 + i) % exchange.nbuf
+        exchange.wait(b)
+        counts = allc[i]
+        grid.count(iso, slab.range())                                # selects the isovalue's buffers for the emit (nothing is computed)
+        id_base, _ = exchange.bases(counts, slab.rank)
+        V, N, T = exchange.targets(b, counts)
+        grid.emit_into(V, N, T, id_base)
+        exchange.start(b, counts, async_op=async_op)
+        if on_emitted is not None:
+            on_emitted(i)
+        out.append((counts, mine[i]))
+    return out

@@ -203,6 +203,64 @@ def test_sweep_many_equals_single_sweeps(reflibs, dtype):
     assert np.array_equal(N0.cpu().numpy()[~nan].view(np.uint32), ref.N[~nan].view(np.uint32))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "u16mix", "u8"])
+def test_prepare_many_counts_first_then_emits_in_any_order(reflibs, dtype):
+    """mc33hip_prepare_many makes the sweeps AND the tails of up to 8 isovalues ahead, one launch of every tail kernel per pass
+    for its 4 isovalues, each isovalue into buffers of its own: all counts can be read before the first emit (z-slabs: one
+    exchange of counts per step), the emits come in any order, any number of times, also at another id base - and equal the
+    reference's arrays.  7 isovalues = passes of 4 + 2 + 1; a slab with a ghost slice; a capacity that is too small."""
+    import torch
+    from mc33_c_library_amd import DeviceGrid, Range
+    if dtype == "f32":
+        data, isos = fx.noise_quant(0, 3, shape=(40, 70, 300)), [0.0, 1.0, -1.0, 0.5, 1.5, -0.5, 2.0]
+    elif dtype == "u16mix":
+        data, isos, dtype = fx.cos_field_u16(300, 130, 50), [25268.0, 15268.5, 32768.0, 70000.0, -5.0, 40000.0, 30268.5], "u16"
+    else:
+        data, isos = fx.noise_u8(0, 4, 5, shape=(30, 66, 258)), [2.0, 1.5, 3.0, 2.5, 1.0]
+    t = torch.from_numpy(data).cuda()
+    if t.dtype == torch.uint16:
+        t = t.view(torch.int16)
+    g = DeviceGrid(t)
+    refs = [reflibs[dtype].isosurface(data, iso) for iso in isos]
+    for rep in range(2):
+        g.prepare_many(isos)
+        cnts = [g.count(iso) for iso in isos]                       # all counts before the first emit
+        for c, r in zip(cnts, refs):
+            assert (c.nV, c.nT) == (r.nV, r.nT)
+        order = list(range(len(isos)))[::-1] + [1, 1, 0]              # backwards, then some of them again
+        for k in order:
+            c = g.count(isos[k])                                    # selects the isovalue's buffers; nothing is computed
+            assert (c.nV, c.nT) == (refs[k].nV, refs[k].nT)
+            V = torch.empty((max(c.nV, 1), 3), dtype=torch.float32, device="cuda"); N = torch.empty_like(V)
+            T = torch.empty((max(c.nT, 1), 3), dtype=torch.int32, device="cuda")
+            base = 1000 * rep
+            g.emit_into(V, N, T, base)
+            torch.cuda.synchronize()
+            r = refs[k]
+            assert np.array_equal(T.cpu().numpy().view(np.uint32)[:r.nT], r.T + np.uint32(base)), (dtype, isos[k])
+            assert beq(V.cpu().numpy()[:r.nV], r.V)
+            nan = np.isnan(r.N)
+            assert np.array_equal(N.cpu().numpy()[:r.nV][~nan].view(np.uint32), r.N[~nan].view(np.uint32))
+    # extract (count + emit in one call) on a prepared isovalue, with too little room first
+    g.prepare_many(isos[:3])
+    small = torch.empty((4, 3), dtype=torch.float32, device="cuda")
+    cnt, ok = g.extract_into(isos[1], small, torch.empty_like(small), torch.empty((4, 3), dtype=torch.int32, device="cuda"))
+    assert (not ok or refs[1].nV <= 4) and (cnt.nV, cnt.nT) == (refs[1].nV, refs[1].nT)
+    _same_as_reference(g.extract(isos[1]), refs[1], "prepared isovalue after a refused emit")
+    _same_as_reference(g.extract(isos[2]), refs[2], "prepared isovalue through extract")
+    # a slab with a ghost slice; an isovalue that was not prepared sweeps for itself
+    nz = data.shape[0] - 1
+    rng = Range(nz // 2, nz, 1, 0)
+    g.prepare_many(isos[:5], rng)
+    g2 = DeviceGrid(t)
+    for k in (4, 0, 2):
+        V1, N1, T1, c1 = g.extract(isos[k], rng)
+        V2, N2, T2, c2 = g2.extract(isos[k], rng)
+        assert (c1.nV, c1.nT) == (c2.nV, c2.nT) and torch.equal(T1, T2) and torch.equal(V1.view(torch.int32), V2.view(torch.int32))
+    _same_as_reference(g.extract(isos[-1]), refs[-1], "whole volume after prepared slabs")
+    g.close(); g2.close()
+
+
 def _same_as_reference(got, ref, what):
     V, N, T, cnt = got
     assert (cnt.nV, cnt.nT) == (ref.nV, ref.nT), what

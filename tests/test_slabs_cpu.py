@@ -21,7 +21,7 @@ WORKER = textwrap.dedent('''
     sys.path.insert(0, %r); sys.path.insert(0, %r)
     import fixtures as fx
     from mc33_emu import Emu
-    from mc33_c_library_amd.slabs import Slab, SurfaceExchange, extract_slab, MODES
+    from mc33_c_library_amd.slabs import Slab, SurfaceExchange, extract_slab, extract_slab_many, MODES
 
     class EmuGrid:
         """DeviceGrid's count / emit_into on the host emulator (tensors on the CPU)"""
@@ -35,6 +35,8 @@ WORKER = textwrap.dedent('''
         def count(self, iso, rng):
             self.iso = iso
             return self._run(iso, 0)
+        def prepare_many(self, isos, rng):
+            self.prepared = list(isos)
         def emit_into(self, V, N, T, id_base):
             s = self._run(self.iso, id_base)
             V[:s.nV] = torch.from_numpy(s.V); N[:s.nV] = torch.from_numpy(s.N); T[:s.nT] = torch.from_numpy(s.T.view(np.int32))
@@ -75,6 +77,25 @@ WORKER = textwrap.dedent('''
         else:
             assert ex.bytes_received == (sum(c[0] * 24 + c[1] * 12 for c in counts[1:]) if rank == 0 else 0)
         dist.barrier()
+    # an iso sweep over the slabs: ALL counts in one collective, then the emits (extract_slab_many)
+    isos = [0.0, 2.0, -3.5]
+    c0 = [grid.count(v, None) for v in isos]
+    caps = torch.tensor([max(c.nV for c in c0) + 7, max(c.nT for c in c0) + 5])
+    dist.all_reduce(caps, op=dist.ReduceOp.MAX)
+    ex = SurfaceExchange(world, rank, torch.device("cpu"), int(caps[0]), int(caps[1]), mode="pairs", nbuf=3, host_collectives=True)
+    res = extract_slab_many(grid, slab, ex, isos)
+    ex.drain()
+    assert grid.prepared == isos and len(res) == 3
+    for i, v in enumerate(isos):
+        counts, c = res[i]
+        assert counts[rank] == (c.nV, c.nT)
+        V, N, T = ex.concatenated(i, counts)
+        if rank == 0:
+            from mc33_capi import MC33Lib, ref_path
+            from mc33_oracle import Oracle
+            w = (MC33Lib(ref_path("f32"), "f32") if os.path.exists(ref_path("f32")) else Oracle("f32")).isosurface(data, v)
+            assert np.array_equal(T.numpy().view(np.uint32), w.T) and np.array_equal(V.numpy().view(np.uint32), w.V.view(np.uint32)), v
+    dist.barrier()
     if rank == 0:
         print("SLABS_OK", whole.nV, whole.nT)
     dist.destroy_process_group()
