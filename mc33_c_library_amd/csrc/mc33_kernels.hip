@@ -1803,8 +1803,18 @@ struct EmitVLds {                        // per wave
 // exactly their bytes) but 157 us, every block paying its start-up chain; the same with 2-4 rounds per block 139 us;
 // batches handed out in order by per-XCD atomic counters: 402 MB but 171 us (the compiler waits for every atomic on the
 // spot).  MC33_EV_BLOCKED: every block a contiguous piece of its XCD's eighth instead.
+#ifndef MC33_EV_RUN
+#define MC33_EV_RUN 1  // batches a wave takes back to back before it strides on (developer A/B, round 4: consecutive batches are consecutive slices of a tile column)
+#endif
 struct XcdBatchWalk {
 	uint32_t first, end, stride;
+	// the t-th batch of this wave: runs of MC33_EV_RUN consecutive batches, the runs dealt to the waves of the XCD in turn
+	__device__ uint32_t at(uint32_t t) const {
+		constexpr uint32_t R = MC33_EV_RUN;
+		if (R == 1) return first + t * stride;
+		return base + ((t / R) * waves + wave) * R + (t % R);
+	}
+	uint32_t base, waves, wave;
 	__device__ XcdBatchWalk(uint32_t n) {
 		const uint32_t per_xcd = (n + 7u) / 8u;
 		const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, blocks_per_xcd = (gridDim.x + 7u) >> 3;
@@ -1819,6 +1829,8 @@ struct XcdBatchWalk {
 		end = xend;
 		stride = blocks_per_xcd * 4u;
 #endif
+		base = xcd * per_xcd; waves = blocks_per_xcd * 4u; wave = slot * 4u + (threadIdx.x >> 6);
+		if (MC33_EV_RUN > 1) first = at(0u);
 	}
 };
 
@@ -1900,15 +1912,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 		}
 		asm volatile("" ::"v"(r.seg), "v"(r.rowvb));
 	};
-	uint32_t j = w.first;
+	uint32_t t = 0, j = w.at(0u);
 	BatchInfo d0 = load_batch(a.batches, j), d1 = d0;
-	if (j + w.stride < w.end) d1 = load_batch(a.batches, j + w.stride);
+	if (w.at(1u) < w.end) d1 = load_batch(a.batches, w.at(1u));
 	Rec rec0 = load_rec(d0), rec1 = rec0;
 	finish_rec(rec0, d0);
 	for (;;) {  // wave-uniform
-		const bool more = j + w.stride < w.end, more2 = j + 2u * w.stride < w.end;
+		const bool more = w.at(t + 1u) < w.end, more2 = w.at(t + 2u) < w.end;
 		BatchInfo d2 = d1;
-		if (more2) d2 = load_batch(a.batches, j + 2u * w.stride);
+		if (more2) d2 = load_batch(a.batches, w.at(t + 2u));
 		auto next_batch = [&]() {  // (before the vertex stores: see above)
 			if (more) finish_rec(rec1, d1);
 		};
@@ -2108,7 +2120,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 			}
 		} else next_batch();
 		if (!more) break;
-		j += w.stride;
+		t++;
+		j = w.at(t);
 		d0 = d1; d1 = d2; rec0 = rec1;
 	}
 }
