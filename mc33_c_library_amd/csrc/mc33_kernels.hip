@@ -513,6 +513,13 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 // below is put together by k_boundary from the bit rows both tiles leave behind (2 KiB each) - re-reading that
 // plane instead cost 1/depth of the traffic (6 % at depth 16).
 // ---------------------------------------------------------------------------------------------------
+// How a ballot (the sign bits of 64 samples of one row, an SGPR pair) is parked in the lane of its row: 0 = two v_writelane_b32
+// (rounds 1 - 3), 1 = ONE v_mov_b64 with EXEC narrowed to that lane (gfx940+ moves 64 bits in one instruction, and an SGPR
+// pair is a legal source): 4 instead of 8 vector instructions per row and isovalue - the passes over four isovalues of narrow
+// samples are bound by exactly these (round 4)
+#ifndef MC33_PARK
+#define MC33_PARK 1
+#endif
 #ifndef MC33_EDGE_COMPACT
 #define MC33_EDGE_COMPACT 0  // (developer A/B: the edge records of the single-isovalue pass in compact form too - leave_edge)
 #endif
@@ -604,7 +611,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	__shared__ uint32_t s_prevh[PREV_LDS ? NI : 1][PREV_LDS ? 256 : 1];  // ... and its halo-column bits
 	const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	uint64_t cur[NI][4], prev[PREV_LDS ? 1 : NI][4];
-	uint32_t c_lo[NI][4], c_hi[NI][4];
+	uint32_t c_lo[MC33_PARK ? 1 : NI][4], c_hi[MC33_PARK ? 1 : NI][4];  // the rows being assembled: as halves (MC33_PARK 0) ...
+	uint64_t c64[MC33_PARK ? NI : 1][4];                                 // ... or as words (MC33_PARK 1)
 	uint32_t cur_h[NI], prev_h[PREV_LDS ? 1 : NI];
 	uint64_t cur_zc[NI], prev_zc[PREV_LDS ? 1 : NI], zcacc[NI];  // ... and the lanes that loaded one
 	uint64_t cur_z[NI], prev_z[PREV_LDS ? 1 : NI], zacc[NI];  // sample rows of the plane that hold a sample equal to the isovalue (wave-uniform),
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			if constexpr (PREV_LDS) s_prev[q][k][threadIdx.x] = 0; else prev[q][k] = 0;
-			c_lo[q][k] = c_hi[q][k] = 0;
+			if constexpr (MC33_PARK) c64[q][k] = 0; else c_lo[q][k] = c_hi[q][k] = 0;
 		}
 		cur_h[q] = 0; cur_z[q] = zacc[q] = 0; cur_zc[q] = zcacc[q] = 0;
 		if constexpr (PREV_LDS) { s_prevz[q][0][wv] = 0; s_prevz[q][1][wv] = 0; s_prevh[q][threadIdx.x] = 0; } else { prev_z[q] = 0; prev_zc[q] = 0; prev_h[q] = 0; }
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 			for (int k = 0; k < 4; k++) f[k] = sample(dd, rr, k);
 			static_for<NI>([&](auto qc) __attribute__((always_inline)) {
 				constexpr int q = decltype(qc)::value;
-				uint32_t m[8];
+				uint64_t bw[4];
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
 					uint64_t bb;
@@ -726,24 +734,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 						bb = __ballot(f[k] > iso[q]);                         // = the sign bit of iso - F for an integer sample
 						if constexpr (ZM == 1) zeq[q] |= __ballot(f[k] == iso[q]);
 					}
-					m[2 * k] = (uint32_t)bb; m[2 * k + 1] = (uint32_t)(bb >> 32);
+					bw[k] = bb;
 				}
-				// park the bit row of sample row r+rr in lane r+rr: v_writelane takes its lane select from M0
-				// when the data operand is an SGPR too (one SGPR per VOP3 on gfx9-class encodings)
+				// park the bit row of sample row r+rr in lane r+rr
 				// (references and the row number named here: operands of an asm statement do not capture by themselves inside a generic lambda;
 				// the row number through readfirstlane - uniform anyway, but short of SGPRs the compiler moved the batch counter into
 				// a vector register and handed THAT to the "s" operand)
-				uint32_t &l0 = c_lo[q][0], &h0 = c_hi[q][0], &l1 = c_lo[q][1], &h1 = c_hi[q][1], &l2 = c_lo[q][2], &h2 = c_hi[q][2], &l3 = c_lo[q][3], &h3 = c_hi[q][3];
 				const uint32_t rowsel = (uint32_t)__builtin_amdgcn_readfirstlane((int)(r + (uint32_t)rr));
-				asm volatile(
-				    "s_mov_b32 m0, %16\n\t"
-				    "v_writelane_b32 %0, %8, m0\n\tv_writelane_b32 %1, %9, m0\n\t"
-				    "v_writelane_b32 %2, %10, m0\n\tv_writelane_b32 %3, %11, m0\n\t"
-				    "v_writelane_b32 %4, %12, m0\n\tv_writelane_b32 %5, %13, m0\n\t"
-				    "v_writelane_b32 %6, %14, m0\n\tv_writelane_b32 %7, %15, m0"
-				    : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2), "+v"(l3), "+v"(h3)
-				    : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), "s"(rowsel)
-				    : "m0");
+				if constexpr (MC33_PARK) {
+					// EXEC = that one lane, four 64-bit moves from the SGPR pairs, EXEC back (it is all ones here: the wave's control flow is
+					// uniform; saved and restored all the same).  SALU writes of EXEC need no wait states before a VALU instruction.
+					uint64_t &w0 = c64[q][0], &w1 = c64[q][1], &w2 = c64[q][2], &w3 = c64[q][3];
+					uint64_t saved;
+					asm volatile(
+					    "s_mov_b64 %4, exec\n\t"
+					    "s_lshl_b64 exec, 1, %9\n\t"
+					    "v_mov_b64 %0, %5\n\tv_mov_b64 %1, %6\n\tv_mov_b64 %2, %7\n\tv_mov_b64 %3, %8\n\t"
+					    "s_mov_b64 exec, %4"
+					    : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "=&s"(saved)
+					    : "s"(bw[0]), "s"(bw[1]), "s"(bw[2]), "s"(bw[3]), "s"(rowsel)
+					    : "scc");  // (s_lshl_b64 sets SCC: without the clobber the compiler carried a loop condition across the statement in it)
+				} else {
+					// v_writelane takes its lane select from M0 when the data operand is an SGPR too (one SGPR per VOP3 on gfx9-class encodings)
+					uint32_t &l0 = c_lo[q][0], &h0 = c_hi[q][0], &l1 = c_lo[q][1], &h1 = c_hi[q][1], &l2 = c_lo[q][2], &h2 = c_hi[q][2], &l3 = c_lo[q][3], &h3 = c_hi[q][3];
+					const uint32_t m0 = (uint32_t)bw[0], m1 = (uint32_t)(bw[0] >> 32), m2 = (uint32_t)bw[1], m3 = (uint32_t)(bw[1] >> 32);
+					const uint32_t m4 = (uint32_t)bw[2], m5 = (uint32_t)(bw[2] >> 32), m6 = (uint32_t)bw[3], m7 = (uint32_t)(bw[3] >> 32);
+					asm volatile(
+					    "s_mov_b32 m0, %16\n\t"
+					    "v_writelane_b32 %0, %8, m0\n\tv_writelane_b32 %1, %9, m0\n\t"
+					    "v_writelane_b32 %2, %10, m0\n\tv_writelane_b32 %3, %11, m0\n\t"
+					    "v_writelane_b32 %4, %12, m0\n\tv_writelane_b32 %5, %13, m0\n\t"
+					    "v_writelane_b32 %6, %14, m0\n\tv_writelane_b32 %7, %15, m0"
+					    : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2), "+v"(l3), "+v"(h3)
+					    : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "s"(m6), "s"(m7), "s"(rowsel)
+					    : "m0");
+				}
 			});
 		});
 		if constexpr (ZM != 2)
@@ -762,7 +787,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 		if (grouped) {  // (block-uniform) column 0 of this plane for the wave to the left; the right neighbour's for this wave
 			static_for<NI>([&](auto qc) __attribute__((always_inline)) {
 				constexpr int q = decltype(qc)::value;
-				const uint64_t hb = __ballot((c_lo[q][0] & 1u) != 0u);  // (word 0 bit 0 is the segment's first sample in every layout S)
+				const uint64_t hb = __ballot(((MC33_PARK ? (uint32_t)c64[MC33_PARK ? q : 0][0] : c_lo[MC33_PARK ? 0 : q][0]) & 1u) != 0u);  // (word 0 bit 0 is the segment's first sample in every layout S)
 				if (lp == 0) {
 					s_mail[par][wv][q][0] = hb;
 					s_mail[par][wv][q][1] = (ZM != 2 && (zcacc[q] & 1ull)) ? zacc[q] : 0ull;  // (lane 0 loaded column 0; rows to the batch: a superset is fine)
@@ -775,7 +800,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 			constexpr int q = decltype(qc)::value;
 			const SweepLane &L = a.lane[q];
 #pragma unroll
-			for (int k = 0; k < 4; k++) { cur[q][k] = u64(c_lo[q][k], c_hi[q][k]); c_lo[q][k] = c_hi[q][k] = 0; }
+			for (int k = 0; k < 4; k++) {
+				if constexpr (MC33_PARK) { cur[q][k] = c64[q][k]; c64[q][k] = 0; }
+				else { cur[q][k] = u64(c_lo[q][k], c_hi[q][k]); c_lo[q][k] = c_hi[q][k] = 0; }
+			}
 			if (from_right) {  // (wave-uniform; the mailbox word is read here, per isovalue: held over the loop it cost the 4-isovalue form registers it does not have)
 				const uint64_t nb_bits = s_mail[par][wv + 1u][q][0], nb_zero = ZM != 2 ? s_mail[par][wv + 1u][q][1] : 0ull;
 				cur_h[q] = (uint32_t)((nb_bits >> lp) & 1ull);
