@@ -518,7 +518,7 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 // pair is a legal source): 4 instead of 8 vector instructions per row and isovalue - the passes over four isovalues of narrow
 // samples are bound by exactly these (round 4)
 #ifndef MC33_PARK
-#define MC33_PARK 1
+#define MC33_PARK 2
 #endif
 #ifndef MC33_EDGE_COMPACT
 #define MC33_EDGE_COMPACT 0  // (developer A/B: the edge records of the single-isovalue pass in compact form too - leave_edge)
@@ -709,6 +709,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 			real_t f[4];
 #pragma unroll
 			for (int k = 0; k < 4; k++) f[k] = sample(dd, rr, k);
+			uint64_t bwq[NI][4];  // (MC33_PARK 2: the ballots of the row for all isovalues, parked two isovalues per EXEC switch)
 			static_for<NI>([&](auto qc) __attribute__((always_inline)) {
 				constexpr int q = decltype(qc)::value;
 				uint64_t bw[4];
@@ -741,7 +742,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 				// the row number through readfirstlane - uniform anyway, but short of SGPRs the compiler moved the batch counter into
 				// a vector register and handed THAT to the "s" operand)
 				const uint32_t rowsel = (uint32_t)__builtin_amdgcn_readfirstlane((int)(r + (uint32_t)rr));
-				if constexpr (MC33_PARK) {
+				if constexpr (MC33_PARK == 2 && NI >= 2) {
+#pragma unroll
+					for (int k = 0; k < 4; k++) bwq[q][k] = bw[k];
+				} else if constexpr (MC33_PARK) {
 					// EXEC = that one lane, four 64-bit moves from the SGPR pairs, EXEC back (it is all ones here: the wave's control flow is
 					// uniform; saved and restored all the same).  SALU writes of EXEC need no wait states before a VALU instruction.
 					uint64_t &w0 = c64[q][0], &w1 = c64[q][1], &w2 = c64[q][2], &w3 = c64[q][3];
@@ -770,6 +774,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 					    : "m0");
 				}
 			});
+			if constexpr (MC33_PARK == 2 && NI >= 2) {
+				static_for<NI / 2>([&](auto hc) __attribute__((always_inline)) {
+					constexpr int q0 = 2 * decltype(hc)::value;
+					const uint32_t rowsel = (uint32_t)__builtin_amdgcn_readfirstlane((int)(r + (uint32_t)rr));
+					uint64_t &w0 = c64[q0][0], &w1 = c64[q0][1], &w2 = c64[q0][2], &w3 = c64[q0][3];
+					uint64_t &w4 = c64[q0 + 1][0], &w5 = c64[q0 + 1][1], &w6 = c64[q0 + 1][2], &w7 = c64[q0 + 1][3];
+					const uint64_t b0 = bwq[q0][0], b1 = bwq[q0][1], b2 = bwq[q0][2], b3 = bwq[q0][3];
+					const uint64_t b4 = bwq[q0 + 1][0], b5 = bwq[q0 + 1][1], b6 = bwq[q0 + 1][2], b7 = bwq[q0 + 1][3];
+					uint64_t saved;
+					asm volatile(
+					    "s_mov_b64 %8, exec\n\t"
+					    "s_lshl_b64 exec, 1, %17\n\t"
+					    "v_mov_b64 %0, %9\n\tv_mov_b64 %1, %10\n\tv_mov_b64 %2, %11\n\tv_mov_b64 %3, %12\n\t"
+					    "v_mov_b64 %4, %13\n\tv_mov_b64 %5, %14\n\tv_mov_b64 %6, %15\n\tv_mov_b64 %7, %16\n\t"
+					    "s_mov_b64 exec, %8"
+					    : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7), "=&s"(saved)
+					    : "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7), "s"(rowsel)
+					    : "scc");
+				});
+			}
 		});
 		if constexpr (ZM != 2)
 			static_for<NI>([&](auto qc) __attribute__((always_inline)) {  // a sample of these RB rows equals the isovalue: mark the rows
@@ -2283,6 +2307,7 @@ struct TailSet {
 	uint32_t tail_serial;     // tails enqueued (seg_tagged)
 	bool tail_incomplete;     // a tail was begun and did not reach its last launch: Counters::live_cursor may not be zero
 	uint32_t records_hint;    // work records of the last extraction whose counters were read (grid of the triangle pass, first guess of a new set)
+	uint32_t slow_hint;       // ... and its slow records + 1 (0: not known yet): the grid of k_emit_slow
 	Counters *d_ctr, *h_ctr;
 	bool ctr_published;       // the emit pass enqueued last leaves the counters in h_ctr itself (k_emit_fast_triangles)
 };
@@ -3258,8 +3283,12 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 		if (fork_all) HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
 		HIP_TRY(hipStreamWaitEvent(c->aux2, c->ev_fork, 0));
 	}
+	// k_emit_slow walks the slow list with a grid stride: any grid is right.  Beside the fast passes it gets as many blocks as the
+	// last extraction's slow records fill four times over, 64 at least (8 800 of them at 1024^3: 140 blocks, not 1 024 whose waves are started beside
+	// the vertex pass only to find the list exhausted); 1 024 while nothing is known
+	const uint32_t slow_grid = env_u32("MC33_HIP_SLOW_BLOCKS", c->w->slow_hint ? std::min(1024u, std::max(64u, (c->w->slow_hint + 255u) / 256u * 4u)) : 1024u);
 	if (fork_slow) {  // (first: it is the one with the long chains)
-		hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, ss, a);
+		hipLaunchKernelGGL(k_emit_slow, dim3(slow_grid), dim3(256), 0, ss, a);
 		HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
 	}
 #ifdef MC33_DEV
@@ -3281,7 +3310,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 		}
 	hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, sv, a);
 	if (fork_all) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
-	if (!fork_slow) hipLaunchKernelGGL(k_emit_slow, dim3(env_u32("MC33_HIP_SLOW_BLOCKS", 1024)), dim3(256), 0, ss, a);
+	if (!fork_slow) hipLaunchKernelGGL(k_emit_slow, dim3(slow_grid), dim3(256), 0, ss, a);
 	HIP_TRY(hipGetLastError());
 	if (fork_all) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
 	if (fork_slow) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
@@ -3296,6 +3325,7 @@ static int fetch_counters(mc33hip_ctx *c) {
 	c->w->ctr_published = true;  // (h_ctr matches the set's counters until the next tail into this set: enqueue_tail)
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->w->records_hint = c->w->h_ctr->entry_cursor == 0xFFFFFFFFu ? 0u : c->w->h_ctr->entry_cursor;
+	c->w->slow_hint = c->w->h_ctr->slow_cursor + 1u;
 	if (getenv("MC33_HIP_VERBOSE"))
 		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, record batches %u)\n", c->w->h_ctr->entry_cursor,
 		        c->w->h_ctr->slow_cursor, c->w->h_ctr->dirty_cursor, c->w->h_ctr->batch_cursor);

@@ -14,6 +14,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU"; do
   d="$out/$(echo $grp | tr ' ' '_' | cut -c1-40)"
   mkdir -p "$d"
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$d" -o runc/r -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --with-c5 off "$@" > "$d.log" 2>&1 || { echo "pass failed: $grp"; tail -3 "$d.log"; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$d" -o runc/r -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-c-api --with-c5 off "$@" > "$d.log" 2>&1 || { echo "pass failed: $grp"; tail -3 "$d.log"; exit 1; }
   echo "pass done: $grp"
 done
