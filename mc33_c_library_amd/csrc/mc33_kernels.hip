@@ -559,7 +559,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	// completed (one ballot) in an LDS mailbox, one block barrier per PLANE (the four waves run in step anyway: a plane is
 	// ~270 loads), and only the last segment of the group still loads its halo.  All four waves complete the same number
 	// of planes (same rows, same z range), so every wave reaches every barrier; blocks of unrelated tiles keep the load.
-	bool grouped = !(MC33_DEBUG_BITS(a) & 128u);
+#ifdef MC33_NO_MAILBOX  // (developer A/B: every wave loads its halo column itself)
+	bool grouped = false;
+#else
+	bool grouped = true;
+#endif
 	{
 		const uint32_t t0 = blockIdx.x * 4u;
 		if (t0 + 3u >= a.ntiles) grouped = false;
