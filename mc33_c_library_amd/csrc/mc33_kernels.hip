@@ -3204,6 +3204,8 @@ static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n, bool ta
 			if (ensure_set(c, c->ts[k], hint) != 0) {  // (out of device memory: no sets beyond the first, no tails ahead)
 				for (int j = 1; j <= k; j++) free_set(c->ts[j]);
 				(void)hipGetLastError();
+				c->w = &c->ts[0];  // (the last count may have worked in one of the sets that are gone)
+				c->counted = false;
 				tails_ahead = false;
 			}
 		if (!tails_ahead) { if (int rc = ensure_set(c, c->ts[0])) return rc; }
