@@ -431,7 +431,7 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True, capi=F
     if not multi:
         best_ms, med_ms, nbytes = grid.probe_read(10)
         read_ceiling = {"GBps": nbytes / (best_ms * 1e-3) / 1e9, "GBps_median": nbytes / (med_ms * 1e-3) / 1e9, "ms_best": best_ms, "bytes": nbytes,
-                        "what": "mc33hip_probe_read: every 16-byte chunk of the resident grid read once (nontemporal), nothing written; best of 10 launches, hipEvents"}
+                        "what": "mc33hip_probe_read: every 16-byte chunk of the resident grid read once (nontemporal loads, every block a contiguous piece, 16 loads in flight per lane: the best plain-read shape of tools/read_ceiling_probe.hip), nothing written; best of 10 launches, hipEvents"}
     gather_info = None
     extract_only_ms = None
     rank_sweep = None

@@ -134,7 +134,8 @@ int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t);
 int mc33hip_set_timing(mc33hip_ctx *c, int level);
 
 /* Measurement aid (bench.py's `roofline.read_ceiling`): a plain read-only kernel over the resident grid -
- * every 16-byte chunk once, nothing written - timed with hipEvents on the context's stream, reps launches after a warm-up.
+ * every 16-byte chunk once (every block a contiguous piece, 16 loads in flight per lane: the shape that reads fastest on this part),
+ * nothing written - timed with hipEvents on the context's stream, reps launches after a warm-up.
  * *bytes / *ms_best is what a read stream reaches on this device, in this process, on this very buffer: the ceiling the
  * sweep (MC:1832-1868, which reads every sample once) is set beside.  Not part of any extraction. */
 int mc33hip_probe_read(mc33hip_ctx *c, int reps, float *ms_best, float *ms_median, unsigned long long *bytes);

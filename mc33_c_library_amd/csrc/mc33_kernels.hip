@@ -367,6 +367,7 @@ __device__ __forceinline__ void valid_masks(uint32_t xbase, uint32_t nx, uint64_
 // 256 bytes (dword r = row r) instead of 2 KiB (PLANE_COMPACT; k_cells rebuilds the words).  The hand-over is what the sweep
 // pays for beyond its reads, by the byte: 68 MB at C3, 1.08 GB per 4-isovalue pass at C5 before this.
 constexpr uint32_t PLANE_RAW = 0u, PLANE_COMPACT = 1u;
+constexpr uint32_t PLANE_UNIFORM0 = 2u, PLANE_UNIFORM1 = 3u;  // (edge records only: every bit of the plane is 0 / 1 - nothing but the header is written)
 __device__ __forceinline__ void decode_row(uint32_t desc, uint64_t (&w)[4]) {
 	const uint64_t base = (desc & 1u) ? ~0ull : 0ull;
 	const uint32_t n = (desc >> 1) & 3u;
@@ -519,6 +520,12 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 // samples are bound by exactly these (round 4)
 #ifndef MC33_PARK
 #define MC33_PARK 2
+#endif
+#ifndef MC33_SWEEP_BUFS
+#define MC33_SWEEP_BUFS 2  // register buffers of loaded batches in k_sweep's single-isovalue forms (3: developer A/B, round 4)
+#endif
+#ifndef MC33_EDGE_UNIFORM
+#define MC33_EDGE_UNIFORM 1  // (0: developer A/B - an edge record for every plane, as until round 4)
 #endif
 #ifndef MC33_EDGE_COMPACT
 #define MC33_EDGE_COMPACT 0  // (developer A/B: the edge records of the single-isovalue pass in compact form too - leave_edge)
@@ -861,7 +868,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 				// 0.75 - 0.78 ms; the costs of the sweep's stores do not add (round 3, profiles/r03_sweep_parts.txt))
 				uint32_t fmt = PLANE_RAW;
 				uint4 *rec = L.edge_bits + ((uint64_t)wtile * 2u + which) * 128u;
-				if constexpr (NI >= 2 || MC33_EDGE_COMPACT) fmt = store_plane_record<S>(rec, cur[q], lp);
+				// A plane of the tile that lies wholly on one side of the surface - two thirds of them on a smooth field - leaves no
+				// record, only the header with its side (round 4: the records are two thirds of what the single-isovalue sweep writes)
+				const uint64_t w_or = cur[q][0] | cur[q][1] | cur[q][2] | cur[q][3], w_and = cur[q][0] & cur[q][1] & cur[q][2] & cur[q][3];
+				const bool all0 = MC33_EDGE_UNIFORM && __ballot(w_or != 0ull) == 0ull, all1 = MC33_EDGE_UNIFORM && __ballot(w_and != ~0ull) == 0ull;
+				if (all0 || all1) fmt = all0 ? PLANE_UNIFORM0 : PLANE_UNIFORM1;
+				else if constexpr (NI >= 2 || MC33_EDGE_COMPACT) fmt = store_plane_record<S>(rec, cur[q], lp);
 				else if (!(MC33_DEBUG_BITS(a) & 8192u)) {  // (developer builds: 8192 no record, 4096 no header)
 					uint64_t o[4];
 					to_standard<S>(cur[q], o);
@@ -926,6 +938,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	// 1.66 -> 1.72 ms.  No gain.  What the plane's work costs the stream is its stores, wherever they are issued:
 	// profiles/r03_sweep_parts.txt.)
 	issue(dA, hA, ip, ib); MC33_ADV_ISSUE();
+#ifdef MC33_DEV  // MC33_HIP_DEBUG 16384: the loads alone - every batch waited for and dropped, no classification at all
+	if (MC33_DEBUG_BITS(a) & 16384u) {
+		auto drop = [&](const raw_t (&dd)[16], const real_t &hv) __attribute__((always_inline)) {
+#pragma unroll
+			for (int k = 0; k < 16; k++) asm volatile("" ::"v"(dd[k]));
+			asm volatile("" ::"v"(hv));
+		};
+		for (uint32_t t = 0; t < T; t += 2) {
+			issue(dB, hB, ip, ib); MC33_ADV_ISSUE();
+			drop(dA, hA);
+			issue(dA, hA, ip, ib); MC33_ADV_ISSUE();
+			drop(dB, hB);
+		}
+		return;
+	}
+#endif
+	if constexpr (MC33_SWEEP_BUFS == 3 && NI == 1) {
+		// Three buffers (round 4, single-isovalue passes): TWO batches stay in flight while one is turned into bit rows - also across
+		// the work on a complete plane (cut-cell test, hand-over stores), which with two buffers ran with one batch in flight.
+		raw_t dC[16];
+		real_t hC = 0;
+		issue(dB, hB, ip, ib); MC33_ADV_ISSUE();
+		for (uint32_t t = 0; t < T; t += 3) {
+			issue(dC, hC, ip, ib); MC33_ADV_ISSUE();
+			process(dA, hA, pp, pb); MC33_ADV(pp, pb);
+			issue(dA, hA, ip, ib); MC33_ADV_ISSUE();
+			if (t + 1 < T) { process(dB, hB, pp, pb); MC33_ADV(pp, pb); }
+			issue(dB, hB, ip, ib); MC33_ADV_ISSUE();
+			if (t + 2 < T) { process(dC, hC, pp, pb); MC33_ADV(pp, pb); }
+		}
+	} else
 	for (uint32_t t = 0; t < T; t += 2) {
 		issue(dB, hB, ip, ib); MC33_ADV_ISSUE();
 		process(dA, hA, pp, pb); MC33_ADV(pp, pb);
@@ -965,6 +1008,8 @@ __global__ __launch_bounds__(256) void k_boundary(const SweepArgs a, const TileB
 	uint64_t cur[4] = {u64(c0.x, c0.y), u64(c0.z, c0.w), u64(c1.x, c1.y), u64(c1.z, c1.w)};
 	if (zp.z == PLANE_COMPACT) decode_row(dp, prev);
 	if (zc.z == PLANE_COMPACT) decode_row(dc, cur);
+	if (zp.z >= PLANE_UNIFORM0) { prev[0] = prev[1] = prev[2] = prev[3] = zp.z == PLANE_UNIFORM1 ? ~0ull : 0ull; }  // (no record was written: what was loaded is an older extraction's)
+	if (zc.z >= PLANE_UNIFORM0) { cur[0] = cur[1] = cur[2] = cur[3] = zc.z == PLANE_UNIFORM1 ? ~0ull : 0ull; }
 	const uint64_t bp = u64(hp.x, hp.y), bc = u64(hc.x, hc.y);
 	uint64_t valid[4], act[4];
 	valid_masks(seg * SEG_CELLS, P.nx, valid);
@@ -3525,18 +3570,24 @@ extern "C" int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t) {
 // ---------------------------------------------------------------------------------------------------
 // mc33hip_probe_read: what a plain read of the resident grid reaches on this device, in this process, on this buffer -
 // the ceiling the sweep's `roofline.frac` is set beside ("of peak" and "of a measured read ceiling").
-// Every 16-byte chunk once, nontemporal, four loads in flight per lane; nothing is written.
+// Every 16-byte chunk once, nontemporal, nothing written.  The launch shape is the best of tools/read_ceiling_probe.hip
+// (profiles/r04_read_ceiling_probe.txt): every block a CONTIGUOUS piece of the buffer, 16 loads in flight per lane - 7.1 - 7.2
+// TB/s at any occupancy on a 4 GiB buffer, where a grid-stride loop over 8 blocks per CU (the first form of this probe) reaches
+// 6.2 - 6.4 and flattered the sweep.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_probe_read(const u32x4_t *p, uint64_t n16, uint32_t *sink) {
-	const uint64_t stride = (uint64_t)gridDim.x * 256u;
-	uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+	constexpr int U = 16;
+	const uint64_t per = ((n16 + gridDim.x - 1) / gridDim.x + 255u) & ~(uint64_t)255, lo = (uint64_t)blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
 	u32x4_t acc = {0u, 0u, 0u, 0u};
-	for (; i + 3u * stride < n16; i += 4u * stride) {
-		const u32x4_t a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
-		const u32x4_t c = __builtin_nontemporal_load(p + i + 2u * stride), d = __builtin_nontemporal_load(p + i + 3u * stride);
-		acc ^= a ^ b ^ c ^ d;
+	uint64_t i = lo + threadIdx.x;
+	for (; i + (U - 1) * 256u < hi; i += U * 256u) {
+		u32x4_t v[U];
+#pragma unroll
+		for (int k = 0; k < U; k++) v[k] = __builtin_nontemporal_load(p + i + k * 256u);
+#pragma unroll
+		for (int k = 0; k < U; k++) acc ^= v[k];
 	}
-	for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(p + i);
+	for (; i < hi; i += 256u) acc ^= __builtin_nontemporal_load(p + i);
 	if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u && sink) atomicAdd(sink, 1u);  // (keeps the loads; the word is as likely as any other)
 }
 
@@ -3554,7 +3605,7 @@ extern "C" int mc33hip_probe_read(mc33hip_ctx *c, int reps, float *ms_best, floa
 	std::vector<float> t;
 	for (int k = 0; k < reps + 1; k++) {  // (the first launch is a warm-up)
 		(void)hipEventRecord(e0, c->stream);
-		hipLaunchKernelGGL(k_probe_read, dim3((uint32_t)std::max(1, c->cus) * 8u), dim3(256), 0, c->stream, p, n16, (uint32_t *)nullptr);
+		hipLaunchKernelGGL(k_probe_read, dim3((uint32_t)std::max(1, c->cus) * 4u), dim3(256), 0, c->stream, p, n16, (uint32_t *)nullptr);
 		(void)hipEventRecord(e1, c->stream);
 		if (hipEventSynchronize(e1) != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); set_err("k_probe_read failed"); return MC33HIP_ERUNTIME; }
 		float ms = 0.f;
