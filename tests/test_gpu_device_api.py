@@ -261,6 +261,21 @@ def test_prepare_many_counts_first_then_emits_in_any_order(reflibs, dtype):
     g.close(); g2.close()
 
 
+def test_probe_read_reports_the_resident_bytes():
+    """mc33hip_probe_read (bench.py's roofline.read_ceiling): a plain read of the resident grid - every byte once, a positive time,
+    and nothing of an extraction is disturbed by it."""
+    import torch
+    from mc33_c_library_amd import DeviceGrid
+    data, r0, d = fx.cos_field(96)
+    g = DeviceGrid(torch.from_numpy(data).cuda(), r0=r0, d=d)
+    before = g.count(0.0)
+    best, med, nbytes = g.probe_read(3)
+    assert nbytes == data.nbytes and 0.0 < best <= med
+    after = g.count(0.0)
+    assert (before.nV, before.nT) == (after.nV, after.nT)
+    g.close()
+
+
 def _same_as_reference(got, ref, what):
     V, N, T, cnt = got
     assert (cnt.nV, cnt.nT) == (ref.nV, ref.nT), what
