@@ -463,6 +463,33 @@ __device__ __forceinline__ void store_plane(const SweepLane &a, uint64_t plane_s
 	if (lane == 0) a.plane_fmt[plane_slot] = (uint8_t)fmt;
 }
 
+// the raw form of a plane record (2 KiB), w in layout S
+template <int S>
+__device__ __forceinline__ void store_plane_raw(uint4 *rec, const uint64_t (&w)[4], uint32_t lane) {
+	const __amdgpu_buffer_rsrc_t rs = record_rsrc(rec, 2048u);
+	uint64_t o[4];
+	to_standard<S>(w, o);
+	__builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)}, rs, lane * 16u, 0u, 0);
+	__builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)}, rs, lane * 16u, 1024u, 0);
+}
+
+// What a wave of the single-isovalue sweep hands on is kept in LDS and written behind the tile's LAST load (round 4).  Stores
+// issued inside the read stream cost the stream far more than their bytes (15 MB of them a tenth of the kernel,
+// whatever their form or place in the loop); the same stores issued when the wave has nothing left to read - measured with
+// dummy data first: 0.754 -> 0.684 ms at 1024^3, against 0.636 with no stores at all.  Kept: the compact plane records (a dword
+// per row: every plane of a smooth field), the slice headers with their partial sums, the first plane's edge record in compact
+// form.  A plane that needs the raw form (noise) is stored at once as before; a log that is full (very deep tiles) is written
+// out and started again.
+constexpr uint32_t LOG_PLANES = 20, LOG_SLICES = 20, LOG_NONE = 0xFFFFFFFFu;
+struct SweepLog {  // per wave
+	uint32_t plane[LOG_PLANES][64];  // compact records: dword r = row r
+	uint64_t plane_slot[LOG_PLANES];
+	uint32_t hdr[LOG_SLICES][12];    // the ten words of a SliceHeader, word 10: batches of 64 records
+	uint64_t hdr_slot[LOG_SLICES];
+	uint32_t edge[64];               // the tile's first plane for k_boundary (compact)
+	uint32_t edge_hdr[8];
+};
+
 // (slot: of the slice; slot_up: of the slice above = the slot of the upper plane; write_prev / write_cur: the
 // plane has not been written by this wave yet)
 template <int S>
@@ -526,6 +553,12 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 #endif
 #ifndef MC33_EDGE_UNIFORM
 #define MC33_EDGE_UNIFORM 1  // (0: developer A/B - an edge record for every plane, as until round 4)
+#endif
+#ifndef MC33_SWEEP_DEFER
+#define MC33_SWEEP_DEFER 1  // (0: developer A/B - every store of the sweep where its data is made, as until round 4)
+#endif
+#ifndef MC33_EDGE_LAST_COMPACT
+#define MC33_EDGE_LAST_COMPACT 1
 #endif
 #ifndef MC33_EDGE_COMPACT
 #define MC33_EDGE_COMPACT 0  // (developer A/B: the edge records of the single-isovalue pass in compact form too - leave_edge)
@@ -620,6 +653,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	__shared__ uint64_t s_prev[PREV_LDS ? NI : 1][4][PREV_LDS ? 256 : 1];
 	__shared__ uint64_t s_prevz[PREV_LDS ? NI : 1][2][4];  // ... and its 'sample equals the isovalue' row / lane masks, per wave
 	__shared__ uint32_t s_prevh[PREV_LDS ? NI : 1][PREV_LDS ? 256 : 1];  // ... and its halo-column bits
+	constexpr bool DEFER = NI == 1 && MC33_SWEEP_DEFER;   // the hand-over goes through the wave's log in LDS (SweepLog)
+	__shared__ typename std::conditional<DEFER, SweepLog, uint32_t>::type s_log[DEFER ? 4 : 1];
+	uint32_t log_np = 0, log_ns = 0, log_edge = LOG_NONE;  // planes / slices in the log; the format of the pending first edge record (wave-uniform)
 	const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	uint64_t cur[NI][4], prev[PREV_LDS ? 1 : NI][4];
 	uint32_t c_lo[MC33_PARK ? 1 : NI][4], c_hi[MC33_PARK ? 1 : NI][4];  // the rows being assembled: as halves (MC33_PARK 0) ...
@@ -708,6 +744,89 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 		if constexpr (S == 2) return ((uint32_t)dd[rr * 2 + (k >> 1)] >> (16 * (k & 1))) & 0xFFFFu;
 		else if constexpr (S == 4) return ((uint32_t)dd[rr] >> (8 * k)) & 0xFFu;
 		else return 0u;
+	};
+	// ---- the wave's log of what it hands on (DEFER; see SweepLog) ----
+	auto log_flush = [&]() __attribute__((always_inline)) {
+		if constexpr (DEFER) {
+			SweepLog &G = s_log[wv];
+			const SweepLane &L0 = a.lane[0];
+			const uint32_t ln = fresh_lane();
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			for (uint32_t k = 0; k < log_np; k++) {  // wave-uniform
+				const uint64_t slot = readlane64(G.plane_slot[k], 0);
+				__builtin_amdgcn_raw_buffer_store_b32(G.plane[k][ln], record_rsrc(L0.slice_bits + slot * 128u, 2048u), ln * 4u, 0u, 0);
+				if (ln == 0) L0.plane_fmt[slot] = (uint8_t)PLANE_COMPACT;
+			}
+			{  // a lane per slice: its header; the partial sums (k_slots) added up per chunk of slots first - the slices of a tile come in
+				// rising slot order, so the slices of one chunk are neighbouring lanes, and the first of them adds for all (a tile's 6
+				// cut slices lie in 1 - 2 chunks: a third of the atomics, all of which arrive in the kernel's last microseconds)
+				const bool mine = ln < log_ns;
+				const uint32_t e = mine ? ln : 0u;
+				const uint32_t *w = G.hdr[e];
+				const uint64_t slot = G.hdr_slot[e];
+				if (mine) {
+					uint32_t *h = (uint32_t *)(L0.slice_hdr + slot);
+					*(uint4 *)h = uint4{w[0], w[1], w[2], w[3]};
+					*(uint4 *)(h + 4) = uint4{w[4], w[5], w[6], w[7]};
+					*(uint2 *)(h + 8) = uint2{w[8], w[9]};
+				}
+				const uint32_t chunk = mine ? (uint32_t)(slot / SLOT_CHUNK) : 0xFFFFFFFFu;
+				const uint32_t cells = mine ? w[5] : 0u, batches = mine ? w[10] : 0u;
+				uint32_t sum_c = cells, sum_b = batches;
+#pragma unroll 1  // (rolled: unrolled, its 57 cross-lane reads were all asked for at once and cost the kernel a wave per SIMD)
+				for (uint32_t dlt = 1; dlt < log_ns; dlt++) {
+					const uint32_t c2 = __shfl_down(chunk, dlt), v2 = __shfl_down(cells, dlt), b2 = __shfl_down(batches, dlt);
+					const bool same = c2 == chunk && ln + dlt < 64u;
+					sum_c += same ? v2 : 0u; sum_b += same ? b2 : 0u;
+				}
+				const uint32_t before = __shfl_up(chunk, 1);
+				if (mine && (ln == 0u || before != chunk)) atomicAdd(L0.slot_part + chunk, (unsigned long long)sum_b << 32 | sum_c);
+			}
+			if (log_edge != LOG_NONE) {  // the first plane's edge record: compact, or wholly on one side (header only)
+				if (log_edge == PLANE_COMPACT) __builtin_amdgcn_raw_buffer_store_b32(G.edge[ln], record_rsrc(L0.edge_bits + (uint64_t)wtile * 2u * 128u, 2048u), ln * 4u, 0u, 0);
+				if (ln == 0) {
+					const uint32_t *e = G.edge_hdr;
+					L0.edge_hdr[(uint64_t)wtile * 2u * 2u] = uint4{e[0], e[1], e[2], e[3]};
+					L0.edge_hdr[(uint64_t)wtile * 2u * 2u + 1u] = uint4{e[4], e[5], e[6], e[7]};
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the log is written again)
+			log_np = 0; log_ns = 0; log_edge = LOG_NONE;
+		}
+	};
+	// a plane of a cut slice: into the log when it has the compact form, to memory at once when it needs the raw one
+	auto log_plane = [&](uint64_t slot, const uint64_t (&w)[4], uint32_t ln) __attribute__((always_inline)) {
+		if constexpr (DEFER) {
+			uint32_t desc;
+			if (encode_plane<S>(w, desc)) {  // (wave-uniform)
+				if (log_np == LOG_PLANES) log_flush();
+				SweepLog &G = s_log[wv];
+				G.plane[log_np][ln] = desc;
+				if (ln == 0) G.plane_slot[log_np] = slot;
+				log_np++;
+			} else {
+				store_plane_raw<S>(a.lane[0].slice_bits + slot * 128u, w, ln);
+				if (ln == 0) a.lane[0].plane_fmt[slot] = (uint8_t)PLANE_RAW;
+			}
+		}
+	};
+	auto log_header = [&](uint64_t slot, uint64_t bp, uint64_t bc, uint64_t zrows, uint64_t zcols, const uint64_t (&act)[4], uint32_t ln) __attribute__((always_inline)) {
+		if constexpr (DEFER) {
+			uint32_t ncell = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
+#pragma unroll
+			for (int dlt = 32; dlt; dlt >>= 1) ncell += __shfl_xor(ncell, dlt);
+			if (log_ns == LOG_SLICES) log_flush();
+			if (ln == 0) {
+				SweepLog &G = s_log[wv];
+				uint32_t *w = G.hdr[log_ns];
+				w[0] = a.lane[0].epoch << 2 | SLICE_VALID | (zrows ? SLICE_HAS_ISO : 0u);
+				w[1] = (uint32_t)bp; w[2] = (uint32_t)(bp >> 32); w[3] = (uint32_t)bc; w[4] = (uint32_t)(bc >> 32); w[5] = ncell;
+				w[6] = (uint32_t)zrows; w[7] = (uint32_t)(zrows >> 32); w[8] = (uint32_t)zcols; w[9] = (uint32_t)(zcols >> 32);
+				w[10] = (ncell + 63u) >> 6;  // the records of a slice are handed to the emit passes 64 at a time (BatchDesc)
+				G.hdr_slot[log_ns] = slot;
+			}
+			log_ns++;
+		}
 	};
 	real_t halo = 0;  // lane r: halo sample of row r of the plane being assembled
 	// (always_inline: the body is called twice, and in the largest forms - packed uchar samples, four isovalues, equality tests - the
@@ -872,8 +991,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 				// record, only the header with its side (round 4: the records are two thirds of what the single-isovalue sweep writes)
 				const uint64_t w_or = cur[q][0] | cur[q][1] | cur[q][2] | cur[q][3], w_and = cur[q][0] & cur[q][1] & cur[q][2] & cur[q][3];
 				const bool all0 = MC33_EDGE_UNIFORM && __ballot(w_or != 0ull) == 0ull, all1 = MC33_EDGE_UNIFORM && __ballot(w_and != ~0ull) == 0ull;
-				if (all0 || all1) fmt = all0 ? PLANE_UNIFORM0 : PLANE_UNIFORM1;
-				else if constexpr (NI >= 2 || MC33_EDGE_COMPACT) fmt = store_plane_record<S>(rec, cur[q], lp);
+				bool deferred = false;  // (the tile's FIRST plane: its record, when it is small, waits in the log with everything else)
+				if (all0 || all1) { fmt = all0 ? PLANE_UNIFORM0 : PLANE_UNIFORM1; deferred = DEFER && which == 0u && !MC33_DEBUG_BITS(a); }
+				else if (DEFER && which == 0u && !MC33_DEBUG_BITS(a)) {
+					uint32_t desc;
+					if (encode_plane<S>(cur[q], desc)) {
+						if constexpr (DEFER) s_log[wv].edge[lp] = desc;
+						fmt = PLANE_COMPACT; deferred = true;
+					} else store_plane_raw<S>(rec, cur[q], lp);
+				}
+				else if constexpr (NI >= 2 || MC33_EDGE_COMPACT || (DEFER && MC33_EDGE_LAST_COMPACT)) fmt = store_plane_record<S>(rec, cur[q], lp);  // (DEFER: the last plane's record, stored at the tile's end with the rest: the compact form where it fits)
 				else if (!(MC33_DEBUG_BITS(a) & 8192u)) {  // (developer builds: 8192 no record, 4096 no header)
 					uint64_t o[4];
 					to_standard<S>(cur[q], o);
@@ -882,6 +1009,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 					__builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)}, rs, lp * 16u, 1024u, 0);
 				}
 				const uint64_t bh = __ballot(cur_h[q] != 0);
+				if (deferred) {
+					if constexpr (DEFER) {
+						if (lp == 0) {
+							uint32_t *e = s_log[wv].edge_hdr;
+							e[0] = (uint32_t)bh; e[1] = (uint32_t)(bh >> 32); e[2] = (uint32_t)cur_z[q]; e[3] = (uint32_t)(cur_z[q] >> 32);
+							e[4] = (uint32_t)cur_zc[q]; e[5] = (uint32_t)(cur_zc[q] >> 32); e[6] = fmt; e[7] = 0u;
+						}
+						log_edge = fmt;
+					}
+				} else
 				if (lp == 0 && !(MC33_DEBUG_BITS(a) & 4096u)) {
 					L.edge_hdr[((uint64_t)wtile * 2u + which) * 2u] = uint4{(uint32_t)bh, (uint32_t)(bh >> 32), (uint32_t)cur_z[q], (uint32_t)(cur_z[q] >> 32)};
 					L.edge_hdr[((uint64_t)wtile * 2u + which) * 2u + 1u] = uint4{(uint32_t)cur_zc[q], (uint32_t)(cur_zc[q] >> 32), fmt, 0u};
@@ -904,6 +1041,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 						uint64_t pz, pzc;
 						if constexpr (PREV_LDS) { pz = readlane64(s_prevz[q][0][wv], 0); pzc = readlane64(s_prevz[q][1][wv], 0); }  // (wave-uniform: into SGPRs, not four registers held from an early LDS read to the header's store)
 						else { pz = prev_z[q]; pzc = prev_zc[q]; }
+						if (DEFER && !MC33_DEBUG_BITS(a)) {  // (developer switches keep the direct stores they were written for)
+							const uint64_t slot = slice_slot(p - 1 - P.zs, yt, seg, a.sd), slot_up = slice_slot(p - P.zs, yt, seg, a.sd);
+							if (!prev_written[q]) log_plane(slot, pq, lp);
+							log_plane(slot_up, cur[q], lp);
+							log_header(slot, __ballot(ph != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act, lp);
+						} else
 						hand_over_slice<S>(L, slice_slot(p - 1 - P.zs, yt, seg, a.sd), slice_slot(p - P.zs, yt, seg, a.sd), pq, cur[q],
 						                   !prev_written[q], true, __ballot(ph != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act, lp,
 						                   MC33_DEBUG_BITS(a));
@@ -975,6 +1118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 		issue(dA, hA, ip, ib); MC33_ADV_ISSUE();
 		if (t + 1 < T) { process(dB, hB, pp, pb); MC33_ADV(pp, pb); }
 	}
+	log_flush();  // (DEFER: everything the tile hands on, behind its last load)
 	if (a.trace && lane == 0) {
 		unsigned long long *tr = a.trace + 4ull * wtile;
 		tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime(); tr[2] = c_start; tr[3] = __builtin_amdgcn_s_memtime();
