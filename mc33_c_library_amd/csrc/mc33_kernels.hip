@@ -173,7 +173,10 @@ struct SweepLane {
 	                         // rows.  A plane is written once, by the first slice with cut cells that touches it: writes are
 	                         // what the sweep pays for (100 MB of them cost as much as 600 MB of reads), and consecutive slices
 	                         // share a plane
-	uint8_t *plane_fmt;      // [slice_slot of the PLANE]: PLANE_COMPACT / PLANE_RAW - how its record in slice_bits is written (store_plane)
+	uint32_t *slice_compact; // [slice_slot of the PLANE][64]: the plane's record in compact form, 256 bytes - an array of its own (round 4), so that
+	                         // the records of the four slices of a group, which one wave writes and one wave of k_cells reads, are ONE KiB of
+	                         // memory rather than four pieces 2 KiB apart
+	uint8_t *plane_fmt;      // [slice_slot of the PLANE]: PLANE_COMPACT / PLANE_RAW - in which of the two arrays the plane's record is (store_plane)
 	unsigned long long *slot_part;  // [slot / SLOT_CHUNK]: record batches << 32 | cells of the slices of that chunk
 	uint4 *edge_bits;        // [tile * 2 + (0 bottom | 1 top)][2][lane]: bit rows of the tile's first / last plane
 	uint4 *edge_hdr;         // ... their halo-column bits and "a sample equals the isovalue" flag
@@ -443,14 +446,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t record_rsrc(const void *base, 
 	return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
 }
 // writes the record at `rec` (2 KiB reserved) in the form that fits; returns the form
+// (compact: where the 256-byte form goes - the head of the 2 KiB record for the edge records, slice_compact for the planes of cut slices)
 template <int S>
-__device__ __forceinline__ uint32_t store_plane_record(uint4 *rec, const uint64_t (&w)[4], uint32_t lane) {
-	const __amdgpu_buffer_rsrc_t rs = record_rsrc(rec, 2048u);
+__device__ __forceinline__ uint32_t store_plane_record(uint4 *rec, uint32_t *compact, const uint64_t (&w)[4], uint32_t lane) {
 	uint32_t desc;
 	if (encode_plane<S>(w, desc)) {
-		__builtin_amdgcn_raw_buffer_store_b32(desc, rs, lane * 4u, 0u, 0);
+		__builtin_amdgcn_raw_buffer_store_b32(desc, record_rsrc(compact, 256u), lane * 4u, 0u, 0);
 		return PLANE_COMPACT;
 	}
+	const __amdgpu_buffer_rsrc_t rs = record_rsrc(rec, 2048u);
 	uint64_t o[4];
 	to_standard<S>(w, o);
 	__builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)}, rs, lane * 16u, 0u, 0);
@@ -459,7 +463,7 @@ __device__ __forceinline__ uint32_t store_plane_record(uint4 *rec, const uint64_
 }
 template <int S>
 __device__ __forceinline__ void store_plane(const SweepLane &a, uint64_t plane_slot, const uint64_t (&w)[4], uint32_t lane) {
-	const uint32_t fmt = store_plane_record<S>(a.slice_bits + plane_slot * 128u, w, lane);
+	const uint32_t fmt = store_plane_record<S>(a.slice_bits + plane_slot * 128u, a.slice_compact + plane_slot * 64u, w, lane);
 	if (lane == 0) a.plane_fmt[plane_slot] = (uint8_t)fmt;
 }
 
@@ -495,7 +499,8 @@ struct SweepLog {  // per wave
 template <int S>
 __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slot, uint64_t slot_up, const uint64_t (&prev)[4],
                                                 const uint64_t (&cur)[4], bool write_prev, bool write_cur, uint64_t bp, uint64_t bc,
-                                                uint64_t zrows, uint64_t zcols, const uint64_t (&act)[4], uint32_t lane, uint32_t dev = 0) {
+                                                uint64_t zrows, uint64_t zcols, const uint64_t (&act)[4], uint32_t lane, uint32_t dev = 0,
+                                                uint32_t *pend_chunk = nullptr, unsigned long long *pend_sum = nullptr) {
 #ifdef MC33_DEV  // MC33_HIP_DEBUG 32: no bit-plane stores, no header; 128: the bit-plane stores alone (the later passes see nothing)
 	if (dev & 32u) { write_prev = write_cur = false; }
 #endif
@@ -517,7 +522,19 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 		*(uint4 *)h = uint4{a.epoch << 2 | SLICE_VALID | (zrows ? SLICE_HAS_ISO : 0u), (uint32_t)bp, (uint32_t)(bp >> 32), (uint32_t)bc};
 		*(uint4 *)(h + 4) = uint4{(uint32_t)(bc >> 32), ncell, (uint32_t)zrows, (uint32_t)(zrows >> 32)};
 		*(uint2 *)(h + 8) = uint2{(uint32_t)zcols, (uint32_t)(zcols >> 32)};
-		atomicAdd(a.slot_part + slot / SLOT_CHUNK, (unsigned long long)nbatch << 32 | ncell);
+		if (!pend_chunk) atomicAdd(a.slot_part + slot / SLOT_CHUNK, (unsigned long long)nbatch << 32 | ncell);
+	}
+	if (pend_chunk) {
+		// (the passes over several isovalues: the partial sums of the wave's slices are added up per chunk of slots - consecutive
+		// slices of a tile mostly fall into the same one - and reach memory as one atomic per chunk: the pass over 4 isovalues of
+		// the 2048 x 2048 x 1024 grid issued 380 000 of them onto 2 100 addresses, a tenth of a millisecond with the headers)
+		const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(slot / SLOT_CHUNK));
+		const uint32_t nc = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncell);
+		if (*pend_chunk != chunk) {
+			if (*pend_sum && lane == 0) atomicAdd(a.slot_part + *pend_chunk, *pend_sum);
+			*pend_chunk = chunk; *pend_sum = 0ull;
+		}
+		*pend_sum += (unsigned long long)((nc + 63u) >> 6) << 32 | nc;
 	}
 }
 
@@ -656,6 +673,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	constexpr bool DEFER = NI == 1 && MC33_SWEEP_DEFER;   // the hand-over goes through the wave's log in LDS (SweepLog)
 	__shared__ typename std::conditional<DEFER, SweepLog, uint32_t>::type s_log[DEFER ? 4 : 1];
 	uint32_t log_np = 0, log_ns = 0, log_edge = LOG_NONE;  // planes / slices in the log; the format of the pending first edge record (wave-uniform)
+	uint32_t pend_chunk[NI];            // (NI >= 2) partial sums not yet added to memory: their chunk of slots ...
+	unsigned long long pend_sum[NI];    // ... batches << 32 | cells (wave-uniform)
+#pragma unroll
+	for (int q = 0; q < NI; q++) { pend_chunk[q] = 0u; pend_sum[q] = 0ull; }
 	const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	uint64_t cur[NI][4], prev[PREV_LDS ? 1 : NI][4];
 	uint32_t c_lo[MC33_PARK ? 1 : NI][4], c_hi[MC33_PARK ? 1 : NI][4];  // the rows being assembled: as halves (MC33_PARK 0) ...
@@ -754,7 +775,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			for (uint32_t k = 0; k < log_np; k++) {  // wave-uniform
 				const uint64_t slot = readlane64(G.plane_slot[k], 0);
-				__builtin_amdgcn_raw_buffer_store_b32(G.plane[k][ln], record_rsrc(L0.slice_bits + slot * 128u, 2048u), ln * 4u, 0u, 0);
+				__builtin_amdgcn_raw_buffer_store_b32(G.plane[k][ln], record_rsrc(L0.slice_compact + slot * 64u, 256u), ln * 4u, 0u, 0);
 				if (ln == 0) L0.plane_fmt[slot] = (uint8_t)PLANE_COMPACT;
 			}
 			{  // a lane per slice: its header; the partial sums (k_slots) added up per chunk of slots first - the slices of a tile come in
@@ -1000,7 +1021,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 						fmt = PLANE_COMPACT; deferred = true;
 					} else store_plane_raw<S>(rec, cur[q], lp);
 				}
-				else if constexpr (NI >= 2 || MC33_EDGE_COMPACT || (DEFER && MC33_EDGE_LAST_COMPACT)) fmt = store_plane_record<S>(rec, cur[q], lp);  // (DEFER: the last plane's record, stored at the tile's end with the rest: the compact form where it fits)
+				else if constexpr (NI >= 2 || MC33_EDGE_COMPACT || (DEFER && MC33_EDGE_LAST_COMPACT)) fmt = store_plane_record<S>(rec, (uint32_t *)rec, cur[q], lp);  // (DEFER: the last plane's record, stored at the tile's end with the rest: the compact form where it fits)
 				else if (!(MC33_DEBUG_BITS(a) & 8192u)) {  // (developer builds: 8192 no record, 4096 no header)
 					uint64_t o[4];
 					to_standard<S>(cur[q], o);
@@ -1049,7 +1070,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 						} else
 						hand_over_slice<S>(L, slice_slot(p - 1 - P.zs, yt, seg, a.sd), slice_slot(p - P.zs, yt, seg, a.sd), pq, cur[q],
 						                   !prev_written[q], true, __ballot(ph != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act, lp,
-						                   MC33_DEBUG_BITS(a));
+						                   MC33_DEBUG_BITS(a), NI >= 2 ? &pend_chunk[q] : nullptr, NI >= 2 ? &pend_sum[q] : nullptr);
 						cur_written[q] = true;
 					}
 				}
@@ -1119,6 +1140,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 		if (t + 1 < T) { process(dB, hB, pp, pb); MC33_ADV(pp, pb); }
 	}
 	log_flush();  // (DEFER: everything the tile hands on, behind its last load)
+	if constexpr (NI >= 2) {
+#pragma unroll
+		for (int q = 0; q < NI; q++)
+			if (pend_sum[q] && lane == 0) atomicAdd(a.lane[q].slot_part + pend_chunk[q], pend_sum[q]);
+	}
 	if (a.trace && lane == 0) {
 		unsigned long long *tr = a.trace + 4ull * wtile;
 		tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime(); tr[2] = c_start; tr[3] = __builtin_amdgcn_s_memtime();
@@ -1361,6 +1387,7 @@ struct CellsArgs {
 	uint32_t live_cap;
 	const SliceHeader *slice_hdr;
 	const uint4 *slice_bits;
+	const uint32_t *slice_compact;
 	const uint8_t *plane_fmt;
 	uint32_t epoch;          // number of this extraction: headers written by earlier ones are not valid
 	const uint2 *slot_base;  // [slice_slot]: {first work record, first batch descriptor} (k_slots)
@@ -1464,8 +1491,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 		// form, one dword per row, and how they are written; a plane in raw form (a row with more than two changes) costs
 		// a second round trip below
 		slot_up = slice_slot(z + 1u - P.zs, yt, seg, a.sd);
-		dl = ((const uint32_t *)(a.slice_bits + slot * 128u))[lane];
-		du = ((const uint32_t *)(a.slice_bits + slot_up * 128u))[lane];
+		dl = a.slice_compact[slot * 64u + lane];
+		du = a.slice_compact[slot_up * 64u + lane];
 		fmt_l = a.plane_fmt[slot]; fmt_u = a.plane_fmt[slot_up];
 	}
 	const bool live = in_grid && slice_valid(h.flags, a.epoch);  // wave-uniform
@@ -2457,6 +2484,7 @@ constexpr int MC33_MANY_PASSES = 4;  // passes of one mc33hip_sweep_many call: 8
 struct IsoLane {
 	SliceHeader *slice_hdr;   // one record per (wave tile, cell slice) of the sweep
 	uint4 *slice_bits;
+	uint32_t *slice_compact;
 	uint8_t *plane_fmt;
 	unsigned long long *slot_part;
 	uint4 *edge_bits, *edge_hdr;
@@ -2691,7 +2719,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	for (int k = 0; k < MC33_LANES; k++) free_set(c->ts[k]);
 	for (int k = 0; k < MC33_LANES; k++) {
 		IsoLane &L = c->lanes[k];
-		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.plane_fmt); (void)hipFree(L.slot_part); (void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
+		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.slice_compact); (void)hipFree(L.plane_fmt); (void)hipFree(L.slot_part); (void)hipFree(L.edge_bits); (void)hipFree(L.edge_hdr);
 	}
 	(void)hipFree(c->d_tiles);
 	(void)hipFree(c->d_bounds);
@@ -3039,10 +3067,11 @@ static int slot_geometry(mc33hip_ctx *c, SlotGeom &g) {
 // buffers of one isovalue lane for the current range and tile plan; a new extraction number (epoch)
 static int begin_lane(mc33hip_ctx *c, IsoLane &L, const SlotGeom &g, hipStream_t st) {
 	if (L.slice_cap < g.nslots) {
-		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.plane_fmt); (void)hipFree(L.slot_part);
-		L.slice_hdr = nullptr; L.slice_bits = nullptr; L.plane_fmt = nullptr; L.slot_part = nullptr; L.slice_cap = 0;
+		(void)hipFree(L.slice_hdr); (void)hipFree(L.slice_bits); (void)hipFree(L.slice_compact); (void)hipFree(L.plane_fmt); (void)hipFree(L.slot_part);
+		L.slice_hdr = nullptr; L.slice_bits = nullptr; L.slice_compact = nullptr; L.plane_fmt = nullptr; L.slot_part = nullptr; L.slice_cap = 0;
 		HIP_TRY(hipMalloc(&L.slice_hdr, g.nslots * sizeof(SliceHeader)));
 		HIP_TRY(hipMalloc(&L.slice_bits, g.nslots * 2048));  // (slots of planes: SlotDims)
+		HIP_TRY(hipMalloc(&L.slice_compact, g.nslots * 256));
 		HIP_TRY(hipMalloc(&L.plane_fmt, g.nslots));
 		const uint64_t part_bytes = ((g.nslots + SLOT_CHUNK - 1) / SLOT_CHUNK) * 8;
 		HIP_TRY(hipMalloc(&L.slot_part, 2 * part_bytes));  // two halves, used by alternate extractions
@@ -3093,7 +3122,7 @@ static void sweep_args(mc33hip_ctx *c, const SlotGeom &g, SweepArgs &a) {
 	a.z_end = c->range.z_end;
 	a.trace = nullptr;
 	a.debug = 0;
-	for (int q = 0; q < SWEEP_MAXNI; q++) a.lane[q] = SweepLane{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, (real_t)0, 0, 0xFFFFFFFFu};
+	for (int q = 0; q < SWEEP_MAXNI; q++) a.lane[q] = SweepLane{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, (real_t)0, 0, 0xFFFFFFFFu};
 }
 // SweepLane::iso_gt / iso_eq of an isovalue for packed samples of `top` as their largest value
 static void sweep_iso_words(real_t v, real_t top, int32_t &gt, uint32_t &eq) {
@@ -3102,7 +3131,7 @@ static void sweep_iso_words(real_t v, real_t top, int32_t &gt, uint32_t &eq) {
 	eq = (v == fl && fl >= 0 && fl <= top) ? (uint32_t)fl : 0xFFFFFFFFu;
 }
 static void set_lane(SweepArgs &a, int q, const IsoLane &L, double iso) {
-	a.lane[q] = SweepLane{L.slice_hdr, L.slice_bits, L.plane_fmt, lane_part(L, false), L.edge_bits, L.edge_hdr, L.epoch, (real_t)iso, 0, 0xFFFFFFFFu};
+	a.lane[q] = SweepLane{L.slice_hdr, L.slice_bits, L.slice_compact, L.plane_fmt, lane_part(L, false), L.edge_bits, L.edge_hdr, L.epoch, (real_t)iso, 0, 0xFFFFFFFFu};
 	if (SWEEP_PACK > 1) sweep_iso_words((real_t)iso, SWEEP_PACK == 2 ? (real_t)65535 : (real_t)255, a.lane[q].iso_gt, a.lane[q].iso_eq);
 }
 
@@ -3118,10 +3147,10 @@ static bool sweep_packed(const mc33hip_ctx *c) {
 template <int NI, int ZM>
 static uint32_t launch_sweep_zm(mc33hip_ctx *c, const SweepArgs &a, hipStream_t st) {
 	const uint64_t blocks = (c->ntiles + 3) / 4;
-	// (packed narrow samples, four isovalues, classified by subtraction - an isovalue of -0.0 among the four: the conversions of
-	// a batch and four sets of bit rows do not fit the registers of 3 waves per SIMD - 468 bytes of scratch per lane for uchar,
-	// 20 for ushort; that corner takes the unpacked form, which has none)
-	constexpr bool packed_form = !(SWEEP_PACK >= 2 && NI == 4 && ZM == 0);
+	// (packed narrow samples, several isovalues, classified by subtraction - an isovalue of -0.0 among them: the conversions of
+	// a batch and the sets of bit rows do not fit the registers of 3 waves per SIMD - 468 bytes of scratch per lane for uchar
+	// with four isovalues, 20 for ushort, 8 for uchar with two; that corner takes the unpacked form, which has none)
+	constexpr bool packed_form = !(SWEEP_PACK >= 2 && NI >= 2 && ZM == 0);
 	if (packed_form && sweep_packed(c)) {
 		hipLaunchKernelGGL((k_sweep<packed_form ? SWEEP_PACK : 1, NI, ZM>), dim3((uint32_t)blocks), dim3(256), 0, st, a);
 		return (uint32_t)SWEEP_PACK;
@@ -3215,7 +3244,7 @@ static int enqueue_tail(mc33hip_ctx *c, const int *idx, const int *sidx, const d
 		ca.G.p = c->d_grid; ca.G.pitch = (uint32_t)c->pitch; ca.G.z0 = c->desc.plane0; ca.G.slice = c->slice;
 		ca.P = P; ca.fast = c->d_fast; ca.pat = c->d_pat;
 		ca.ze = ze; ca.sd = g.sd;
-		ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.plane_fmt = L.plane_fmt; ca.slot_base = w.slot_base;
+		ca.slice_hdr = L.slice_hdr; ca.slice_bits = L.slice_bits; ca.slice_compact = L.slice_compact; ca.plane_fmt = L.plane_fmt; ca.slot_base = w.slot_base;
 		// the tag of this tail's row-segment counts; the array is cleared whenever the tags start over
 		if (w.tail_serial % SEG_TAGS == 0) HIP_TRY(hipMemsetAsync(w.seg_cnt, 0, w.seg_cap * 4, st));
 		const uint32_t seg_tag = w.tail_serial % SEG_TAGS + 1u;
@@ -3404,6 +3433,9 @@ static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n, bool ta
 		const int ni = (n - k >= 4) ? 4 : (n - k >= 2) ? 2 : 1;
 		SweepArgs a;
 		sweep_args(c, g, a);
+#ifdef MC33_DEV
+		a.debug = env_u32("MC33_HIP_DEBUG", 0);
+#endif
 		for (int q = 0; q < ni; q++) {
 			IsoLane &L = c->lanes[k + q];
 			if (int rc = begin_lane(c, L, g, st)) return rc;
