@@ -577,6 +577,9 @@ __device__ __forceinline__ void hand_over_slice(const SweepLane &a, uint64_t slo
 #ifndef MC33_EDGE_LAST_COMPACT
 #define MC33_EDGE_LAST_COMPACT 1
 #endif
+#ifndef MC33_LOG_EARLY_PLANES
+#define MC33_LOG_EARLY_PLANES 0u
+#endif
 #ifndef MC33_EDGE_COMPACT
 #define MC33_EDGE_COMPACT 0  // (developer A/B: the edge records of the single-isovalue pass in compact form too - leave_edge)
 #endif
@@ -768,6 +771,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	};
 	// ---- the wave's log of what it hands on (DEFER; see SweepLog) ----
 	auto log_flush = [&]() __attribute__((always_inline)) {
+#ifdef MC33_LOG_NO_FLUSH  // (developer timing experiment: the log is kept and dropped - results wrong)
+		log_np = 0; log_ns = 0; log_edge = LOG_NONE;
+		return;
+#endif
 		if constexpr (DEFER) {
 			SweepLog &G = s_log[wv];
 			const SweepLane &L0 = a.lane[0];
@@ -853,6 +860,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	// (always_inline: the body is called twice, and in the largest forms - packed uchar samples, four isovalues, equality tests - the
 	// compiler made a real FUNCTION of it, every captured array behind a pointer into 1.5 KiB of scratch memory per lane)
 	auto process = [&](const raw_t (&dd)[16], const real_t &hv, uint32_t p, uint32_t bi) __attribute__((always_inline)) {
+		// (developer A/B, MC33_LOG_EARLY_PLANES = n: the log goes out n planes before the tile's end instead of behind it.  Every wave of
+		// the launch ends at the same moment, and what they all store then is the kernel's tail - 0.03 of 0.68 ms at 1024^3 - but
+		// stores beside even the last planes' loads cost more: 0.691 / 0.703 / 0.694 -> 0.711 / 0.708 / 0.704 (n = 1) -> 0.716 / 0.724 / 0.725 (2))
+		if (DEFER && MC33_LOG_EARLY_PLANES && bi == 0u && p + MC33_LOG_EARLY_PLANES == z_hi + 1u && z_hi - pl0 >= 2u * MC33_LOG_EARLY_PLANES) log_flush();
 		const uint32_t r = bi * (uint32_t)RB;
 		halo = (lane / (uint32_t)RB) == bi ? hv : halo;
 		unrolled_for<RB, (S >= 4)>([&](auto rc) __attribute__((always_inline)) {
