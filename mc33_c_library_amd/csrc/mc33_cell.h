@@ -1289,7 +1289,8 @@ MC33_HD SegBase2 seg_base_pair(const SegBase *p) {
 // (before: the record before this one in the array, o1 when x - 1 is wanted - the caller has it from the load of `en` itself)
 template <typename T>
 MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const EntryA &before, uint32_t s, uint32_t self_index, const URef &ids) {
-	if (segment_coord(c.P, s).z < c.z_emit) return;
+	// (a ghost slice of a z-slab; z = zs + s / (nseg ny), without the division)
+	if (c.z_emit > c.P.zs && (uint64_t)s < (uint64_t)(c.z_emit - c.P.zs) * c.P.nseg * c.P.ny) return;
 	const uint32_t xl = en.w0 & 0xFFu;
 	const uint32_t i = (en.w0 >> 8) & 0xFFu;
 #define MC33_SIDE(k) ((i >> (7 - (k))) & 1u)
@@ -1299,8 +1300,9 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const Ent
 #undef MC33_SIDE
 	const bool need[6] = {cut0, cut1 || cut2, cut3, cut4 || cut9, cut7 || cut11, cut8};
 	// the bases of this row segment and of the one before it (y - 1: segment B) in one load
+	// (asked for here, looked at only behind the neighbours' loads: a select on it up here made the directory words below
+	// wait for it - a round trip of its own in every record's chain, round 4)
 	const SegBase2 sp = seg_base_pair(c.seg_base + (s ? s - 1u : 0u));
-	const SegBase sb = s ? sp.hi : sp.lo;
 	Entry oe[6];
 	uint32_t ovb[6];
 	if (xl != 0) {
@@ -1317,7 +1319,7 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const Ent
 		const uint64_t sa = (uint64_t)s - ((needseg[0] || needseg[2]) ? dz : 0ull);
 		const SegBase2 ap = seg_base_pair(c.seg_base + (sa ? sa - 1ull : 0ull));
 		svb[0] = sa ? ap.hi.vbase : ap.lo.vbase;
-		svb[1] = needseg[1] ? sp.lo.vbase : sb.vbase;
+		svb[1] = sp.lo.vbase;  // (looked at only when B is wanted: y >= 1 then, and s - 1 is B)
 		svb[2] = ap.lo.vbase;  // (looked at only when C is wanted: y >= 1 then, and sa - 1 is C)
 		EntryA oa[6];
 		uint32_t oi[6];
@@ -1338,7 +1340,7 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const Ent
 		// halves B: from the table for fast records; a third round trip only for neighbours that are tested or slow cells
 		for (int o = 0; o < 6; o++)
 			oe[o] = entry_join(oa[o], ctx_half_b(c, oa[o], oi[o]));
-		ovb[0] = ovb[3] = svb[0]; ovb[2] = ovb[4] = svb[1]; ovb[5] = svb[2]; ovb[1] = sb.vbase;
+		ovb[0] = ovb[3] = svb[0]; ovb[2] = ovb[4] = svb[1]; ovb[5] = svb[2]; ovb[1] = s ? sp.hi.vbase : sp.lo.vbase;
 	} else {
 		// first cell of a row segment: the x-1 neighbours are the last cells of the previous segment (ny row segments back) -
 		// six lookups, again in rounds: directory words and bases, then halves A, then halves B
@@ -1360,6 +1362,7 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const Ent
 		}
 		for (int o = 0; o < 6; o++) oe[o] = entry_join(oa[o], ctx_half_b(c, oa[o], oi[o]));
 	}
+	const SegBase sb = s ? sp.hi : sp.lo;
 	fast_triangles_write(c, en, oe, ovb, sb, ids);
 }
 

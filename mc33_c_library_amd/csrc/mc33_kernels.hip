@@ -1991,10 +1991,16 @@ struct XcdWalk {
 };
 
 // capacity / overflow check shared by both emit kernels; fills the slab offsets of the context
+template <bool TOGETHER = false>
 __device__ __forceinline__ bool emit_prepare(const EmitArgs &a, EmitCtx<sample_t> &c, const Counters &ctr) {
 	const uint64_t gV = a.ghost_segs ? ctr.ghostV : 0, gT = a.ghost_segs ? ctr.ghostT : 0;
-	if (ctr.entry_cursor > a.entry_cap || ctr.totV - gV > a.capV || ctr.totT - gT > a.capT || ctr.totV > 0xFFFFFFFFull ||
-	    ctr.totT > 0xFFFFFFFFull || (uint64_t)a.id_base + (ctr.totV - gV) > 0xFFFFFFFFull) {
+	// TOGETHER: `|`, not `||` - every counter is asked for before the first is looked at; with short circuits the compiler fetches
+	// them one comparison at a time, a scalar round trip each (the triangle pass, whose waves live for one record per lane)
+	const bool over = TOGETHER ? (bool)((ctr.entry_cursor > a.entry_cap) | (ctr.totV - gV > a.capV) | (ctr.totT - gT > a.capT) | (ctr.totV > 0xFFFFFFFFull) |
+	                                    (ctr.totT > 0xFFFFFFFFull) | ((uint64_t)a.id_base + (ctr.totV - gV) > 0xFFFFFFFFull))
+	                           : (ctr.entry_cursor > a.entry_cap || ctr.totV - gV > a.capV || ctr.totT - gT > a.capT || ctr.totV > 0xFFFFFFFFull ||
+	                              ctr.totT > 0xFFFFFFFFull || (uint64_t)a.id_base + (ctr.totV - gV) > 0xFFFFFFFFull);
+	if (over) {
 		if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->emit_skipped = 1;
 		return false;
 	}
@@ -2418,37 +2424,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	__shared__ uint32_t s_id[13][256];
 	__shared__ EntryB s_fast_b[256];
-	s_fast_b[threadIdx.x] = a.c.fast_b[threadIdx.x];
-	__syncthreads();
+	// A wave of this kernel lives for one record per lane and ~8 dependent round trips; what it does before the first of the
+	// record's own counts in full.  So: the table's words, the counters and - as soon as the counters say which record - the
+	// record itself are all asked for before anything is waited for, and the table goes into LDS behind that.  (Before round 4:
+	// table load, wait, LDS, barrier, counters, wait, more counters, wait, record: three round trips ahead of the first.)
+	const EntryB fb = a.c.fast_b[threadIdx.x];
 	const Counters ctr = *a.ctr;
 	EmitCtx<sample_t> c = a.c;
 	c.fast_b = s_fast_b; c.fast_b_in_lds = true;
-	const bool ok = emit_prepare(a, c, ctr);
+	const bool ok = emit_prepare<true>(a, c, ctr);
+	const XcdWalk w(ctr.entry_cursor);
+	uint32_t e = w.first;
+	const uint32_t e0 = ok && e < w.end ? e : 0u;  // (records 0 and 1 exist in every allocation)
+	uint32_t seg = c.entry_seg[e0];
+	EntryA2 pair = entry_pair(c.entries_a + (e0 ? e0 - 1u : 0u));  // the record and the one before it (the owner of two of its edges, mostly)
+	asm volatile("" ::"v"(seg), "v"(pair.lo.a0), "v"(pair.hi.a0));
+	s_fast_b[threadIdx.x] = fb;
+	__syncthreads();
 	// The counters of the extraction for the host, straight into its pinned copy (everything before this kernel on the stream
 	// has finished: they are final, and every emit kernel decides `emit_skipped` alike): the call's one synchronisation then
 	// finds them there, without a device-to-host copy command of 100 bytes behind the last kernel.
-	if (a.host_ctr && blockIdx.x == 0 && threadIdx.x == 0) {
-		// (word by word from memory to memory: a private copy of the struct put scratch memory into the kernel - every wave's
-		// launch pays for that - as soon as the struct grew by two words: 90 -> 122 us at 1024^3, round 3)
-		static_assert(sizeof(Counters) % 4 == 0, "Counters in words");
+	if (a.host_ctr && blockIdx.x == 0 && threadIdx.x < sizeof(Counters) / 4) {
+		// (a lane per word from memory to memory: a private copy of the struct put scratch memory into the kernel - every wave's
+		// launch pays for that - as soon as the struct grew by two words: 90 -> 122 us at 1024^3, round 3; one lane copying word
+		// after word was a chain of 24 load / store round trips to host memory in the first wave of the grid)
+		static_assert(sizeof(Counters) % 4 == 0 && sizeof(Counters) / 4 <= 64, "Counters in words, a lane each");
+		static_assert(offsetof(Counters, emit_skipped) % 4 == 0, "emit_skipped is a word");
 		const volatile uint32_t *src = (const volatile uint32_t *)a.ctr;
 		volatile uint32_t *dst = (volatile uint32_t *)a.host_ctr;
-		for (uint32_t k = 0; k < sizeof(Counters) / 4; k++) dst[k] = src[k];
-		a.host_ctr->emit_skipped = ok ? 0u : 1u;
+		const uint32_t k = threadIdx.x;
+		dst[k] = k == offsetof(Counters, emit_skipped) / 4 ? (ok ? 0u : 1u) : src[k];
 	}
 	if (!ok) return;
 	const URef ids{&s_id[0][threadIdx.x], 256};
-	const XcdWalk w(ctr.entry_cursor);
-	for (uint32_t e = w.first; e < w.end; e += w.stride) {
-		const uint32_t seg = c.entry_seg[e];
-		const EntryA2 pair = entry_pair(c.entries_a + (e ? e - 1u : 0u));  // the record and the one before it (the owner of two of its edges, mostly)
+	while (e < w.end) {
 		const EntryA ea = e ? pair.hi : pair.lo;
-		asm volatile("" ::"v"(seg), "v"(ea.a0));
 		const Entry en = entry_join(ea, ctx_half_b(c, ea, e));
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, pair.lo, seg, e, ids);
+		e += w.stride;
+		if (e >= w.end) break;
+		seg = c.entry_seg[e];
+		pair = entry_pair(c.entries_a + e - 1u);
+		asm volatile("" ::"v"(seg), "v"(pair.lo.a0), "v"(pair.hi.a0));
 	}
 }
 
+// k_emit_slow: the records the generic per-cell code writes (cells on the grid's 0-faces, corners equal to the isovalue, aliases), one
+// thread per record walking its up to 13 pattern slots one after the other (emit_cell).  The form for MANY slow records (noise,
+// integer isovalues on integer grids: 2 M of them at 1024^3 in 0.75 ms); with few the call waits for the length of one thread's chain
+// of 20 - 30 dependent round trips - see k_emit_slow_slots.
 __global__ __launch_bounds__(256) void k_emit_slow(const EmitArgs a) {
 	__shared__ real_t s_v[8][256];
 	__shared__ real_t s_w[8][256];
@@ -2466,6 +2490,112 @@ __global__ __launch_bounds__(256) void k_emit_slow(const EmitArgs a) {
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
 		const uint32_t gq = cm.group_of(t);
 		emit_cell(c, a.slow_list[a.slot_base[(uint64_t)gq << a.lc.shift].x + (t - cm.pre[gq])], v, w, ids);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_emit_slow_slots: the same records with SIXTEEN LANES PER RECORD, a lane per pattern slot (edges 0..11 and the centre; lanes
+// 13..15 only take triangles) - the form for FEW slow records (round 4).
+//
+// One thread per record (k_emit_slow) goes, for each of up to 13 slots, either through the vertex it creates (its gradient samples: a
+// round trip) or through the chase to the record that did (directory word, record, its stored plan, next hop: two or three round
+// trips per hop), one slot after the other - a chain of 20 - 30 dependent round trips, 31 us for the 8 800 such cells of the 1024^3
+// cos field with the GPU to itself.  It used to be hidden beside the fast passes on a second stream, at the price of an event at the
+// fork, a cross-queue wait at the join (6 - 7 us each inside an emit stage of 200) and of slow blocks still resident when the vertex
+// pass placed its own (see enqueue_emit).  With a lane per slot the chain is as long as ONE slot's: record, plan, the slot's vertex or
+// chase, ids through LDS, a lane per triangle - 14 us for those 8 800 records, 32 us for 34 000 (2048 x 2048 x 1024 ushort), in
+// sequence behind the fast passes.  Every lane repeats the record's set-up, though: 2 M records take 2.3 ms this way against 0.75 ms
+// with a thread each - the host picks by the last count (enqueue_emit).  Same functions, same stores per vertex and per triangle:
+// emit_cell (mc33_cell.h, what the host emulator runs) is the statement of what this computes.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emit_slow_slots(const EmitArgs a) {
+	__shared__ real_t s_v[8][16];      // corner values of the block's 16 records (the 16 lanes of a record write the same eight)
+	__shared__ real_t s_w[8][256];     // per lane: the corners of an owner cell on a chase (iso = -0.0 only)
+	__shared__ uint32_t s_id[16][16];  // [record][slot]: vertex ids
+	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+	const Counters ctr = *a.ctr;
+	EmitCtx<sample_t> c = a.c;
+	if (!emit_prepare(a, c, ctr)) return;
+	if (blockIdx.x * 16u >= ctr.slow_cursor) return;  // (k_slow_plan left the total there)
+	const uint32_t sub = threadIdx.x & 15u, cell = threadIdx.x >> 4, lane = threadIdx.x & 63u, gsh = lane & 48u;
+	const VRef v{&s_v[0][cell], 16}, w{&s_w[0][threadIdx.x], 256};
+	uint32_t *ids = s_id[cell];
+	ChunkMap cm;
+	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);
+	const uint32_t n = cm.total;
+	for (uint32_t t0 = blockIdx.x * 16u; t0 < n; t0 += gridDim.x * 16u) {  // (block-uniform)
+		const uint32_t t = t0 + cell;
+		bool live = t < n;
+		uint32_t entry_index = 0, x = 0, y = 0, z = 0, vbase = 0, tpos = 0;
+		Entry en{};
+		if (live) {
+			const uint32_t gq = cm.group_of(t);
+			entry_index = a.slow_list[a.slot_base[(uint64_t)gq << a.lc.shift].x + (t - cm.pre[gq])];
+			const uint32_t s = c.entry_seg[entry_index];
+			en = ctx_entry(c, entry_index);
+			const SegCoord sc = segment_coord(c.P, s);
+			y = sc.y; z = sc.z; x = sc.xbase + (en.w0 & 0xFFu);
+			// (a tested cell that k_slow_plan found on the slow list: the fast emit passes write it; a ghost slice: the rank below does)
+			live = (en.w3 & ENTRY_SLOW) && z >= c.z_emit;
+			if (live) {
+				const SegBase sb = c.seg_base[s];
+				vbase = sb.vbase + (en.w1 & 0xFFFFu);
+				tpos = sb.tbase + (en.w1 >> 16) - c.t_skip;
+			}
+		}
+		CellPlan p{};
+		uint32_t id = NO_ID;
+		if (live) {
+			load_cell(c.G, c.P.iso, x, y, z, v);
+			plan_restore(p, c.tab.lut, en, c.entries_c[entry_index]);
+			plan_restore_points(p, v);
+			const uint32_t e = sub;
+			if (e < 13u && (p.visited & (1u << e))) {  // the slot's id; a NEW vertex is written on the way (emit_cell's loop body)
+				const uint32_t r = plan_rank(p, e);
+				if (r != 15u) {
+					id = vbase + r;
+					if (p.created & (1u << e)) {
+						real_t g[6];
+						if (e == 12u) vertex_centre(x, y, z, v, g);
+						else if (p.onpoint & (1u << e)) {
+							const uint32_t cc = corner_code((p.onb & (1u << e)) ? edge_b(e) : edge_a(e));
+							vertex_on_point(c.P, c.G, x + (cc & 1), y + ((cc >> 1) & 1), z + (cc >> 2), g);
+						} else
+							vertex_on_edge(c.P, c.G, x, y, z, e, v, g);
+						store_vertex(c.P, g, c.V, c.N, vbase + r - c.v_skip);
+					}
+				} else {
+					const RootRef root = chase_root(c, tgt_edge(plan_tgt(p, e), x, y, z), w);
+					id = root.rec == NO_ID ? NO_ID : c.seg_base[root.seg].vbase + root.voff + root.rank;
+				}
+			}
+		}
+		ids[sub] = id;
+		// the triangles: lane k of the record takes the k-th of its pattern (at most 12; the last one has no continuation bits)
+		uint32_t word = 0xF000u;
+		if (live) word = c.tab.lut[min((uint32_t)p.poff + 1u + sub, (uint32_t)MC33_LUT_COUNT - 1u)];
+		const uint32_t ends = (uint32_t)(__ballot(live && !(word >> 12)) >> gsh) & 0xFFFFu;  // (every lane of the wave gets here)
+		const bool mine = live && ends && sub <= (uint32_t)__builtin_ctz(ends | 0x10000u);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the ids of the 16 lanes of a record: one wave)
+		uint32_t ti[3] = {0u, 0u, 0u};
+		bool keep = false;
+		if (mine) {  // MC:780-784, 1235-1250
+			const uint32_t e2 = word & 15u, e1 = (word >> 4) & 15u, e0 = (word >> 8) & 15u;
+			ti[2] = ids[e2]; ti[1] = ids[e1]; ti[0] = ids[e0];
+			// MC:1235 on the ids - except for iso = -0.0, where ids may be "no vertex" (see chase_root): the triangle slots were counted by
+			// vertex identity (count_triangles_stored), and the same test decides here
+			RootMemo memo{nullptr, 0, 0u};
+			keep = c.P.negzero_iso ? (slots_differ_stored(c, p, x, y, z, e2, e1, w, memo) && slots_differ_stored(c, p, x, y, z, e2, e0, w, memo) &&
+			                          slots_differ_stored(c, p, x, y, z, e1, e0, w, memo))
+			                       : (ti[0] != ti[1] && ti[0] != ti[2] && ti[1] != ti[2]);
+		}
+		const uint32_t kept = (uint32_t)(__ballot(keep) >> gsh) & 0xFFFFu;
+		if (keep) {
+			uint32_t *tr = c.Tri + 3 * (uint64_t)(tpos + (uint32_t)__popc(kept & ((1u << sub) - 1u)));
+			const bool swap = (p.n != 0) != (c.P.normal_neg != 0);  // MC:1246-1250
+			tr[0] = (swap ? ti[1] : ti[0]) + c.id_delta; tr[1] = (swap ? ti[0] : ti[1]) + c.id_delta; tr[2] = ti[2] + c.id_delta;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (before the next round's ids and corner values)
 	}
 }
 
@@ -3509,35 +3639,49 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	// of 0.18 ms at 768^3); with the loads of a round trip asked for together they keep the GPU busy by themselves and
 	// one after the other is as fast or faster (C3 tail 0.401 against 0.404 - 0.409 ms, C5 step 15.97 against 16.18 ms), without
 	// the events between the streams.  MC33_HIP_NO_FORK=0 still runs them side by side.
-	// MC33_HIP_NO_FORK: 0 = all three side by side, 1 = all in sequence, unset = the two fast passes in sequence and, on
-	// large grids, the slow one beside them on a second stream: its few blocks wait through long chains of dependent lookups
-	// (34 us for 8 800 cells at C3) and fill nothing - in sequence that is 34 us added to the call, beside the others none.
+	// MC33_HIP_NO_FORK: 0 = all three side by side, 1 = all in sequence, unset = the two fast passes in sequence and the slow one
+	// behind them (few slow records) or, on large grids, beside them on a second stream (many: see below).
 	const char *fork_env = getenv("MC33_HIP_NO_FORK");
 	const uint64_t range_cells = (uint64_t)c->P.nx * c->P.ny * (c->range.z_end - c->P.zs);
 	const bool fork_all = fork_env && !atoi(fork_env);
-	const bool fork_slow = fork_all || (!fork_env && range_cells >= 300000000ull);  // (small grids: the events cost more than they gain)
-	hipStream_t sv = fork_all ? c->aux : c->stream, ss = fork_slow ? c->aux2 : c->stream;
-	if (fork_slow) {
-		HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-		if (fork_all) HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-		HIP_TRY(hipStreamWaitEvent(c->aux2, c->ev_fork, 0));
-	}
-	// k_emit_slow walks the slow list with a grid stride: any grid is right.  Beside the fast passes it gets as many blocks as the
-	// last extraction's slow records fill four times over, 64 at least (8 800 of them at 1024^3: 140 blocks, not 1 024 whose waves are started beside
-	// the vertex pass only to find the list exhausted); 1 024 while nothing is known
-	const uint32_t slow_grid = env_u32("MC33_HIP_SLOW_BLOCKS", c->w->slow_hint ? std::min(1024u, std::max(64u, (c->w->slow_hint + 255u) / 256u * 4u)) : 1024u);
-	if (fork_slow) {  // (first: it is the one with the long chains)
-		hipLaunchKernelGGL(k_emit_slow, dim3(slow_grid), dim3(256), 0, ss, a);
-		HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
-	}
 	// Which fast pass goes first (round 4).  The triangle pass lives on dependent look-ups in what the tail has just written - records,
 	// directory lines, segment bases: 144 MB at 1024^3 float - and right behind the tail it finds them in the 256 MB last-level cache;
 	// behind the vertex pass, which pulls 0.45 GB of sample lines through that cache, it does not: 85 -> 68 - 70 us at 1024^3 with
 	// the triangles first, the vertex pass unchanged (110 - 115), the step 1.05 - 1.06 -> 1.02 - 1.03 ms.  On the 2048 x 2048 x 1024
 	// ushort grid (14.4 M records per isovalue: the set does not fit either way) the order costs the triangle pass 20 - 25 us and
 	// gives the vertex pass 14: the vertex pass stays first there.  MC33_HIP_TRI_FIRST=0 / 1 forces the order.
+	// The slow pass.  FEW slow records - the usual case: cells on the grid's faces, a corner equal to the isovalue here and there - go
+	// through k_emit_slow_slots in sequence behind the two fast passes (8 800 records of the 1024^3 cos field in 14 us with the GPU to
+	// itself; a thread per record: 31).  Until round 4 the pass always ran beside the fast passes on a second stream: an event at the
+	// fork and a cross-queue wait at the join (6 - 7 us each inside an emit stage of 200), and once the triangle pass went first, slow
+	// blocks still resident when the vertex pass placed its own - that kernel is as many blocks as the device holds (3 per CU by its
+	// LDS image) with a fixed share of the batches each, and 26 KB of a slow block in the middle of a CU's LDS kept the CU's third
+	// vertex block out until one of the other two had finished: 170 instead of 112 us in a third of the calls whenever the slow pass
+	// ended 0 - 3 us behind the triangle pass (profiles/r04_vertex_pass_bimodal.txt).  MANY slow records (noise, integer isovalues on
+	// integer grids) - or an unknown number - take a thread each (k_emit_slow), on large grids beside the fast passes on the second
+	// stream as before, the vertex pass first as before.  MC33_HIP_SLOW_SLOTS=0 / 1 forces the kernel, MC33_HIP_NO_FORK the streams.
+	const char *se = getenv("MC33_HIP_SLOW_SLOTS");
+	const bool slow_slots = se && *se ? atoi(se) != 0 : (c->w->slow_hint != 0u && c->w->slow_hint <= 32768u);
+	const bool fork_slow = fork_all || (!fork_env && !slow_slots && range_cells >= 300000000ull);  // (small grids: the events cost more than they gain)
 	const char *tf = getenv("MC33_HIP_TRI_FIRST");
-	const bool tri_first = !fork_all && (tf ? atoi(tf) != 0 : c->w->records_hint <= 6000000u);
+	const bool tri_first = !fork_all && (tf ? atoi(tf) != 0 : (c->w->records_hint <= 6000000u && !fork_slow));
+	hipStream_t sv = fork_all ? c->aux : c->stream, ss = fork_slow ? c->aux2 : c->stream;
+	if (fork_slow) {
+		HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+		if (fork_all) HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+		HIP_TRY(hipStreamWaitEvent(c->aux2, c->ev_fork, 0));
+	}
+	// Both slow kernels walk the slow list with a grid stride: any grid is right.  A thread per record: as many blocks as the last
+	// extraction's slow records fill four times over, 64 at least (waves that are started beside the vertex pass only to find the list
+	// exhausted cost it), 1 024 at most and while nothing is known.  A lane per slot, 16 records per block and round: as many blocks as
+	// the records need and an eighth more.
+	const uint32_t slow_grid = env_u32("MC33_HIP_SLOW_BLOCKS", slow_slots ? std::max(64u, (c->w->slow_hint + c->w->slow_hint / 8u + 15u) / 16u)
+	                                                                    : c->w->slow_hint ? std::min(1024u, std::max(64u, (c->w->slow_hint + 255u) / 256u * 4u)) : 1024u);
+#define MC33_LAUNCH_SLOW(st) do { if (slow_slots) hipLaunchKernelGGL(k_emit_slow_slots, dim3(slow_grid), dim3(256), 0, st, a); else hipLaunchKernelGGL(k_emit_slow, dim3(slow_grid), dim3(256), 0, st, a); } while (0)
+	if (fork_slow) {  // (first: it is the one with the long chains)
+		MC33_LAUNCH_SLOW(ss);
+		HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
+	}
 	if (tri_first) hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, sv, a);
 #ifdef MC33_DEV
 	if (env_u32("MC33_HIP_OLD_VERTEX_PASS", 0)) hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);  // (the round-2 pass, for A/B timing)
@@ -3555,10 +3699,11 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 		case 2: hipLaunchKernelGGL(k_emit_vertices<2>, vgrid, dim3(256), 0, c->stream, a); break;
 		default: hipLaunchKernelGGL(k_emit_vertices<3>, vgrid, dim3(256), 0, c->stream, a); break;
 		}
-		}
+	}
 	if (!tri_first) hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, sv, a);
 	if (fork_all) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
-	if (!fork_slow) hipLaunchKernelGGL(k_emit_slow, dim3(slow_grid), dim3(256), 0, ss, a);
+	if (!fork_slow) MC33_LAUNCH_SLOW(ss);
+#undef MC33_LAUNCH_SLOW
 	HIP_TRY(hipGetLastError());
 	if (fork_all) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
 	if (fork_slow) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));

@@ -72,7 +72,7 @@ def test_no_kernel_has_a_scratch_segment(dtype):
         pytest.skip("library not built")
     ks = kernel_metadata(lib)
     names = [k["pretty"] for k in ks]
-    for must in ("k_sweep<1, 1, 0>", "k_cells", "k_slots", "k_scan_apply", "k_emit_fast_triangles", "k_emit_vertices<0>", "k_emit_slow"):
+    for must in ("k_sweep<1, 1, 0>", "k_cells", "k_slots", "k_scan_apply", "k_emit_fast_triangles", "k_emit_vertices<0>", "k_emit_slow", "k_emit_slow_slots"):
         assert must in names, "%s: kernel %s not found in the code object (found %s)" % (dtype, must, names)
     bad = []
     for k in ks:

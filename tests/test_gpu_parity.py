@@ -54,6 +54,22 @@ def test_degenerate_small_alphabet(products, reflibs):
     check(products, reflibs, "f32", fx.noise_quant(0, 4, L=2, shape=(20, 20, 20)), 0.0, label="quant L2")
 
 
+@pytest.mark.parametrize("slots", ["0", "1"])
+def test_both_slow_emit_kernels(products, reflibs, slots, monkeypatch):
+    """The generic per-cell records are written by one of two kernels, picked by how many the last extraction had: a thread per
+    record (k_emit_slow: many) or sixteen lanes per record, a lane per pattern slot (k_emit_slow_slots: few).  Forced either way
+    on inputs that are all such records - quantised noise with samples equal to the isovalue, the grid's faces, iso = -0.0 -
+    both must give the reference's arrays."""
+    monkeypatch.setenv("MC33_HIP_SLOW_SLOTS", slots)
+    for seed, iso in ((1, 0.0), (2, 1.0), (3, -1.0)):
+        check(products, reflibs, "f32", fx.noise_quant(32, seed), iso, label="quant s%d iso %g slots=%s" % (seed, iso, slots))
+    check(products, reflibs, "f32", fx.noise_quant(0, 9, L=3, shape=(7, 9, 300)), 0.0, label="quant L3 wide slots=%s" % slots)
+    check(products, reflibs, "f32", fx.noise_f32(0, 11, shape=(66, 65, 258)), 0.05, label="ragged slots=%s" % slots)
+    check(products, reflibs, "u8", (fx.noise_quant(40, 5, L=6) * 20 + 100).astype(np.uint8), 100.0, label="u8 integer iso slots=%s" % slots)
+    data, r0, d = fx.cos_field(64)
+    check(products, reflibs, "f32", data, 0.0, r0, d, "cos64 slots=%s" % slots)
+
+
 @pytest.mark.parametrize("shape", [(2, 2, 2), (2, 3, 5), (3, 2, 2), (9, 17, 33), (5, 70, 3), (4, 3, 600), (66, 65, 258)])
 def test_ragged_shapes(products, reflibs, shape):
     check(products, reflibs, "f32", fx.noise_f32(0, 11, shape=shape), 0.05, label="ragged %s" % (shape,))
