@@ -2523,6 +2523,19 @@ __global__ __launch_bounds__(256) void k_emit_slow_slots(const EmitArgs a) {
 	ChunkMap cm;
 	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);
 	const uint32_t n = cm.total;
+	if (n > gridDim.x * 32u) {
+		// Far more records than the launch was sized for: the host went by the count of an EARLIER extraction (mc33hip_extract_into does
+		// not stop to read this one's), and the isovalue has moved onto the samples since.  A thread per record then, as k_emit_slow.
+		__shared__ real_t s_v1[8][256];
+		__shared__ uint32_t s_id1[13][256];
+		const VRef v1{&s_v1[0][threadIdx.x], 256};
+		const URef ids1{&s_id1[0][threadIdx.x], 256};
+		for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+			const uint32_t gq = cm.group_of(t);
+			emit_cell(c, a.slow_list[a.slot_base[(uint64_t)gq << a.lc.shift].x + (t - cm.pre[gq])], v1, w, ids1);
+		}
+		return;
+	}
 	for (uint32_t t0 = blockIdx.x * 16u; t0 < n; t0 += gridDim.x * 16u) {  // (block-uniform)
 		const uint32_t t = t0 + cell;
 		bool live = t < n;
@@ -3674,8 +3687,9 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	// Both slow kernels walk the slow list with a grid stride: any grid is right.  A thread per record: as many blocks as the last
 	// extraction's slow records fill four times over, 64 at least (waves that are started beside the vertex pass only to find the list
 	// exhausted cost it), 1 024 at most and while nothing is known.  A lane per slot, 16 records per block and round: as many blocks as
-	// the records need and an eighth more.
-	const uint32_t slow_grid = env_u32("MC33_HIP_SLOW_BLOCKS", slow_slots ? std::max(64u, (c->w->slow_hint + c->w->slow_hint / 8u + 15u) / 16u)
+	// the records need and an eighth more, 1 024 at least (a block beyond the list leaves at once, and should the count have been an
+	// earlier isovalue's and far too small, the kernel goes through the list with a thread per record: it needs the threads then).
+	const uint32_t slow_grid = env_u32("MC33_HIP_SLOW_BLOCKS", slow_slots ? std::max(1024u, (c->w->slow_hint + c->w->slow_hint / 8u + 15u) / 16u)
 	                                                                    : c->w->slow_hint ? std::min(1024u, std::max(64u, (c->w->slow_hint + 255u) / 256u * 4u)) : 1024u);
 #define MC33_LAUNCH_SLOW(st) do { if (slow_slots) hipLaunchKernelGGL(k_emit_slow_slots, dim3(slow_grid), dim3(256), 0, st, a); else hipLaunchKernelGGL(k_emit_slow, dim3(slow_grid), dim3(256), 0, st, a); } while (0)
 	if (fork_slow) {  // (first: it is the one with the long chains)

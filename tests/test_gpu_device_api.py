@@ -129,6 +129,32 @@ def test_one_context_many_extractions_of_different_extent(reflibs):
             g2.close()
 
 
+def test_slow_emit_with_a_stale_count(reflibs):
+    """`extract_into` does not stop to read the counters before the emit passes: which slow-emit kernel runs, and on how many
+    blocks, follows the count of the PREVIOUS extraction of the context.  A half-integer isovalue on an unsigned char grid
+    (a few slow records on the grid's faces: 16 lanes per record) followed by an integer one (every cut cell has a corner equal
+    to it: tens of thousands of slow records, into a launch sized for the few) and back again - each must be the reference's."""
+    import torch
+    from mc33_c_library_amd import DeviceGrid
+    f, _, _ = fx.cos_field(176)
+    data = np.round(128.0 + 40.0 * f).astype(np.uint8)
+    t = torch.from_numpy(data).cuda()
+    g = DeviceGrid(t)
+    refs = {iso: reflibs["u8"].isosurface(data, iso) for iso in (100.5, 100.0, 128.0)}
+    cap_v, cap_t = max(r.nV for r in refs.values()) + 64, max(r.nT for r in refs.values()) + 64
+    V = torch.empty((cap_v, 3), dtype=torch.float32, device="cuda")
+    N = torch.empty_like(V)
+    T = torch.empty((cap_t, 3), dtype=torch.int32, device="cuda")
+    for step, iso in enumerate((100.5, 100.0, 100.0, 100.5, 128.0, 100.5)):
+        V.fill_(float("nan")); N.fill_(float("nan")); T.fill_(-1)
+        cnt, ok = g.extract_into(iso, V, N, T)
+        ref = refs[iso]
+        assert ok and (cnt.nV, cnt.nT) == (ref.nV, ref.nT), (step, iso)
+        assert np.array_equal(T[:cnt.nT].cpu().numpy().view(np.uint32), ref.T), (step, iso)
+        assert beq(V[:cnt.nV].cpu().numpy(), ref.V) and beq(N[:cnt.nV].cpu().numpy(), ref.N), (step, iso)
+    g.close()
+
+
 def test_segment_count_tags_start_over(reflibs):
     """The counts of the row segments carry the number of the tail that wrote them (1 .. 255 in turn; a word with another
     number counts as zero, so the rows of slices without cut cells are never written and nothing is cleared between
