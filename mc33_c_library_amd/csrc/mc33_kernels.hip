@@ -1802,14 +1802,30 @@ __global__ __launch_bounds__(256) void k_slow_count(const PerLane<SlowArgs> A) {
 	}
 }
 
-// one thread per row segment that holds slow cells: running offsets of its records, segment totals
+// one thread per row segment that holds slow cells: running offsets of its records, segment totals.  A record that still waits
+// for its triangle count (ENTRYA_COUNT) is counted on the way: k_slow_count, a launch of its own for exactly that, costs 5 - 6 us
+// even when its blocks read one flag and leave - the case of nearly every extraction - so the host enqueues it only when the last
+// extraction of the context had such records (then they are many, and a thread per RECORD is the faster way through them), and
+// whatever is left over when it was not enqueued - the isovalue has moved onto the samples since - is caught here, a segment's
+// records one after the other.
 __global__ __launch_bounds__(256) void k_seg_fix(const PerLane<SlowArgs> A) {
 	const SlowArgs &a = A.a[blockIdx.y];
 	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
-	if (blockIdx.x * 256u >= a.ctr->dirty_cursor) return;  // (k_slow_plan left the total there)
+	__shared__ real_t s_w[8][256];
+	__shared__ uint64_t s_key[12][256];
+	const uint32_t dirty_total = a.ctr->dirty_cursor, records = a.ctr->entry_cursor;  // (asked for together)
+	const bool pending = a.ctr->count_pending != 0u;  // (k_slow_plan: some record waits for its count - unless k_slow_count has been through)
+	if (blockIdx.x * 256u >= dirty_total) return;  // (k_slow_plan left the total there)
 	ChunkMap cm;
 	cm.build(s_pre, s_red, a.lc.dirty_cnt, a.lc.n);
-	if (a.ctr->entry_cursor > a.entry_cap) return;
+	if (records > a.entry_cap) return;
+	EmitCtx<sample_t> c;
+	c.tab = a.tab; c.P = a.P; c.G = a.G;
+	c.seg_base = nullptr; c.seg_dir = a.seg_dir;
+	c.entries_a = a.entries_a; c.entries_b = a.entries_b; c.entries_c = a.entries_c; c.fast_b = a.fast_b; c.fast_b_in_lds = false; c.entry_seg = a.entry_seg;
+	c.V = nullptr; c.N = nullptr; c.Tri = nullptr;
+	c.z_emit = a.z_emit; c.v_skip = c.t_skip = c.id_delta = 0;
+	const VRef w{&s_w[0][threadIdx.x], 256};
 	const uint32_t n = cm.total;
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
 		const uint32_t gq = cm.group_of(t);
@@ -1818,9 +1834,20 @@ __global__ __launch_bounds__(256) void k_seg_fix(const PerLane<SlowArgs> A) {
 		uint32_t nv = 0, nt = 0;
 		for (uint32_t k = 0; k < cnt; k++) {
 			EntryA *e = a.entries_a + first + k;  // (counts and offsets live in half A)
+			EntryA ea = *e;
+			if (pending && (ea.a0 & ENTRYA_COUNT)) {  // (as k_slow_count)
+				const Entry en = entry_join(ea, a.entries_b[first + k]);
+				CellPlan pl;
+				plan_restore(pl, a.tab.lut, en, a.entries_c[first + k]);
+				const SegCoord sc = segment_coord(a.P, s);
+				RootMemo memo{&s_key[0][threadIdx.x], 256, 0u};
+				const uint32_t ntri = count_triangles_stored(c, pl, sc.xbase + (ea.a0 & 0xFFu), sc.y, sc.z, w, memo);
+				ea.a0 = (ea.a0 & ~(15u << 20) & ~ENTRYA_COUNT) | ntri << 20;
+				e->a0 = ea.a0;
+			}
 			e->a1 = nv | nt << 16;
-			nv += entrya_nnew(*e);
-			nt += entrya_ntri(*e);
+			nv += entrya_nnew(ea);
+			nt += entrya_ntri(ea);
 		}
 		a.seg_cnt[s] = seg_tagged(nv, nt, a.seg_tag);
 	}
@@ -2683,6 +2710,7 @@ struct TailSet {
 	bool tail_incomplete;     // a tail was begun and did not reach its last launch: Counters::live_cursor may not be zero
 	uint32_t records_hint;    // work records of the last extraction whose counters were read (grid of the triangle pass, first guess of a new set)
 	uint32_t slow_hint;       // ... and its slow records + 1 (0: not known yet): the grid of k_emit_slow
+	bool count_known, count_needed;  // ... and whether it had records waiting for k_slow_count (corners equal to the isovalue): see enqueue_tail
 	Counters *d_ctr, *h_ctr;
 	bool ctr_published;       // the emit pass enqueued last leaves the counters in h_ctr itself (k_emit_fast_triangles)
 };
@@ -3459,7 +3487,13 @@ static int enqueue_tail(mc33hip_ctx *c, const int *idx, const int *sidx, const d
 	// the chain of dependent loads of the cells that ARE slow, not their empty blocks; round 3)
 	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);
 	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
-	hipLaunchKernelGGL(k_slow_count, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
+	{  // k_slow_count only when the last extraction of (one of) the set(s) had records for it, or nothing is known: k_seg_fix counts what is left over
+		bool wanted = false;
+		for (int q = 0; q < n; q++) wanted |= !c->ts[sidx[q]].count_known || c->ts[sidx[q]].count_needed;
+		const char *fc = getenv("MC33_HIP_SLOW_COUNT");
+		if (fc && *fc) wanted = atoi(fc) != 0;
+		if (wanted) hipLaunchKernelGGL(k_slow_count, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
+	}
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
 	hipLaunchKernelGGL(k_scan_reduce, dim3(nb, ny), dim3(256), 0, st, NA, c->nsegs, c->P);
 	hipLaunchKernelGGL(k_scan_apply, dim3(nb, ny), dim3(256), 0, st, NA, c->nsegs, c->P, c->ghost_segs);
@@ -3733,6 +3767,7 @@ static int fetch_counters(mc33hip_ctx *c) {
 	HIP_TRY(hipStreamSynchronize(c->stream));  // (polling the stream before blocking - hipStreamQuery for up to 3 ms - gains nothing: 1.086 / 1.087 / 1.097 against 1.063 / 1.094 / 1.126 ms per step at 1024^3, round 4)
 	c->w->records_hint = c->w->h_ctr->entry_cursor == 0xFFFFFFFFu ? 0u : c->w->h_ctr->entry_cursor;
 	c->w->slow_hint = c->w->h_ctr->slow_cursor + 1u;
+	c->w->count_known = true; c->w->count_needed = c->w->h_ctr->count_pending != 0u;
 	if (getenv("MC33_HIP_VERBOSE"))
 		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, record batches %u)\n", c->w->h_ctr->entry_cursor,
 		        c->w->h_ctr->slow_cursor, c->w->h_ctr->dirty_cursor, c->w->h_ctr->batch_cursor);

@@ -70,6 +70,18 @@ def test_both_slow_emit_kernels(products, reflibs, slots, monkeypatch):
     check(products, reflibs, "f32", data, 0.0, r0, d, "cos64 slots=%s" % slots)
 
 
+@pytest.mark.parametrize("launch", ["0", "1"])
+def test_identity_counts_with_and_without_their_own_launch(products, reflibs, launch, monkeypatch):
+    """Triangles of cells with a corner equal to the isovalue are counted by vertex identity (MC:1235) - by k_slow_count when the
+    context's last extraction had such cells, otherwise by k_seg_fix on its way through the segment.  Forced either way."""
+    monkeypatch.setenv("MC33_HIP_SLOW_COUNT", launch)
+    for seed, iso in ((1, 0.0), (1, 1.0), (2, 0.0), (7, 2.0)):
+        check(products, reflibs, "f32", fx.noise_quant(32, seed), iso, label="quant s%d iso %g count=%s" % (seed, iso, launch))
+    check(products, reflibs, "f32", fx.noise_quant(0, 4, L=2, shape=(20, 20, 20)), 0.0, label="quant L2 count=%s" % launch)
+    check(products, reflibs, "u16", fx.noise_u16(24, 3, mod=7), 3.0, label="u16 mod 7 count=%s" % launch)
+    check(products, reflibs, "u8", (fx.noise_quant(40, 5, L=6) * 20 + 100).astype(np.uint8), 100.0, label="u8 integer iso count=%s" % launch)
+
+
 @pytest.mark.parametrize("shape", [(2, 2, 2), (2, 3, 5), (3, 2, 2), (9, 17, 33), (5, 70, 3), (4, 3, 600), (66, 65, 258)])
 def test_ragged_shapes(products, reflibs, shape):
     check(products, reflibs, "f32", fx.noise_f32(0, 11, shape=shape), 0.05, label="ragged %s" % (shape,))
