@@ -1865,6 +1865,14 @@ struct SweepWalk {
 	uint32_t sg, y, nseg, ny;
 	uint64_t zbase;  // z * nseg * ny
 	__device__ SweepWalk(const Params &P, uint64_t q) : nseg(P.nseg), ny(P.ny) {
+		if ((q >> 32) == 0) {  // (32-bit divisions where they do: a 64-bit one is ~80 instructions, and every load of the scan waits for two)
+			const uint32_t q32 = (uint32_t)q, zy = q32 / P.nseg;
+			sg = q32 - zy * P.nseg;
+			const uint32_t z = zy / P.ny;
+			y = zy - z * P.ny;
+			zbase = (uint64_t)z * P.nseg * P.ny;
+			return;
+		}
 		const uint64_t zy = q / P.nseg;
 		sg = (uint32_t)(q % P.nseg);
 		const uint64_t z = zy / P.ny;
@@ -1933,6 +1941,17 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PerLane<ScanArgs> A, u
 	Counters *ctr = sa.ctr;
 	__shared__ uint32_t sv[4], st[4];
 	__shared__ uint64_t s_bv[4], s_bt[4];
+	// (the chunk's own counts are asked for first: the sums before the chunk end in a block barrier, and no load crosses one)
+	const uint64_t q0 = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+	uint32_t cv[SCAN_PER_THREAD], ct[SCAN_PER_THREAD], v = 0, t = 0, raw[SCAN_PER_THREAD];
+	uint64_t st_idx[SCAN_PER_THREAD];
+	SweepWalk walk(P, q0);
+#pragma unroll
+	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
+		st_idx[k] = (q0 + k < n) ? walk.store() : 0;
+		walk.next();
+		raw[k] = seg_cnt[st_idx[k]];  // (position 0 for the lanes beyond the end: a valid address, the value is dropped)
+	}
 	uint64_t bv = 0, bt = 0;  // vertices / triangles of all chunks before this one
 	const uint32_t grp = grV ? blockIdx.x / SCAN_GROUP : 0u;
 	for (uint32_t k = threadIdx.x; k < grp; k += 256u) { bv += grV[k]; bt += grT[k]; }
@@ -1942,15 +1961,9 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PerLane<ScanArgs> A, u
 	__syncthreads();
 	bv = s_bv[0] + s_bv[1] + s_bv[2] + s_bv[3]; bt = s_bt[0] + s_bt[1] + s_bt[2] + s_bt[3];
 	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { ctr->totV = bv + bsV[blockIdx.x]; ctr->totT = bt + bsT[blockIdx.x]; }
-	const uint64_t q0 = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
-	uint32_t cv[SCAN_PER_THREAD], ct[SCAN_PER_THREAD], v = 0, t = 0;
-	uint64_t st_idx[SCAN_PER_THREAD];
-	SweepWalk walk(P, q0);
 #pragma unroll
 	for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
-		st_idx[k] = (q0 + k < n) ? walk.store() : 0;
-		walk.next();
-		const uint32_t c = (q0 + k < n) ? seg_counts(seg_cnt[st_idx[k]], tag) : 0u;
+		const uint32_t c = (q0 + k < n) ? seg_counts(raw[k], tag) : 0u;
 		cv[k] = c & 0xFFFu; ct[k] = c >> 12;
 		v += cv[k]; t += ct[k];
 	}
