@@ -21,15 +21,19 @@
 //                   record per cut cell, contiguous in the reference's visiting order, (#new vertices, #triangles) per
 //                   row segment, and one descriptor per batch of 64 records for the vertex pass.
 //   k_slow_plan   - the generic plan (MC:683-779, 788-1224: cells on the grid's 0-faces, corners equal to the isovalue).
-//   k_slow_count  - triangles of cells with a corner equal to the isovalue, by vertex identity (MC:1235).
-//   k_seg_fix     - offsets of the row segments a slow cell changed.
+//   k_slow_count  - triangles of cells with a corner equal to the isovalue, by vertex identity (MC:1235); enqueued when the
+//                   context's last extraction had such cells.
+//   k_seg_fix     - offsets of the row segments a slow cell changed (and the identity counts k_slow_count was not enqueued for).
 //   k_scan_*      - exclusive prefix sums over the row segments in the reference's sweep order: this IS the
 //                   reference's vertex / triangle numbering.
 //   k_emit_vertices<MODE> - one WAVE per batch of 64 records of one slice slot: the sample rows the batch needs staged in
 //                   LDS by cooperative 16-byte loads, one lane per vertex (MC:810-1230, 485-585).
 //   k_emit_fast_triangles - one thread per record: vertex ids of the nine shared edges through the owners' records,
-//                   triangles (MC:1235-1250); leaves the counters of the extraction in the host's pinned copy.
-//   k_emit_slow   - the generic emit of the slow records (on a second stream beside the other two on large grids).
+//                   triangles (MC:1235-1250); leaves the counters of the extraction in the host's pinned copy.  First of the
+//                   emit passes while the record set fits the last-level cache, behind the vertex pass otherwise.
+//   k_emit_slow_slots / k_emit_slow - the generic emit of the slow records: 16 lanes per record (a lane per pattern slot) in
+//                   sequence behind the fast passes when they are few; a thread per record, on large grids on a second
+//                   stream beside the fast passes, when they are many.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
