@@ -285,6 +285,22 @@ def test_repeatable_and_reusable_context(products):
     lib.lib.free_memory_grd(G)
 
 
+def test_plateau_field_with_integer_isovalue_large(products, reflibs):
+    """Unsigned char field so coarse that samples repeat along every axis, integer isovalue: every cut cell has a corner equal
+    to it (the CT / MRI case of the reference's file readers).  At 704^3 points that is more than a million slow records on a
+    grid large enough for the slow emit pass to go beside the fast ones on the second stream (a thread per record, vertex
+    pass first) - the configuration the small fixtures never reach; then the half-integer isovalue beside it through the
+    same object (few slow records: 16 lanes each, in sequence), and the integer one again."""
+    f, _, _ = fx.cos_field(704)
+    data = np.round(128.0 + 40.0 * f).astype(np.uint8)
+    del f
+    for iso in (100.0, 100.5, 100.0):
+        got = products["u8"].isosurface(data, iso)
+        ref = reflibs["u8"].isosurface(data, iso)
+        ev, en, vb, nb = assert_surface_parity(got, ref, 704.0, "u8 plateaus 704 iso %g" % iso, bit_exact=True)
+        print("u8 plateaus 704 iso %g nV %d nT %d bit-exact V %s N %s" % (iso, got.nV, got.nT, vb, nb))
+
+
 def test_config2_cos1024_full_size(products, reflibs):
     """BASELINE.json configs[2] at full size through the reference C API: 1024^3 float grid (4 GiB upload),
     iso 0 - counts as published in SURVEY.md section 6, triangles identical to the reference run on this host,
