@@ -1288,7 +1288,8 @@ MC33_HD SegBase2 seg_base_pair(const SegBase *p) {
 }
 // (before: the record before this one in the array, o1 when x - 1 is wanted - the caller has it from the load of `en` itself)
 template <typename T>
-MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const EntryA &before, uint32_t s, uint32_t self_index, const URef &ids) {
+MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const EntryA &before, uint32_t s, uint32_t self_index, const URef &ids,
+                                 const uint32_t *known_below = nullptr, uint32_t *keep_below = nullptr) {  // (developer experiment: the positions of x in segments A, B, C given / kept)
 	// (a ghost slice of a z-slab; z = zs + s / (nseg ny), without the division)
 	if (c.z_emit > c.P.zs && (uint64_t)s < (uint64_t)(c.z_emit - c.P.zs) * c.P.nseg * c.P.ny) return;
 	const uint32_t xl = en.w0 & 0xFFu;
@@ -1312,9 +1313,10 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const Ent
 		const bool needseg[3] = {need[0] || need[3], need[2] || need[4], need[5]};
 		const uint64_t dz = (uint64_t)c.P.nseg * c.P.ny;  // segment index: ((z - zs) nseg + seg) ny + y
 		const uint64_t gs[3] = {(uint64_t)s - (needseg[0] ? dz : 0ull), (uint64_t)s - (needseg[1] ? 1ull : 0ull), (uint64_t)s - (needseg[2] ? dz + 1ull : 0ull)};
-		DirWord sd[3];
+		DirWord sd[3] = {};
 		uint32_t svb[3];
-		for (int g = 0; g < 3; g++) sd[g] = dir_word(c, gs[g], xl);  // round trip 1: one 16-byte directory word per segment ...
+		if (!known_below)
+			for (int g = 0; g < 3; g++) sd[g] = dir_word(c, gs[g], xl);  // round trip 1: one 16-byte directory word per segment ...
 		// ... and the bases: B's came with this segment's; A's (y, z-1) and C's (y-1, z-1) are neighbours too
 		const uint64_t sa = (uint64_t)s - ((needseg[0] || needseg[2]) ? dz : 0ull);
 		const SegBase2 ap = seg_base_pair(c.seg_base + (sa ? sa - 1ull : 0ull));
@@ -1326,7 +1328,8 @@ MC33_HD void emit_fast_triangles(const EmitCtx<T> &c, const Entry &en, const Ent
 		oi[1] = need[1] ? self_index - 1 : self_index;  // o1: the cell x-1 is active whenever needed ...
 		oa[1] = need[1] ? before : entry_a(en);         // ... and its record the one before this one
 		uint32_t below[3];
-		for (int g = 0; g < 3; g++) below[g] = record_rank(sd[g], xl);  // the record of x in that segment (or where it would be)
+		for (int g = 0; g < 3; g++) below[g] = known_below ? known_below[g] : record_rank(sd[g], xl);  // the record of x in that segment (or where it would be)
+		if (keep_below) for (int g = 0; g < 3; g++) keep_below[g] = below[g];
 		// round trip 2: halves A of the records.  x - 1 is the record before x's position (it is active whenever needed): the two
 		// of a segment come as a pair, from the record before x's on (x's own position when that is the array's first record)
 		oi[3] = need[3] ? below[0] : self_index; oi[0] = need[0] ? below[0] - 1 : self_index;

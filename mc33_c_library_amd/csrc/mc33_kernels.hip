@@ -2011,6 +2011,9 @@ struct EmitArgs {
 	uint32_t batch_cap;
 	uint32_t stage_rows;  // every sample row of the grid starts on a 16-byte boundary: k_emit_vertices may stage rows in LDS
 	Counters *host_ctr;   // pinned host copy of the counters: the triangle pass (the last kernel of an extraction) leaves them there
+#ifdef MC33_DEV
+	uint32_t *below_idx;  // [record][3] (developer experiment MC33_HIP_TRI_BELOW): positions of x in the three neighbouring row segments
+#endif
 };
 
 // The fast emit passes take the records in storage order, which k_slots made (4 slices of a tile column, next
@@ -2465,6 +2468,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 // instructions per 64 records.  Bit-identical, and slower: 568 against 395 us per isovalue at C5.  A batch is a chain of
 // dependent steps - directory words, run bounds, staging, LDS, ids - and 16 waves per CU do not hide it; one thread per
 // record at 32 waves per CU does.  Dropped.)
+#ifdef MC33_DEV
+template <int BELOW = 0>  // developer experiment: 1 = keep the owner positions found through the directory, 2 = take them from that array instead
+#else
+constexpr int BELOW = 0;
+#endif
 __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	__shared__ uint32_t s_id[13][256];
 	__shared__ EntryB s_fast_b[256];
@@ -2482,7 +2490,11 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	const uint32_t e0 = ok && e < w.end ? e : 0u;  // (records 0 and 1 exist in every allocation)
 	uint32_t seg = c.entry_seg[e0];
 	EntryA2 pair = entry_pair(c.entries_a + (e0 ? e0 - 1u : 0u));  // the record and the one before it (the owner of two of its edges, mostly)
-	asm volatile("" ::"v"(seg), "v"(pair.lo.a0), "v"(pair.hi.a0));
+	uint32_t kb[3] = {0u, 0u, 0u};
+#ifdef MC33_DEV
+	if (BELOW == 2) { kb[0] = a.below_idx[3ull * e0]; kb[1] = a.below_idx[3ull * e0 + 1u]; kb[2] = a.below_idx[3ull * e0 + 2u]; }  // (with the record)
+#endif
+	asm volatile("" ::"v"(seg), "v"(pair.lo.a0), "v"(pair.hi.a0), "v"(kb[0]), "v"(kb[1]), "v"(kb[2]));
 	s_fast_b[threadIdx.x] = fb;
 	__syncthreads();
 	// The counters of the extraction for the host, straight into its pinned copy (everything before this kernel on the stream
@@ -2504,11 +2516,19 @@ __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	while (e < w.end) {
 		const EntryA ea = e ? pair.hi : pair.lo;
 		const Entry en = entry_join(ea, ctx_half_b(c, ea, e));
+#ifdef MC33_DEV
+		if (BELOW == 1) { uint32_t kept[3] = {e, e, e}; if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, pair.lo, seg, e, ids, nullptr, kept); for (int g = 0; g < 3; g++) a.below_idx[3ull * e + g] = kept[g]; }
+		else if (BELOW == 2) { if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, pair.lo, seg, e, ids, kb); }
+		else
+#endif
 		if (!(en.w3 & ENTRY_SLOW)) emit_fast_triangles(c, en, pair.lo, seg, e, ids);
 		e += w.stride;
 		if (e >= w.end) break;
 		seg = c.entry_seg[e];
 		pair = entry_pair(c.entries_a + e - 1u);
+#ifdef MC33_DEV
+		if (BELOW == 2) { kb[0] = a.below_idx[3ull * e]; kb[1] = a.below_idx[3ull * e + 1u]; kb[2] = a.below_idx[3ull * e + 2u]; }
+#endif
 		asm volatile("" ::"v"(seg), "v"(pair.lo.a0), "v"(pair.hi.a0));
 	}
 }
@@ -3747,7 +3767,22 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 		MC33_LAUNCH_SLOW(ss);
 		HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
 	}
-	if (tri_first) hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, sv, a);
+#ifdef MC33_DEV
+	// developer experiment (MC33_HIP_TRI_BELOW=1): what would the triangle pass take if every record knew where its owners' records
+	// are?  A first pass keeps the positions it finds through the directory (k_emit_fast_triangles<1>), a second one takes them from
+	// that array with the record and never looks at the directory (<2>: same triangles) - the second is the one to time.
+	static uint32_t *s_below = nullptr; static uint64_t s_below_cap = 0;
+	const bool tri_below = env_u32("MC33_HIP_TRI_BELOW", 0) != 0;
+	a.below_idx = nullptr;
+	if (tri_below) {
+		if (s_below_cap < c->w->entry_cap) { (void)hipFree(s_below); s_below = nullptr; HIP_TRY(hipMalloc(&s_below, c->w->entry_cap * 12ull)); s_below_cap = c->w->entry_cap; }
+		a.below_idx = s_below;
+	}
+#define MC33_LAUNCH_TRI(st) do { if (tri_below) { hipLaunchKernelGGL(k_emit_fast_triangles<1>, dim3(blocks), dim3(256), 0, st, a); hipLaunchKernelGGL(k_emit_fast_triangles<2>, dim3(blocks), dim3(256), 0, st, a); } else hipLaunchKernelGGL(k_emit_fast_triangles<0>, dim3(blocks), dim3(256), 0, st, a); } while (0)
+#else
+#define MC33_LAUNCH_TRI(st) hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, st, a)
+#endif
+	if (tri_first) MC33_LAUNCH_TRI(sv);
 #ifdef MC33_DEV
 	if (env_u32("MC33_HIP_OLD_VERTEX_PASS", 0)) hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);  // (the round-2 pass, for A/B timing)
 	else
@@ -3765,7 +3800,8 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 		default: hipLaunchKernelGGL(k_emit_vertices<3>, vgrid, dim3(256), 0, c->stream, a); break;
 		}
 	}
-	if (!tri_first) hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, sv, a);
+	if (!tri_first) MC33_LAUNCH_TRI(sv);
+#undef MC33_LAUNCH_TRI
 	if (fork_all) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
 	if (!fork_slow) MC33_LAUNCH_SLOW(ss);
 #undef MC33_LAUNCH_SLOW
