@@ -70,6 +70,57 @@ def test_both_slow_emit_kernels(products, reflibs, slots, monkeypatch):
     check(products, reflibs, "f32", data, 0.0, r0, d, "cos64 slots=%s" % slots)
 
 
+def _fnv():
+    """FNV-1a-64 as tests/golden/make_golden.py computed it: the oracle library's C routine when it travelled (it is the checker,
+    never the thing checked), the byte loop of tests/mc33_capi.py otherwise."""
+    import os
+    from mc33_oracle import Oracle, oracle_path
+    if os.path.exists(oracle_path("f32")):
+        return Oracle("f32").fnv
+    from mc33_capi import fnv1a64
+    return fnv1a64
+
+
+@pytest.mark.parametrize("name", sorted(__import__("golden_cases").GOLDEN))
+def test_product_matches_committed_golden_vectors(products, name):
+    """The product against the COMMITTED golden vectors (tests/golden/golden.json + .npz, made by tests/golden/make_golden.py from
+    the unmodified reference): counts, FNV-1a-64 of T / V / N, the arrays where they are committed.  The other parity tests
+    compare with oracle/_ref/*.so, which is git-ignored and rebuilt per container: this one hangs on nothing but the repository."""
+    from golden_cases import GENERATORS, GOLDEN, INCLINED, check_against_golden
+    data, r0, d = GENERATORS[name]()
+    lib = products[GOLDEN[name]["dtype"]]
+    inc = INCLINED.get(name)
+    if inc:
+        lib.set_triangular(bool(inc[1]))
+    try:
+        s = lib.isosurface(data, GOLDEN[name]["iso"], r0, d, inclined=inc[0] if inc else None)
+    finally:
+        if inc:
+            lib.set_triangular(False)
+    check_against_golden(name, s, _fnv(), np.ascontiguousarray(data, dtype=lib.np_dtype))
+
+
+@pytest.mark.parametrize("switch", ["MC33_HIP_TRI_FIRST=0", "MC33_HIP_TRI_FIRST=1", "MC33_HIP_NO_FORK=0", "MC33_HIP_NO_FORK=1",
+                                    "MC33_HIP_TRI_FIRST=0,MC33_HIP_NO_FORK=1", "MC33_HIP_TRI_FIRST=1,MC33_HIP_NO_FORK=1",
+                                    "MC33_HIP_NO_PACK=1", "MC33_HIP_NO_STAGE=1", "MC33_HIP_SLOW_SLOTS=0,MC33_HIP_NO_FORK=0"])
+def test_every_emit_order_and_code_path_switch(products, reflibs, switch, monkeypatch):
+    """The library picks the order of its emit passes, the streams they run on, the packed / unpacked form of the sweep and the
+    staged / direct form of the vertex pass from what the last extraction looked like; each switch below forces one of those
+    choices - every one must give the reference's arrays: on a degenerate-rich float grid (slow records, aliases), on a smooth
+    float grid with several row segments and tiles, and on ushort grids (packed samples)."""
+    for kv in switch.split(","):
+        k, v = kv.split("=")
+        monkeypatch.setenv(k, v)
+    check(products, reflibs, "f32", fx.noise_quant(32, 2), 1.0, label="quant s2 iso 1 %s" % switch)
+    check(products, reflibs, "f32", fx.noise_f32(0, 11, shape=(66, 65, 258)), 0.05, label="ragged noise %s" % switch)
+    data, r0, d = fx.cos_field(130)
+    for _ in range(2):  # (twice: the second call decides by the first one's counts)
+        check(products, reflibs, "f32", data, 0.0, r0, d, "cos130 %s" % switch)
+    check(products, reflibs, "u16", fx.noise_u16(24, 3, 7), 3.0, label="u16 mod 7 %s" % switch)
+    check(products, reflibs, "u16", fx.cos_field_u16(600, 150, 70), 32768.0, label="u16 smooth integer iso %s" % switch)
+    check(products, reflibs, "u8", (fx.noise_quant(40, 5, L=6) * 20 + 100).astype(np.uint8), 100.0, label="u8 integer iso %s" % switch)
+
+
 @pytest.mark.parametrize("launch", ["0", "1"])
 def test_identity_counts_with_and_without_their_own_launch(products, reflibs, launch, monkeypatch):
     """Triangles of cells with a corner equal to the isovalue are counted by vertex identity (MC:1235) - by k_slow_count when the
@@ -451,14 +502,18 @@ def test_double_grids(products, reflibs, seed):
     chk(fx.noise_f32(0, seed, shape=(3, 5, 300)).astype(np.float64), 0.0, label="f64 ragged")
 
 
-@pytest.mark.parametrize("dtype", ["f32", "u16"])
+@pytest.mark.parametrize("dtype", ["f32", "u16", "u8", "u32", "f64"])
 def test_grd_orthogonal_flavour(reflibs, dtype):
     """Callers compiled with -DGRD_ORTHOGONAL see smaller _GRD / MC33 structs (reference marching_cubes_33.h:116-120,
     :173-175): the libMC33_<type>_ortho.so flavour against the reference built the same way."""
     from mc33_capi import MC33Lib, product_path, ref_path
     P, R = MC33Lib(product_path(dtype, ortho=True), dtype, ortho=True), MC33Lib(ref_path(dtype, ortho=True), dtype, ortho=True)
-    cases = ([(fx.cos_field(70)[0], 0.0, (-4.0, -4.0, -4.0), (8 / 69,) * 3), (fx.noise_quant(24, 2), 1.0, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0))]
-             if dtype == "f32" else [(fx.noise_u16(24, 3, 7), 3.0, None, None), (fx.cos_field_u16(60, 50, 40), 25268.5, None, (0.5, 0.5, 0.5))])
+    cases = {"f32": [(fx.cos_field(70)[0], 0.0, (-4.0, -4.0, -4.0), (8 / 69,) * 3), (fx.noise_quant(24, 2), 1.0, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0))],
+             "f64": [(fx.cos_field(60)[0].astype(np.float64), 0.0, (-4.0, -4.0, -4.0), (8 / 59,) * 3),
+                     (fx.noise_quant(24, 2).astype(np.float64), 1.0, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0))],
+             "u16": [(fx.noise_u16(24, 3, 7), 3.0, None, None), (fx.cos_field_u16(60, 50, 40), 25268.5, None, (0.5, 0.5, 0.5))],
+             "u8": [(fx.noise_u8(24, 3, 7), 3.0, None, None), (fx.noise_u8(40, 5), 100.5, None, (0.5, 0.5, 0.5))],
+             "u32": [(fx.noise_u32(24, 3, 7), 3.0, None, None), (fx.noise_u32(32, 5), 2.0e9, (1.0, 0.0, 0.0), (0.5, 0.25, 1.0))]}[dtype]
     for data, iso, r0, d in cases:
         got, ref = P.isosurface(data, iso, r0, d), R.isosurface(data, iso, r0, d)
         ev, en, vb, nb = assert_surface_parity(got, ref, float(max(data.shape)), "ortho " + dtype)
@@ -466,7 +521,8 @@ def test_grd_orthogonal_flavour(reflibs, dtype):
         assert (got.nV, got.nT) == (reflibs[dtype].isosurface(data, iso, r0, d).nV, ref.nT)  # and the same surface as the full-layout build
 
 
-@pytest.mark.parametrize("dtype,ortho", [("f32", False), ("u16", False), ("u8", False), ("u32", False), ("f64", False), ("f32", True), ("u16", True)])
+@pytest.mark.parametrize("dtype,ortho", [("f32", False), ("u16", False), ("u8", False), ("u32", False), ("f64", False), ("f32", True), ("u16", True),
+                                         ("u8", True), ("u32", True), ("f64", True)])
 def test_normal_neg_flavour(reflibs, dtype, ortho):
     """libMC33_<type>[_ortho]_nneg.so = the reference compiled with MC33_NORMAL_NEG 1 (source/libMC33.c:20-22; the switch
     applies to every GRD_data_type and combines with GRD_ORTHOGONAL): normals negated (marching_cubes_33.c:509-513), first
@@ -762,8 +818,8 @@ def test_surface_blocks_are_recycled_safely(products, reflibs):
 def test_config4_u16_full_size(products, reflibs):
     """BASELINE.json configs[4] at FULL size: 2048 x 2048 x 1024 unsigned short grid - exactly 2^32 points, so every
     64-bit index path is exercised - one upload, 8 isovalues 15268.5 + 5000 k through create_MC33 + calculate_isosurfaces.
-    All 8 surfaces: counts equal to the reference's size_of_isosurface; two of them element-wise (bit for bit) equal to
-    the reference's calculate_isosurface on the same buffer.  Before that, on the device-level API: two z-slabs of the
+    All 8 surfaces: counts equal to the reference's size_of_isosurface, and every one of them element-wise (bit for bit)
+    equal to the reference's calculate_isosurface on the same buffer.  Before that, on the device-level API: two z-slabs of the
     grid concatenate to the whole-volume result."""
     import ctypes as C
     import torch
@@ -820,7 +876,7 @@ def test_config4_u16_full_size(products, reflibs):
         pv, pt = C.c_uint(0), C.c_uint(0)
         L.size_of_isosurface(M, C.c_float(iso), C.byref(pv), C.byref(pt))
         assert (pv.value, pt.value) == (nV.value, nT.value), k
-    for k in (0, 5):
+    for k in range(8):
         got = lib.copy_surface(out[k])
         S = R.calculate_isosurface(Mr, C.c_float(isos[k]))
         want = ref.copy_surface(S)
@@ -829,8 +885,8 @@ def test_config4_u16_full_size(products, reflibs):
         assert vb and nb
         assert int(got.T.max()) == got.nV - 1 and np.all(got.color == got.color[0])
         del got, want
-    for k in range(8):
-        L.free_surface_memory(out[k])
+        L.free_surface_memory(out[k])  # (one at a time: eight host copies of 1.6 GB surfaces need not be alive together)
+        out[k] = None
     L.free_MC33(M); L.free_memory_grd(G)
     R.free_MC33(Mr); R.free_memory_grd(Gr)
     del keep, keepr
