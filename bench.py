@@ -214,19 +214,18 @@ def c_api_walls(field, r0, d, iso, calls=6):
         lib.lib.free_surface_memory(S)
         frees.append((time.perf_counter() - t1) * 1e3)
         walls.append((t1 - t0) * 1e3)
-    # ... and with MC33_HOST_CACHE_MB raised (read per call): free_surface_memory then keeps the 200 MB of blocks for the next surface
-    # instead of unmapping them - the default, 64 MB, is for a drop-in library that should not sit on memory after `free`
-    cached = []
+    # ... and with nothing kept by free_surface_memory (MC33_HOST_CACHE_MB=0, read per call: every surface in fresh pages that
+    # go back to the kernel afterwards - what the default was until round 5 for surfaces beyond 64 MB)
+    uncached, uncached_free = [], []
     old = os.environ.get("MC33_HOST_CACHE_MB")
-    os.environ["MC33_HOST_CACHE_MB"] = "1024"
+    os.environ["MC33_HOST_CACHE_MB"] = "0"
     for _ in range(calls):
         t0 = time.perf_counter()
         S = lib.lib.calculate_isosurface(M, C.c_float(iso))
-        cached.append((time.perf_counter() - t0) * 1e3)
+        t1 = time.perf_counter()
         lib.lib.free_surface_memory(S)
-    os.environ["MC33_HOST_CACHE_MB"] = "0"   # (hand the kept blocks back: a release with a zero limit frees)
-    S = lib.lib.calculate_isosurface(M, C.c_float(iso))
-    lib.lib.free_surface_memory(S)
+        uncached_free.append((time.perf_counter() - t1) * 1e3)
+        uncached.append((t1 - t0) * 1e3)
     if old is None:
         del os.environ["MC33_HOST_CACHE_MB"]
     else:
@@ -240,12 +239,14 @@ def c_api_walls(field, r0, d, iso, calls=6):
             "upload_GBps": host.nbytes / (create_ms * 1e-3) / 1e9,
             "calculate_isosurface_first_ms": walls[0], "calculate_isosurface_steady_ms": steady, "calls": calls,
             "free_surface_memory_ms": sorted(frees)[len(frees) // 2],
-            "calculate_isosurface_steady_ms_MC33_HOST_CACHE_MB_1024": sorted(cached[1:])[len(cached[1:]) // 2],
+            "calculate_isosurface_steady_ms_MC33_HOST_CACHE_MB_0": sorted(uncached[1:])[len(uncached[1:]) // 2],
+            "free_surface_memory_ms_MC33_HOST_CACHE_MB_0": sorted(uncached_free)[len(uncached_free) // 2],
             "surface_bytes_to_host": surf_bytes, "d2h_inclusive_GBps": surf_bytes / (steady * 1e-3) / 1e9,
             "Mvoxels_per_s_pcie_inclusive": cells / (steady * 1e-3) / 1e6, "vertices": nV, "triangles": nT,
             "note": "host walls of the reference's own API on this workload: create_MC33 = upload of _GRD.F; calculate_isosurface = extraction + "
-                    "device-to-host copy of V, N, T, color into malloc blocks (first call: fresh pages; steady: median of the rest, blocks recycled by "
-                    "free_surface_memory).  PCIe-inclusive - never `value`"}
+                    "device-to-host copy of V, N, T, color into malloc blocks (first call: fresh pages; steady: median of the rest, no environment "
+                    "variable set - free_surface_memory keeps the blocks of the surface it releases for the next one; ..._MC33_HOST_CACHE_MB_0: "
+                    "nothing kept).  PCIe-inclusive - never `value`"}
 
 
 def spread(a):

@@ -86,6 +86,11 @@ int mc33hip_set_normal_neg(mc33hip_ctx *c, int on);
 
 /* Stream all work is enqueued on (a hipStream_t passed as void*; NULL = the default stream). */
 int mc33hip_set_stream(mc33hip_ctx *c, void *hip_stream);
+/* ... or a non-blocking stream of the context's own, for callers without a HIP runtime of their own that drive several contexts
+ * side by side (create_MC33 with MC33_HIP_DEVICES: one context per z-slab). */
+int mc33hip_own_stream(mc33hip_ctx *c);
+/* HIP devices visible to this process (0: none, or no runtime). */
+int mc33hip_device_count(void);
 
 /* Count pass only: classification + prefix sums; the device twin of size_of_isosurface (MC:1892-1940).
  * Synchronises the stream. */
@@ -106,7 +111,10 @@ int mc33hip_sweep_many(mc33hip_ctx *c, const double *isos, int n, const mc33hip_
  * counts of ALL isovalues before the first emit: z-slabs over several GPUs exchange them in ONE collective per step and
  * then emit every isovalue at its global id base (mc33_c_library_amd/slabs.py: extract_slab_many).  On one GPU
  * mc33hip_sweep_many + mc33hip_extract per isovalue is faster: an emit right behind its own tail finds the records in the
- * last-level cache.  Falls back to mc33hip_sweep_many when device memory does not allow the buffers. */
+ * last-level cache.  Falls back to mc33hip_sweep_many when device memory does not allow the buffers.
+ * At most 8 isovalues per call (MC33HIP_EINVAL beyond).  A mc33hip_count / mc33hip_extract of an isovalue or range that was
+ * NOT prepared works in the buffers of prepared isovalue #0 and drops it: its next count sweeps the grid again (same
+ * results, one more pass over the volume). */
 int mc33hip_prepare_many(mc33hip_ctx *c, const double *isos, int n, const mc33hip_range *range);
 
 /* Global number of the first vertex of the range last counted (z-slab decomposition: known only after
@@ -118,6 +126,15 @@ int mc33hip_set_id_base(mc33hip_ctx *c, unsigned int id_base);
  * is passed as a double and used as MC33_real.  Replaces the vertex/triangle appends of MC33_findCase
  * (MC:780-1252).  Asynchronous on the context's stream. */
 int mc33hip_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long long capV, unsigned long long capT);
+
+/* mc33hip_emit with the copy to the HOST pipelined behind it (what calculate_isosurface does, reference MC:1869-1879:
+ * the surface in the caller's malloc blocks): hT (nT x 3 unsigned) is copied on a stream of the context's own as soon as the
+ * passes that write T have been through, hV (nV x 3 MC33_real) and hN (nV x 3 floats) as soon as theirs have - the copies of
+ * one array run beside the kernels of the other.  nV, nT are those of the mc33hip_count before.  Only enqueues;
+ * mc33hip_download_wait returns when all three arrays are in host memory. */
+int mc33hip_emit_download(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long long capV, unsigned long long capT,
+                          void *hV, void *hN, void *hT);
+int mc33hip_download_wait(mc33hip_ctx *c);
 
 /* Whole extraction (count + emit) with ONE synchronisation at the end; fails with MC33HIP_ECAPACITY
  * (and reports the needed sizes in *out) when the buffers are too small.  This is the path

@@ -11,11 +11,13 @@
  * Deliberate difference: the grid is copied to HBM in create_MC33 and stays resident.  A caller that
  * rewrites G->F between calls sets MC33_HIP_REUPLOAD=1 (re-upload before every extraction).
  */
-#define _DEFAULT_SOURCE /* madvise */
+#define _DEFAULT_SOURCE /* madvise, clock_gettime */
 #include <malloc.h> /* malloc_usable_size: asked only about blocks this library allocated itself */
 #include <pthread.h>
 #include <stddef.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 #include <sys/mman.h>
 
@@ -53,16 +55,37 @@ _Static_assert(sizeof(MC33) == 160 + MC33_MATS && offsetof(MC33, memoryfault) ==
 #endif
 int DefaultColorMC = (int)DEFAULT_SURFACE_COLOR;
 
-/* private object: the public MC33 first, so callers can keep treating the pointer as MC33* */
+/* One z-slab of the grid on one device (the same cut as mc33_c_library_amd/slabs.py makes per rank): cell slices
+ * [z_begin, z_end), one ghost slice below (its vertices belong to the slab underneath, but the slab's triangles refer to them),
+ * resident sample planes [p_lo, p_hi] = the cells' own, one above for the central differences of the normals (MC:888-890,
+ * 1036-1038), the ghost slice's lower plane and one below that for vertices on grid points (MC:643-647).  Without
+ * MC33_HIP_DEVICES there is one slab: the whole grid on the current device. */
+#define MC33_MAX_DEVICES 16
+struct staging {     /* device staging of a result, grown on demand; two sets so that calculate_isosurfaces can */
+	void *dV, *dN, *dT; /* download one surface while the next is being extracted                           */
+	unsigned long long capV, capT;
+};
+struct mc33_private_s;
 typedef struct {
+	struct mc33_private_s *owner;
+	mc33hip_ctx *ctx;
+	int device;
+	unsigned z_begin, z_end, ghost, p_lo, p_hi;
+	struct staging set[2];
+	mc33hip_counts cnt; /* of the count in flight */
+	MC33_real iso;
+	int rc;
+	struct mc33_surface *out;   /* the surface being filled, and where this slab's vertices / triangles begin in it */
+	unsigned long long vbase, tbase;
+} mc33_slab;
+
+/* private object: the public MC33 first, so callers can keep treating the pointer as MC33* */
+typedef struct mc33_private_s {
 	MC33 pub;
 	unsigned long long magic;
-	mc33hip_ctx *ctx;
+	int nslab;           /* 1, or the number of devices named by MC33_HIP_DEVICES */
+	mc33_slab slab[MC33_MAX_DEVICES];
 	_GRD *grid;          /* for MC33_HIP_REUPLOAD */
-	struct staging {     /* device staging of a result, grown on demand; two sets so that calculate_isosurfaces can */
-		void *dV, *dN, *dT; /* download one surface while the next is being extracted                           */
-		unsigned long long capV, capT;
-	} set[2];
 	int reupload;
 	int grid_dirty;      /* MC33_grid_changed: the caller rewrote samples of G->F, upload them before the next extraction */
 	int inclined;        /* G->nonortho at create time: the MC33_spnC store */
@@ -74,6 +97,97 @@ static mc33_private *priv(MC33 *M) {
 	mc33_private *p = (mc33_private *)M;
 	return (p && p->magic == MC33_MAGIC) ? p : 0;
 }
+
+/* runs fn on every slab: the slabs of one device one after the other, the devices side by side - the device-level calls block
+ * (count: until the counters are on the host; emit: the runtime's copies into pageable memory return when the data has arrived),
+ * so every device gets a thread and its link is busy at the same time as the others'.  (Slabs that share a device - the
+ * rehearsal on a one-GPU machine - gain nothing from threads of their own: eight threads copying from one GPU into pieces of the
+ * same arrays took 10 ms where one takes 3.5, profiles/r05_capi_walls.txt.) */
+struct slab_group {
+	void *(*fn)(void *);
+	mc33_slab *slab[MC33_MAX_DEVICES];
+	int n;
+};
+static void *slab_group_run(void *arg) {
+	struct slab_group *g = (struct slab_group *)arg;
+	for (int k = 0; k != g->n; k++)
+		g->fn(g->slab[k]);
+	return 0;
+}
+static void for_each_slab(mc33_private *p, void *(*fn)(void *)) {
+	struct slab_group grp[MC33_MAX_DEVICES];
+	int ngrp = 0;
+	for (int k = 0; k != p->nslab; k++) {
+		int g = 0;
+		while (g != ngrp && grp[g].slab[0]->device != p->slab[k].device) g++;
+		if (g == ngrp) { grp[ngrp].fn = fn; grp[ngrp].n = 0; ngrp++; }
+		grp[g].slab[grp[g].n++] = &p->slab[k];
+	}
+	pthread_t th[MC33_MAX_DEVICES];
+	int started[MC33_MAX_DEVICES];
+	for (int g = 1; g < ngrp; g++)
+		started[g] = pthread_create(&th[g], 0, slab_group_run, &grp[g]) == 0;
+	slab_group_run(&grp[0]); /* the first device's on the calling thread */
+	for (int g = 1; g < ngrp; g++) {
+		if (started[g]) pthread_join(th[g], 0);
+		else slab_group_run(&grp[g]);
+	}
+}
+
+static void *slab_create(void *arg) {
+	mc33_slab *s = (mc33_slab *)arg;
+	mc33_private *p = s->owner;
+	const _GRD *G = p->grid;
+	mc33hip_grid_desc d;
+	memset(&d, 0, sizeof d);
+	d.npx = G->N[0] + 1; d.npy = G->N[1] + 1; d.npz_resident = s->p_hi - s->p_lo + 1;
+	d.plane0 = s->p_lo; d.nz_total = G->N[2];
+	for (int j = 0; j != 3; j++) { d.r0[j] = G->r0[j]; d.d[j] = G->d[j]; }
+	d.sample_bytes = (int)sizeof(GRD_data_type);
+	d.device = s->device;
+	s->rc = mc33hip_create(&s->ctx, &d);
+	if (s->rc == MC33HIP_OK) s->rc = mc33hip_set_normal_neg(s->ctx, MC33_NORMAL_NEG);
+	if (s->rc == MC33HIP_OK && p->nslab > 1) s->rc = mc33hip_own_stream(s->ctx); /* several contexts: each on a stream of its own */
+	if (s->rc == MC33HIP_OK) s->rc = mc33hip_upload_rows(s->ctx, (const void *const *const *)(G->F + s->p_lo));
+	return 0;
+}
+
+static void *slab_upload(void *arg) {
+	mc33_slab *s = (mc33_slab *)arg;
+	s->rc = mc33hip_upload_rows(s->ctx, (const void *const *const *)(s->owner->grid->F + s->p_lo));
+	return 0;
+}
+
+/* MC33_HIP_DEVICES: "all", or a comma-separated list of HIP device ordinals - the z-slabs of the grid go to these devices in this
+ * order.  An ordinal may appear several times (several slabs on one GPU: how the path is rehearsed on a one-GPU machine).
+ * Returns the number of entries (0: not set - one slab on the current device). */
+static int parse_devices(int *dev) {
+	const char *e = getenv("MC33_HIP_DEVICES");
+	if (!e || !*e)
+		return 0;
+	const int have = mc33hip_device_count();
+	if (have <= 0)
+		return 0;
+	int n = 0;
+	if (!strcmp(e, "all")) {
+		for (; n < have && n < MC33_MAX_DEVICES; n++) dev[n] = n;
+		return n;
+	}
+	while (*e && n < MC33_MAX_DEVICES) {
+		char *end = 0;
+		const long v = strtol(e, &end, 10);
+		if (end == e || v < 0 || v >= have)
+			return -1; /* not a list of devices of this machine */
+		dev[n++] = (int)v;
+		e = end;
+		while (*e == ',' || *e == ' ') e++;
+	}
+	return *e ? -1 : n;
+}
+
+static int g_objects; /* MC33 objects alive (the host block cache is trimmed when the last one goes) */
+static void cache_trim(size_t keep);
+static size_t cache_limit(int *is_set);
 
 MC33 *create_MC33(_GRD *G) {
 	if (!G || !G->F)
@@ -105,22 +219,35 @@ MC33 *create_MC33(_GRD *G) {
 		M->ca = (MC33_real)(G->d[2] / G->d[0]);
 		M->cb = (MC33_real)(G->d[2] / G->d[1]);
 	}
-	mc33hip_grid_desc d;
-	memset(&d, 0, sizeof d);
-	d.npx = G->N[0] + 1; d.npy = G->N[1] + 1; d.npz_resident = G->N[2] + 1;
-	d.plane0 = 0; d.nz_total = G->N[2];
-	for (int j = 0; j != 3; j++) { d.r0[j] = G->r0[j]; d.d[j] = G->d[j]; }
-	d.sample_bytes = (int)sizeof(GRD_data_type);
-	d.device = -1;
 	const char *e = getenv("MC33_HIP_REUPLOAD");
 	p->reupload = e && *e && *e != '0';
 	p->grid = G;
-	if (G->N[0] < 1 || G->N[1] < 1 || G->N[2] < 1 || mc33hip_create(&p->ctx, &d) != MC33HIP_OK ||
-	    mc33hip_set_normal_neg(p->ctx, MC33_NORMAL_NEG) != MC33HIP_OK ||
-	    mc33hip_upload_rows(p->ctx, (const void *const *const *)G->F) != MC33HIP_OK) {
+	__atomic_add_fetch(&g_objects, 1, __ATOMIC_RELAXED);
+	int dev[MC33_MAX_DEVICES];
+	int n = parse_devices(dev);
+	if (G->N[0] < 1 || G->N[1] < 1 || G->N[2] < 1 || n < 0) {
 		free_MC33(M);
 		return 0;
 	}
+	if (n == 0) { n = 1; dev[0] = -1; } /* the current device */
+	if ((unsigned)n > G->N[2]) n = (int)G->N[2]; /* a slab is at least one cell slice */
+	p->nslab = n;
+	for (int k = 0; k != n; k++) { /* even split along z (slabs.py: Slab) */
+		mc33_slab *s = &p->slab[k];
+		s->owner = p;
+		s->device = dev[k];
+		s->z_begin = (unsigned)((unsigned long long)k * G->N[2] / (unsigned)n);
+		s->z_end = (unsigned)((unsigned long long)(k + 1) * G->N[2] / (unsigned)n);
+		s->ghost = k ? 1u : 0u;
+		s->p_lo = s->z_begin >= s->ghost + 1u ? s->z_begin - s->ghost - 1u : 0u;
+		s->p_hi = s->z_end + 1u <= G->N[2] ? s->z_end + 1u : G->N[2];
+	}
+	for_each_slab(p, slab_create); /* the 1 / n of G->F of every device goes over its own link */
+	for (int k = 0; k != n; k++)
+		if (p->slab[k].rc != MC33HIP_OK) {
+			free_MC33(M);
+			return 0;
+		}
 	return M;
 }
 
@@ -128,16 +255,21 @@ void free_MC33(MC33 *M) {
 	mc33_private *p = priv(M);
 	if (!p)
 		return;
-	if (p->ctx) {
+	for (int q = 0; q != p->nslab; q++) {
+		mc33_slab *s = &p->slab[q];
+		if (!s->ctx)
+			continue;
 		for (int k = 0; k != 2; k++) {
-			if (p->set[k].dV) mc33hip_device_free(p->ctx, p->set[k].dV);
-			if (p->set[k].dN) mc33hip_device_free(p->ctx, p->set[k].dN);
-			if (p->set[k].dT) mc33hip_device_free(p->ctx, p->set[k].dT);
+			if (s->set[k].dV) mc33hip_device_free(s->ctx, s->set[k].dV);
+			if (s->set[k].dN) mc33hip_device_free(s->ctx, s->set[k].dN);
+			if (s->set[k].dT) mc33hip_device_free(s->ctx, s->set[k].dT);
 		}
-		mc33hip_destroy(p->ctx);
+		mc33hip_destroy(s->ctx);
 	}
 	p->magic = 0;
 	free(p);
+	if (__atomic_sub_fetch(&g_objects, 1, __ATOMIC_RELAXED) == 0)
+		cache_trim(cache_limit(0)); /* no extractor left: what free_surface_memory kept beyond the plain limit goes back */
 }
 
 /* --- mult_Abf (reference header :186-191, MC33_util_grd.c:86-114) --------------------------------- */
@@ -169,13 +301,18 @@ static int refresh_grid(mc33_private *p) {
 	if (p->inclined) { /* the reference calls through mult_Abf for every vertex (MC:608, 612) */
 		if (mult_Abf != _multA_bf && mult_Abf != _multTSA_bf)
 			return MC33HIP_EINVAL; /* a caller-supplied function cannot run on the GPU */
-		if (mc33hip_set_inclined(p->ctx, p->grd_A, p->grd_Ai, mult_Abf == _multTSA_bf) != MC33HIP_OK)
-			return MC33HIP_EINVAL;
+		for (int k = 0; k != p->nslab; k++)
+			if (mc33hip_set_inclined(p->slab[k].ctx, p->grd_A, p->grd_Ai, mult_Abf == _multTSA_bf) != MC33HIP_OK)
+				return MC33HIP_EINVAL;
 	}
 	if (!p->reupload && !p->grid_dirty)
 		return 0;
 	p->grid_dirty = 0;
-	return mc33hip_upload_rows(p->ctx, (const void *const *const *)p->grid->F);
+	for_each_slab(p, slab_upload);
+	for (int k = 0; k != p->nslab; k++)
+		if (p->slab[k].rc != MC33HIP_OK)
+			return p->slab[k].rc;
+	return MC33HIP_OK;
 }
 
 /* Extension (not in the reference, which reads G->F anew on every call, MC:1792, 1832-1868): tells the extractor that
@@ -187,15 +324,40 @@ void MC33_grid_changed(MC33 *M) {
 		p->grid_dirty = 1;
 }
 
+/* count pass of one slab (blocks until its counters are on the host) */
+static void *slab_count(void *arg) {
+	mc33_slab *s = (mc33_slab *)arg;
+	mc33hip_range r;
+	r.z_begin = s->z_begin; r.z_end = s->z_end; r.ghost_below = s->ghost; r.id_base = 0;
+	memset(&s->cnt, 0, sizeof s->cnt);
+	s->rc = mc33hip_count(s->ctx, (double)s->iso, &r, &s->cnt);
+	return 0;
+}
+
+/* Counts of every slab, side by side; the totals in *tot.  Vertex ids and triangle slots of slab k begin at the sums over the
+ * slabs below it (the reference numbers vertices in sweep order, so z-slabs concatenate). */
+static int count_slabs(mc33_private *p, MC33_real iso, mc33hip_counts *tot) {
+	memset(tot, 0, sizeof *tot);
+	int rc = refresh_grid(p);
+	if (rc != MC33HIP_OK)
+		return rc;
+	for (int k = 0; k != p->nslab; k++) p->slab[k].iso = iso;
+	for_each_slab(p, slab_count);
+	for (int k = 0; k != p->nslab; k++) {
+		if (p->slab[k].rc != MC33HIP_OK)
+			return p->slab[k].rc;
+		tot->nV += p->slab[k].cnt.nV; tot->nT += p->slab[k].cnt.nT; tot->active_cells += p->slab[k].cnt.active_cells;
+	}
+	return (tot->nV > 0xFFFFFFFFull || tot->nT > 0xFFFFFFFFull) ? MC33HIP_EOVERFLOW : MC33HIP_OK;
+}
+
 unsigned long long size_of_isosurface(MC33 *M, MC33_real iso, unsigned int *nV, unsigned int *nT) {
 	mc33_private *p = priv(M);
 	mc33hip_counts cnt;
-	mc33hip_range r;
 	memset(&cnt, 0, sizeof cnt);
 	if (p) {
-		r.z_begin = 0; r.z_end = M->nz; r.ghost_below = 0; r.id_base = 0;
 		M->iso = iso;
-		if (refresh_grid(p) != MC33HIP_OK || mc33hip_count(p->ctx, iso, &r, &cnt) != MC33HIP_OK)
+		if (count_slabs(p, iso, &cnt) != MC33HIP_OK)
 			memset(&cnt, 0, sizeof cnt);
 	}
 	if (nV) *nV = (unsigned int)cnt.nV;
@@ -204,28 +366,30 @@ unsigned long long size_of_isosurface(MC33 *M, MC33_real iso, unsigned int *nV, 
 	return cnt.nV * (6 * sizeof(MC33_real) + sizeof(int)) + cnt.nT * (3 * sizeof(int)) + sizeof(surface);
 }
 
-static int ensure_staging(mc33_private *p, struct staging *g, unsigned long long nV, unsigned long long nT) {
+static int ensure_staging(mc33_slab *s, struct staging *g, unsigned long long nV, unsigned long long nT) {
 	if (g->capV < nV) {
-		if (g->dV) mc33hip_device_free(p->ctx, g->dV);
-		if (g->dN) mc33hip_device_free(p->ctx, g->dN);
+		if (g->dV) mc33hip_device_free(s->ctx, g->dV);
+		if (g->dN) mc33hip_device_free(s->ctx, g->dN);
 		g->dV = g->dN = 0; g->capV = 0;
 		unsigned long long cap = nV + nV / 8 + 1024;
-		if (mc33hip_device_alloc(p->ctx, &g->dV, cap * 3 * sizeof(MC33_real)) != MC33HIP_OK) return -1;
-		if (mc33hip_device_alloc(p->ctx, &g->dN, cap * 12) != MC33HIP_OK) return -1;
+		if (mc33hip_device_alloc(s->ctx, &g->dV, cap * 3 * sizeof(MC33_real)) != MC33HIP_OK) return -1;
+		if (mc33hip_device_alloc(s->ctx, &g->dN, cap * 12) != MC33HIP_OK) return -1;
 		g->capV = cap;
 	}
 	if (g->capT < nT) {
-		if (g->dT) mc33hip_device_free(p->ctx, g->dT);
+		if (g->dT) mc33hip_device_free(s->ctx, g->dT);
 		g->dT = 0; g->capT = 0;
 		unsigned long long cap = nT + nT / 8 + 1024;
-		if (mc33hip_device_alloc(p->ctx, &g->dT, cap * 12) != MC33HIP_OK) return -1;
+		if (mc33hip_device_alloc(s->ctx, &g->dT, cap * 12) != MC33HIP_OK) return -1;
 		g->capT = cap;
 	}
 	return 0;
 }
 
-/* GPU part of calculate_isosurface: the surface of `iso` into staging set g (device memory), its sizes into *cnt */
+/* GPU part of one surface of calculate_isosurfaces (one slab: the whole grid): the surface of `iso` into staging set g (device
+ * memory), its sizes into *cnt */
 static int extract_to_staging(mc33_private *p, struct staging *g, MC33_real iso, mc33hip_counts *cnt) {
+	mc33_slab *s = &p->slab[0];
 	mc33hip_range r;
 	r.z_begin = 0; r.z_end = p->pub.nz; r.ghost_below = 0; r.id_base = 0;
 	memset(cnt, 0, sizeof *cnt);
@@ -234,26 +398,30 @@ static int extract_to_staging(mc33_private *p, struct staging *g, MC33_real iso,
 		return rc;
 	/* one pass with the staging buffers of an earlier call; if they are too small the counts come back
 	 * anyway, the buffers grow and only the emit pass is repeated */
-	rc = mc33hip_extract(p->ctx, iso, &r, g->dV, g->dN, g->dT, g->capV, g->capT, cnt);
+	rc = mc33hip_extract(s->ctx, iso, &r, g->dV, g->dN, g->dT, g->capV, g->capT, cnt);
 	if (rc == MC33HIP_ECAPACITY) {
-		rc = ensure_staging(p, g, cnt->nV, cnt->nT) ? MC33HIP_ENOMEM : mc33hip_emit(p->ctx, g->dV, g->dN, g->dT, g->capV, g->capT);
+		rc = ensure_staging(s, g, cnt->nV, cnt->nT) ? MC33HIP_ENOMEM : mc33hip_emit(s->ctx, g->dV, g->dN, g->dT, g->capV, g->capT);
 		/* mc33hip_emit only enqueues: the set must be complete before anybody reads it - the helper thread of
 		 * calculate_isosurfaces copies on a stream of its own, which is not ordered after this one */
 		if (rc == MC33HIP_OK)
-			rc = mc33hip_synchronize(p->ctx);
+			rc = mc33hip_synchronize(s->ctx);
 	}
 	return rc;
 }
 
 /* One array of a caller-owned surface: plain free() releases it (MC:84-92).  Large ones start on a 2 MiB boundary and
  * ask for transparent huge pages: a 1024^3 surface is 200 MB, and touching it for the first time in 4 KiB pages (the
- * copy from the GPU, the colour fill, the munmap in free) cost more than the extraction itself.
+ * copy from the GPU, the colour fill, the munmap in free) cost more than the extraction itself - measured on the GPU box
+ * (tools/d2h_probe.hip, profiles/r05_d2h_probe.txt): a 94 MB array arrives in 1.76 ms (56 GB/s, the rate of the link - pinning
+ * the block with hipHostRegister first gains nothing) when its pages are mapped, in 4 - 5 ms when they are fresh, and giving
+ * them back to the kernel costs another 4 - 6 ms; the 15 MB colour fill 0.16 against 3.0 ms.
  *
- * free_surface_memory may keep large blocks for the next surface instead of releasing them (pages that are already
- * mapped and already known to the GPU driver make calculate_isosurface + free_surface_memory at 1024^3 about three
- * times faster than fresh memory).  What it keeps is bounded by MC33_HOST_CACHE_MB: default 64 (one array of a
- * 512^3-class surface; a drop-in library should not sit on a gigabyte after `free`), 0 = keep nothing; callers that
- * extract large surfaces in a loop set it to a few times the surface size.
+ * So free_surface_memory keeps large blocks for the next surface instead of releasing them.  How much it keeps: as much as the
+ * surface it is releasing holds (an unmodified viewer loop - calculate_isosurface, draw, free_surface_memory, next isovalue:
+ * reference GLUT_example/TestMC33_glut.c:421-458 - then always finds the blocks of the surface before), and at least 64 MB.
+ * Blocks of earlier, larger surfaces that do not fit under that bound any more are freed, and when the last MC33 object is
+ * destroyed everything beyond 64 MB goes back.  MC33_HOST_CACHE_MB in the environment replaces the rule by a fixed bound
+ * (0 = keep nothing).
  *
  * Only blocks this library allocated are ever looked at: every large block handed out is entered in a small table
  * (address, size); free_surface_memory looks the pointer up there, and an address it does not know is simply passed to
@@ -264,16 +432,41 @@ static int extract_to_staging(mc33_private *p, struct staging *g, MC33_real iso,
 #define CACHE_MIN_BLOCK (2 * HUGE_PAGE)
 #define CACHE_SLOTS 16
 #define LIVE_SLOTS 256
+#define CACHE_DEFAULT ((size_t)64 << 20)
 static struct {
 	void *p;
 	size_t cap;
+	unsigned long long age; /* (cache only) when it was put back: the oldest goes first */
 } g_cache[CACHE_SLOTS], g_live[LIVE_SLOTS]; /* kept for reuse / handed out and still with the caller */
 static size_t g_cache_bytes;
+static unsigned long long g_cache_clock;
 static pthread_mutex_t g_cache_lock = PTHREAD_MUTEX_INITIALIZER;
 
-static size_t cache_limit(void) {
+/* the plain bound: MC33_HOST_CACHE_MB, 64 MB when it is not set (*is_set says which) */
+static size_t cache_limit(int *is_set) {
 	const char *e = getenv("MC33_HOST_CACHE_MB");
-	return (size_t)(e ? strtoull(e, 0, 10) : 64ull) << 20;
+	if (is_set) *is_set = e && *e;
+	return e && *e ? (size_t)strtoull(e, 0, 10) << 20 : CACHE_DEFAULT;
+}
+
+/* (lock held) frees kept blocks, oldest first, until at most `keep` bytes are left */
+static void cache_trim_locked(size_t keep) {
+	while (g_cache_bytes > keep) {
+		int old = -1;
+		for (int k = 0; k != CACHE_SLOTS; k++)
+			if (g_cache[k].p && (old < 0 || g_cache[k].age < g_cache[old].age))
+				old = k;
+		if (old < 0)
+			break;
+		free(g_cache[old].p);
+		g_cache_bytes -= g_cache[old].cap;
+		g_cache[old].p = 0;
+	}
+}
+static void cache_trim(size_t keep) {
+	pthread_mutex_lock(&g_cache_lock);
+	cache_trim_locked(keep);
+	pthread_mutex_unlock(&g_cache_lock);
 }
 
 /* (lock held) remember a large block that goes to the caller; when the table is full the block is simply not known
@@ -321,58 +514,70 @@ static void *surface_block(size_t bytes, size_t *cap) {
 	return p;
 }
 
-/* the counterpart used by free_surface_memory: keep a large block of ours for the next surface, or free it */
-static void surface_block_release(void *p) {
+/* (lock held) is p a large block of ours that the allocator still holds?  Its capacity, and the table entry is given up */
+static size_t live_take(void *p) {
 	if (!p)
-		return;
-	size_t cap = 0;
-	pthread_mutex_lock(&g_cache_lock);
+		return 0;
 	for (int k = 0; k != LIVE_SLOTS; k++)
 		if (g_live[k].p == p) {
-			cap = g_live[k].cap;
+			const size_t cap = g_live[k].cap;
 			g_live[k].p = 0;
-			break;
+			return malloc_usable_size(p) >= cap ? cap : 0;
 		}
-	if (cap && malloc_usable_size(p) >= cap && g_cache_bytes + cap <= cache_limit())
-		for (int k = 0; k != CACHE_SLOTS; k++)
-			if (!g_cache[k].p) {
-				g_cache[k].p = p;
-				g_cache[k].cap = cap;
-				g_cache_bytes += cap;
-				p = 0;
-				break;
-			}
-	pthread_mutex_unlock(&g_cache_lock);
-	free(p);
+	return 0;
 }
 
-/* host part: a caller-owned `surface` (five malloc blocks, MC:84-92) filled from staging set g.
- * concurrent: copy on the side stream, beside whatever the context is computing */
-static surface *surface_from_staging(mc33_private *p, const struct staging *g, const mc33hip_counts *cnt, MC33_real iso, int concurrent) {
+/* The counterpart used by free_surface_memory and adjustvectorlenght_s: the n arrays of ONE surface go back together.  Those
+ * that are large blocks of ours are kept for the next surface as far as the bound allows - the bound being what these very
+ * blocks hold, or 64 MB if that is more (MC33_HOST_CACHE_MB, when set, instead) - the others are freed. */
+static void surface_blocks_release(void **blk, int n) {
+	size_t cap[8], mine = 0;
+	int is_set = 0;
+	size_t limit = cache_limit(&is_set);
+	pthread_mutex_lock(&g_cache_lock);
+	for (int k = 0; k != n; k++) {
+		cap[k] = live_take(blk[k]);
+		mine += cap[k];
+	}
+	if (!is_set && mine > limit)
+		limit = mine;
+	cache_trim_locked(limit > mine ? limit - mine : 0); /* older blocks make room for these */
+	for (int k = 0; k != n; k++) {
+		if (!cap[k] || g_cache_bytes + cap[k] > limit)
+			continue;
+		for (int q = 0; q != CACHE_SLOTS; q++)
+			if (!g_cache[q].p) {
+				g_cache[q].p = blk[k];
+				g_cache[q].cap = cap[k];
+				g_cache[q].age = ++g_cache_clock;
+				g_cache_bytes += cap[k];
+				blk[k] = 0;
+				break;
+			}
+	}
+	pthread_mutex_unlock(&g_cache_lock);
+	for (int k = 0; k != n; k++)
+		free(blk[k]);
+}
+static void surface_block_release(void *p) { surface_blocks_release(&p, 1); }
+
+/* the four arrays of a surface with nV vertices and nT triangles (caller-owned malloc blocks, MC:84-92); 0 when memory is short */
+static surface *surface_alloc(size_t nV, size_t nT, MC33_real iso) {
 	surface *S = (surface *)malloc(sizeof(surface));
 	if (!S)
 		return 0;
-	if (!cnt->nV) { /* MC:1880-1883 */
-		memset(S, 0, sizeof(surface));
+	memset(S, 0, sizeof(surface)); /* (an empty surface is exactly this, MC:1880-1883) */
+	if (!nV)
 		return S;
-	}
-	const size_t nV = (size_t)cnt->nV, nT = (size_t)cnt->nT;
 	size_t capV = 0, capN = 0, capT = 0, capC = 0;
 	S->V = (MC33_real(*)[3])surface_block(nV * 3 * sizeof(MC33_real), &capV);
 	S->N = (float(*)[3])surface_block(nV * 3 * sizeof(float), &capN);
 	S->T = (unsigned int(*)[3])surface_block((nT ? nT : 1) * 3 * sizeof(int), &capT);
 	S->color = (int *)surface_block(nV * sizeof(int), &capC);
-	void *const dst[3] = {S->V, S->N, S->T};
-	const void *const src[3] = {g->dV, g->dN, g->dT};
-	const size_t bytes[3] = {nV * 3 * sizeof(MC33_real), nV * 12, nT * 12};
-	if (!S->V || !S->N || !S->T || !S->color || mc33hip_download_many(p->ctx, 3, dst, src, bytes, concurrent) != MC33HIP_OK) {
-		surface_block_release(S->V); surface_block_release(S->N); surface_block_release(S->T); surface_block_release(S->color);
-		free(S);
+	if (!S->V || !S->N || !S->T || !S->color) {
+		free_surface_memory(S);
 		return 0;
 	}
-	const int col = DefaultColorMC;
-	for (size_t k = 0; k != nV; k++)
-		S->color[k] = col;
 	S->nV = (unsigned int)nV; S->nT = (unsigned int)nT;
 	/* capacities in elements, as the reference keeps them (MC:94-127 shrinks arrays whose cap exceeds the count) */
 	size_t cv = capV / (3 * sizeof(MC33_real)), ct = capT / (3 * sizeof(int));
@@ -384,6 +589,61 @@ static surface *surface_from_staging(mc33_private *p, const struct staging *g, c
 	return S;
 }
 
+static void fill_color(surface *S) { /* MC:1875-1877 */
+	const int col = DefaultColorMC;
+	int *c = S->color;
+	for (size_t k = 0, n = S->nV; k != n; k++)
+		c[k] = col;
+}
+static void *fill_color_thread(void *arg) {
+	fill_color((surface *)arg);
+	return 0;
+}
+
+/* host part of calculate_isosurfaces: a caller-owned `surface` filled from staging set g.
+ * concurrent: copy on the side stream, beside whatever the context is computing */
+static surface *surface_from_staging(mc33_private *p, const struct staging *g, const mc33hip_counts *cnt, MC33_real iso, int concurrent) {
+	surface *S = surface_alloc((size_t)cnt->nV, (size_t)cnt->nT, iso);
+	if (!S || !S->nV)
+		return S;
+	void *const dst[3] = {S->V, S->N, S->T};
+	const void *const src[3] = {g->dV, g->dN, g->dT};
+	const size_t bytes[3] = {(size_t)S->nV * 3 * sizeof(MC33_real), (size_t)S->nV * 12, (size_t)S->nT * 12};
+	if (mc33hip_download_many(p->slab[0].ctx, 3, dst, src, bytes, concurrent) != MC33HIP_OK) {
+		free_surface_memory(S);
+		return 0;
+	}
+	fill_color(S);
+	return S;
+}
+
+/* emit of one slab at its global base, its arrays copied straight to their place in the caller's blocks */
+static void *slab_emit(void *arg) {
+	mc33_slab *s = (mc33_slab *)arg;
+	struct staging *g = &s->set[0];
+	surface *S = s->out;
+	s->rc = MC33HIP_OK;
+	if (!s->cnt.nV && !s->cnt.nT)
+		return 0;
+	if (ensure_staging(s, g, s->cnt.nV, s->cnt.nT)) { s->rc = MC33HIP_ENOMEM; return 0; }
+	if ((s->rc = mc33hip_set_id_base(s->ctx, (unsigned int)s->vbase)) != MC33HIP_OK) return 0;
+	s->rc = mc33hip_emit_download(s->ctx, g->dV, g->dN, g->dT, g->capV, g->capT, S->V + s->vbase, S->N + s->vbase, S->T + s->tbase);
+	const int w = mc33hip_download_wait(s->ctx); /* (also after a failure: nothing may still be writing into the blocks when they are released) */
+	if (s->rc == MC33HIP_OK) s->rc = w;
+	return 0;
+}
+
+/* MC:1816-1889.  Count on every slab (one, unless MC33_HIP_DEVICES names several devices) -> the sizes of the surface and where
+ * each slab's part begins -> the caller's arrays (recycled blocks, see above) -> every slab emits its vertices and triangles at
+ * its global base and copies them straight to their place in those arrays, each array as soon as the passes that write it are
+ * through, over its own device's link: no device-to-device exchange, nothing to concatenate -> the colours are filled in by a
+ * helper thread while the copies run. */
+static double now_ms(void) {
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
 surface *calculate_isosurface(MC33 *M, MC33_real iso) {
 	mc33_private *p = priv(M);
 	if (!p)
@@ -391,8 +651,43 @@ surface *calculate_isosurface(MC33 *M, MC33_real iso) {
 	M->nT = M->nV = 0;
 	M->memoryfault = 0;
 	M->iso = iso;
-	mc33hip_counts cnt;
-	surface *S = extract_to_staging(p, &p->set[0], iso, &cnt) == MC33HIP_OK ? surface_from_staging(p, &p->set[0], &cnt, iso, 0) : 0;
+	mc33hip_counts tot;
+	static int trace = -1; /* MC33_CAPI_TRACE=1: where the wall time of a call goes (stderr) */
+	if (trace < 0) trace = getenv("MC33_CAPI_TRACE") != 0;
+	double t[6] = {0, 0, 0, 0, 0, 0};
+	if (trace) t[0] = now_ms();
+	const int crc = count_slabs(p, iso, &tot);
+	if (trace) t[1] = now_ms();
+	surface *S = crc == MC33HIP_OK ? surface_alloc((size_t)tot.nV, (size_t)tot.nT, iso) : 0;
+	if (trace) t[2] = now_ms();
+	if (S && S->nV) {
+		int ok = 1;
+		unsigned long long vb = 0, tb = 0;
+		for (int k = 0; k != p->nslab; k++) {
+			mc33_slab *s = &p->slab[k];
+			s->out = S; s->vbase = vb; s->tbase = tb;
+			vb += s->cnt.nV; tb += s->cnt.nT;
+		}
+		pthread_t ct;
+		const int helper = S->nV >= 65536u && pthread_create(&ct, 0, fill_color_thread, S) == 0; /* 16 MB at 1024^3: 0.8 ms beside 3.4 ms of copies */
+		if (trace) t[3] = now_ms();
+		for_each_slab(p, slab_emit);
+		if (trace) t[4] = now_ms();
+		if (helper) pthread_join(ct, 0);
+		else fill_color(S);
+		for (int k = 0; k != p->nslab; k++)
+			if (p->slab[k].rc != MC33HIP_OK)
+				ok = 0;
+		if (trace) {
+			t[5] = now_ms();
+			fprintf(stderr, "[mc33 capi] count %.3f  blocks %.3f  helper %.3f  emit + copies %.3f  colours joined %.3f  total %.3f ms\n", t[1] - t[0], t[2] - t[1],
+			        t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+		}
+		if (!ok) {
+			free_surface_memory(S);
+			S = 0;
+		}
+	}
 	if (!S) {
 		M->memoryfault = 1;
 		return 0;
@@ -429,6 +724,13 @@ unsigned int calculate_isosurfaces(MC33 *M, const MC33_real *iso, unsigned int n
 	if (!p || !iso)
 		return 0;
 	M->memoryfault = 0;
+	if (p->nslab > 1) { /* several devices: every surface by itself (each call already runs its slabs side by side) */
+		for (unsigned int k = 0; k != n; k++)
+			if ((out[k] = calculate_isosurface(M, iso[k])) != 0)
+				done++;
+		M->memoryfault = done != n;
+		return done;
+	}
 	if (refresh_grid(p) != MC33HIP_OK)
 		return 0;
 	struct download_job job;
@@ -443,10 +745,10 @@ unsigned int calculate_isosurfaces(MC33 *M, const MC33_real *iso, unsigned int n
 			r.z_begin = 0; r.z_end = M->nz; r.ghost_below = 0; r.id_base = 0;
 			for (unsigned int q = 0; q != m; q++) many[q] = iso[k + q];
 			if (!p->reupload) /* (the re-upload of every call would drop the sweeps made ahead) */
-				(void)mc33hip_sweep_many(p->ctx, many, (int)m, &r); /* (on failure the single calls sweep for themselves) */
+				(void)mc33hip_sweep_many(p->slab[0].ctx, many, (int)m, &r); /* (on failure the single calls sweep for themselves) */
 		}
 		/* surface k is computed into set k&1 while the helper thread copies surface k-1 out of the other set */
-		struct staging *g = &p->set[k & 1];
+		struct staging *g = &p->slab[0].set[k & 1];
 		mc33hip_counts cnt;
 		M->iso = iso[k];
 		const int rc = extract_to_staging(p, g, iso[k], &cnt);
@@ -477,7 +779,8 @@ unsigned int calculate_isosurfaces(MC33 *M, const MC33_real *iso, unsigned int n
 
 void free_surface_memory(surface *S) { /* MC:84-92 */
 	if (S) {
-		surface_block_release(S->T); surface_block_release(S->V); surface_block_release(S->N); surface_block_release(S->color);
+		void *blk[4] = {S->T, S->V, S->N, S->color};
+		surface_blocks_release(blk, 4);
 		free(S);
 	}
 }

@@ -2471,7 +2471,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 #ifdef MC33_DEV
 template <int BELOW = 0>  // developer experiment: 1 = keep the owner positions found through the directory, 2 = take them from that array instead
 #else
-constexpr int BELOW = 0;
+[[maybe_unused]] constexpr int BELOW = 0;
 #endif
 __global__ __launch_bounds__(256) void k_emit_fast_triangles(const EmitArgs a) {
 	__shared__ uint32_t s_id[13][256];
@@ -2752,10 +2752,22 @@ struct TailSet {
 	bool ctr_published;       // the emit pass enqueued last leaves the counters in h_ctr itself (k_emit_fast_triangles)
 };
 
+// The environment switches (developer A/B, the tests that force a code path), read ONCE when a context is created: a getenv walks
+// the whole environment, and there were some twenty of them on every call.  0 / -1 / nullptr = not set: the library decides.
+struct Switches {
+	uint32_t rz, sweep_blocks_per_cu, min_depth, cells_blocks, slow_blocks, emit_blocks, emit_v_blocks_per_cu;
+	bool no_pack, no_stage, verbose;
+	int slow_count, tails_ahead, no_fork, slow_slots, tri_first;  // -1: not set
+	char *trace_cells, *trace_file;                               // (developer tracing: file names; copies)
+	uint32_t debug, cells_dev, sweep_subtract, tri_below, old_vertex_pass;  // (looked at by -DMC33_DEV builds only)
+};
+
 struct mc33hip_ctx {
 	mc33hip_grid_desc desc;
+	Switches sw;
 	int device;
 	hipStream_t stream;
+	bool own_stream;          // the stream came from the pool (mc33hip_own_stream) and goes back there
 	sample_t *d_grid;
 	bool owns_grid;
 	size_t pitch, slice;  // in samples
@@ -2785,6 +2797,7 @@ struct mc33hip_ctx {
 	hipStream_t aux, aux2;    // the triangle pass and the slow-record pass run beside the vertex pass
 	hipStream_t copy;         // mc33hip_download_concurrent
 	hipEvent_t ev_fork, ev_join, ev_join2;
+	hipEvent_t ev_dl[2];      // mc33hip_emit_download: behind the pass that completes T / behind the one that completes V and N
 	bool emit_pending;        // an emit was enqueued after the last timing read
 	int timing_level;         // MC33_HIP_TIMING: 0 none (default), 1 whole call, 2 per pass - the event records cost ~20 us per call
 	bool inclined, triangular;   // non-orthogonal grid (MC33_spnC): _GRD._A / _GRD.A_ as given
@@ -2805,6 +2818,23 @@ struct mc33hip_ctx {
 
 extern "C" const char *mc33hip_last_error(void) { return g_err; }
 static uint32_t env_u32(const char *name, uint32_t dflt);
+
+static int env_flag(const char *name) {  // -1: not set
+	const char *s = getenv(name);
+	return s && *s ? (atoi(s) != 0 ? 1 : 0) : -1;
+}
+static void read_switches(Switches &w) {
+	w.rz = env_u32("MC33_HIP_RZ", 0); w.sweep_blocks_per_cu = env_u32("MC33_HIP_SWEEP_BLOCKS_PER_CU", 0); w.min_depth = env_u32("MC33_HIP_MIN_DEPTH", 0);
+	w.cells_blocks = env_u32("MC33_HIP_CELLS_BLOCKS", 0); w.slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 0); w.emit_blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 0);
+	w.emit_v_blocks_per_cu = env_u32("MC33_HIP_EMIT_V_BLOCKS_PER_CU", 0);
+	w.no_pack = env_u32("MC33_HIP_NO_PACK", 0) != 0; w.no_stage = env_u32("MC33_HIP_NO_STAGE", 0) != 0; w.verbose = getenv("MC33_HIP_VERBOSE") != nullptr;
+	w.slow_count = env_flag("MC33_HIP_SLOW_COUNT"); w.tails_ahead = env_flag("MC33_HIP_TAILS_AHEAD"); w.no_fork = env_flag("MC33_HIP_NO_FORK");
+	w.slow_slots = env_flag("MC33_HIP_SLOW_SLOTS"); w.tri_first = env_flag("MC33_HIP_TRI_FIRST");
+	w.trace_cells = getenv("MC33_HIP_TRACE_CELLS") ? strdup(getenv("MC33_HIP_TRACE_CELLS")) : nullptr;
+	w.trace_file = getenv("MC33_HIP_TRACE_FILE") ? strdup(getenv("MC33_HIP_TRACE_FILE")) : nullptr;
+	w.debug = env_u32("MC33_HIP_DEBUG", 0); w.cells_dev = env_u32("MC33_HIP_CELLS_DEV", 0); w.sweep_subtract = env_u32("MC33_HIP_SWEEP_SUBTRACT", 0);
+	w.tri_below = env_u32("MC33_HIP_TRI_BELOW", 0); w.old_vertex_pass = env_u32("MC33_HIP_OLD_VERTEX_PASS", 0);
+}
 
 static int use_device(mc33hip_ctx *c) {
 	HIP_TRY(hipSetDevice(c->device));
@@ -2873,6 +2903,7 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	mc33hip_ctx *c = (mc33hip_ctx *)calloc(1, sizeof *c);
 	if (!c) return MC33HIP_ENOMEM;
 	c->desc = *d;
+	read_switches(c->sw);
 	if (d->device >= 0) c->device = d->device;
 	else if (hipGetDevice(&c->device) != hipSuccess) { free(c); set_err("hipGetDevice failed"); return MC33HIP_ENOGPU; }
 	*out = c;
@@ -2923,6 +2954,7 @@ extern "C" int mc33hip_create(mc33hip_ctx **out, const mc33hip_grid_desc *d) {
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
+	for (int k = 0; k < 2; k++) CREATE_TRY(hipEventCreateWithFlags(&c->ev_dl[k], hipEventDisableTiming));
 #undef CREATE_TRY
 	return MC33HIP_OK;
 }
@@ -2952,7 +2984,10 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+	for (int k = 0; k < 2; k++) if (c->ev_dl[k]) (void)hipEventDestroy(c->ev_dl[k]);
 	pool_give(c->device, c->aux); pool_give(c->device, c->aux2); pool_give(c->device, c->copy);  // after the events
+	if (c->own_stream) pool_give(c->device, c->stream);
+	free(c->sw.trace_cells); free(c->sw.trace_file);
 	free(c);
 }
 
@@ -2962,8 +2997,27 @@ static void forget_sweeps(mc33hip_ctx *c) {  // the grid changed: sweeps made ah
 
 extern "C" int mc33hip_set_stream(mc33hip_ctx *c, void *s) {
 	if (!c) return MC33HIP_EINVAL;
+	if (c->own_stream) { pool_give(c->device, c->stream); c->own_stream = false; }
 	c->stream = (hipStream_t)s;
 	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_own_stream(mc33hip_ctx *c) {
+	if (!c) return MC33HIP_EINVAL;
+	if (c->own_stream) return MC33HIP_OK;
+	int rc = use_device(c);
+	if (rc) return rc;
+	hipStream_t st = nullptr;
+	HIP_TRY(pool_take(c->device, &st));
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	c->stream = st;
+	c->own_stream = true;
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_device_count(void) {
+	int n = 0;
+	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
 static int ensure_grid(mc33hip_ctx *c) {
@@ -3113,12 +3167,21 @@ static int alloc_entries(TailSet &w, uint64_t cap) {
 	w.entries_a = nullptr; w.entries_b = nullptr; w.entries_c = nullptr; w.entry_seg = nullptr; w.slow_list = nullptr; w.dirty_list = nullptr;
 	w.entry_cap = 0;
 	if (cap > 0xFFFFFF00ull) cap = 0xFFFFFF00ull;
-	HIP_TRY(hipMalloc(&w.entries_a, (cap + 2) * sizeof(EntryA)));  // (+ 2: the triangle pass reads records in pairs)
-	HIP_TRY(hipMalloc(&w.entries_b, cap * sizeof(EntryB)));  // (touched for tested and slow records only)
-	HIP_TRY(hipMalloc(&w.entries_c, cap * sizeof(EntryC)));  // (... for slow records only)
-	HIP_TRY(hipMalloc(&w.entry_seg, cap * 4));
-	HIP_TRY(hipMalloc(&w.slow_list, cap * 4));
-	HIP_TRY(hipMalloc(&w.dirty_list, cap * 4));
+	const hipError_t e = [&]() -> hipError_t {
+		hipError_t r;
+		if ((r = hipMalloc(&w.entries_a, (cap + 2) * sizeof(EntryA))) != hipSuccess) return r;  // (+ 2: the triangle pass reads records in pairs)
+		if ((r = hipMalloc(&w.entries_b, cap * sizeof(EntryB))) != hipSuccess) return r;        // (touched for tested and slow records only)
+		if ((r = hipMalloc(&w.entries_c, cap * sizeof(EntryC))) != hipSuccess) return r;        // (... for slow records only)
+		if ((r = hipMalloc(&w.entry_seg, cap * 4)) != hipSuccess) return r;
+		if ((r = hipMalloc(&w.slow_list, cap * 4)) != hipSuccess) return r;
+		return hipMalloc(&w.dirty_list, cap * 4);
+	}();
+	if (e != hipSuccess) {  // all or nothing: a set with some of its arrays would pass for a complete one (ensure_set looks at entries_a)
+		(void)hipFree(w.entries_a); (void)hipFree(w.entries_b); (void)hipFree(w.entries_c); (void)hipFree(w.entry_seg); (void)hipFree(w.slow_list); (void)hipFree(w.dirty_list);
+		w.entries_a = nullptr; w.entries_b = nullptr; w.entries_c = nullptr; w.entry_seg = nullptr; w.slow_list = nullptr; w.dirty_list = nullptr;
+		set_err("work-record buffers (%llu records) failed: %s", (unsigned long long)cap, hipGetErrorString(e));
+		return e == hipErrorOutOfMemory ? MC33HIP_ENOMEM : MC33HIP_ERUNTIME;
+	}
 	w.entry_cap = cap;
 	return 0;
 }
@@ -3150,7 +3213,7 @@ static int ensure_set(mc33hip_ctx *c, TailSet &w, uint64_t hint = 0) {
 		w.bsT = w.bsV + nb;
 		w.bs_cap = nb;
 	}
-	if (!w.entries_a) {
+	if (!w.entries_a || !w.entry_cap) {
 		// first guess: one cell in 32 is cut (BASELINE fields: 0.4-6 % of the cells); grown on demand
 		const uint64_t cells = (uint64_t)c->P.nx * c->P.ny * (c->range.z_end - c->P.zs);
 		return alloc_entries(w, hint ? hint + hint / 4 + 65536 : cells / 32 + 65536);
@@ -3172,13 +3235,13 @@ static int grow_entries(TailSet &w, uint64_t need) {
 // the 64 CUs that got a fifth block finished 12 % after the others.
 static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 	const Params &P = c->P;
-	const uint32_t depth = std::max(1u, env_u32("MC33_HIP_RZ", 16));
+	const uint32_t depth = c->sw.rz ? c->sw.rz : 16u;
 	if (c->d_tiles && c->tiles_zs == zs && c->tiles_ze == ze && c->tiles_depth == depth) return 0;
 	if (!c->resident_blocks) {
 		int per_cu = 0, cus = 0;
 		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<1, 1>, 256, 0));
 		HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-		const uint32_t want = env_u32("MC33_HIP_SWEEP_BLOCKS_PER_CU", 4);
+		const uint32_t want = c->sw.sweep_blocks_per_cu ? c->sw.sweep_blocks_per_cu : 4u;
 		c->resident_blocks = (uint32_t)std::max(1, cus) * (uint32_t)std::max(1, std::min(per_cu, (int)want));
 	}
 	// A tile is what ONE wave streams: a row segment (256 samples in x) x a y tile (64 sample rows) x a run of planes.
@@ -3201,7 +3264,7 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 	const double pref = W * nzc / (64.0 * depth);
 	uint64_t B = (uint64_t)c->resident_blocks * 4;
 	if (pref >= (double)B) B *= (uint64_t)(pref / (double)B + 0.5);
-	else B = std::max<uint64_t>(1, std::min<uint64_t>(B, (uint64_t)(W * nzc / (64.0 * std::max(1u, env_u32("MC33_HIP_MIN_DEPTH", 1))))));  // small grid: fill the GPU, tiles down to one plane deep (k_boundary then does the slices)
+	else B = std::max<uint64_t>(1, std::min<uint64_t>(B, (uint64_t)(W * nzc / (64.0 * std::max(1u, c->sw.min_depth)))));  // small grid: fill the GPU, tiles down to one plane deep (k_boundary then does the slices)
 	std::vector<uint32_t> chunks(ncol);  // z pieces of the group (each is one tile per wave of the group)
 	std::vector<std::pair<double, uint64_t>> frac(ncol);
 	uint64_t total = 0;
@@ -3259,7 +3322,7 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 		HIP_TRY(hipMemcpy(c->d_bounds, bounds.data(), bounds.size() * sizeof(TileBoundary), hipMemcpyHostToDevice));
 	}
 	c->tiles_zs = zs; c->tiles_ze = ze; c->tiles_depth = depth;
-	if (getenv("MC33_HIP_VERBOSE"))
+	if (c->sw.verbose)
 		fprintf(stderr, "[mc33hip] sweep plan: %llu wave tiles (%u resident), %llu columns, depth %.1f\n", (unsigned long long)c->ntiles,
 		        c->resident_blocks * 4, (unsigned long long)nYT * P.nseg, (double)nzc * nYT * P.nseg / (double)c->ntiles);
 	return 0;
@@ -3357,7 +3420,7 @@ static void set_lane(SweepArgs &a, int q, const IsoLane &L, double iso) {
 // narrow samples are loaded as dwords when every row of the grid starts on a dword boundary (always true for the
 // library's own pitched copy; a caller's device buffer may have any pitch)
 static bool sweep_packed(const mc33hip_ctx *c) {
-	return SWEEP_PACK > 1 && !env_u32("MC33_HIP_NO_PACK", 0) && ((uintptr_t)c->d_grid % 4u) == 0 && (c->pitch * sizeof(sample_t)) % 4u == 0 &&
+	return SWEEP_PACK > 1 && !c->sw.no_pack && ((uintptr_t)c->d_grid % 4u) == 0 && (c->pitch * sizeof(sample_t)) % 4u == 0 &&
 	       (c->slice * sizeof(sample_t)) % 4u == 0;
 }
 
@@ -3389,7 +3452,7 @@ static uint32_t launch_sweep_ni(mc33hip_ctx *c, const SweepArgs &a, hipStream_t 
 	}
 	bool subtract = negzero;
 #ifdef MC33_DEV
-	subtract |= env_u32("MC33_HIP_SWEEP_SUBTRACT", 0) != 0;  // (A/B of the two forms; same results)
+	subtract |= c->sw.sweep_subtract != 0;  // (A/B of the two forms; same results)
 #endif
 	if (!subtract) {
 		if (can_equal) return launch_sweep_zm<NI, 1>(c, a, st);
@@ -3416,7 +3479,7 @@ static int enqueue_tail(mc33hip_ctx *c, const int *idx, const int *sidx, const d
 	SweepArgs a;
 	sweep_args(c, g, a);
 #ifdef MC33_DEV
-	a.debug = env_u32("MC33_HIP_DEBUG", 0);
+	a.debug = c->sw.debug;
 #endif
 	PerLane<SlotsArgs> SA;
 	PerLane<CellsArgs> CA;
@@ -3458,7 +3521,7 @@ static int enqueue_tail(mc33hip_ctx *c, const int *idx, const int *sidx, const d
 		ca.pack = L.pack ? L.pack : 1u;
 		ca.dev = 0;
 #ifdef MC33_DEV
-		ca.dev = env_u32("MC33_HIP_CELLS_DEV", 0);
+		ca.dev = c->sw.cells_dev;
 #endif
 		ca.G.p = c->d_grid; ca.G.pitch = (uint32_t)c->pitch; ca.G.z0 = c->desc.plane0; ca.G.slice = c->slice;
 		ca.P = P; ca.fast = c->d_fast; ca.pat = c->d_pat;
@@ -3477,7 +3540,7 @@ static int enqueue_tail(mc33hip_ctx *c, const int *idx, const int *sidx, const d
 		ca.batches = w.batches; ca.batch_cap = (uint32_t)std::min<uint64_t>(w.batch_cap, 0xFFFFFFFFull);
 		ca.ctr = w.d_ctr;
 		ca.trace = nullptr;
-		if (n == 1 && getenv("MC33_HIP_TRACE_CELLS")) {
+		if (n == 1 && c->sw.trace_cells) {
 			(void)hipFree(c->trace_cells);
 			c->trace_cells = nullptr;
 			c->trace_cells_n = g.nslots;
@@ -3518,17 +3581,16 @@ static int enqueue_tail(mc33hip_ctx *c, const int *idx, const int *sidx, const d
 	for (int q = 0; q < n; q++) c->lanes[idx[q]].tail_pending = false;  // k_slots has read this epoch's partial sums and cleared the half of the next one
 	// (four times what the GPU holds at once: slices differ in length, and a block that starts late evens the waves out -
 	// 76 -> 66 us at 1024^3; a block per group of four slots, as until round 3, is 17 408 blocks there)
-	hipLaunchKernelGGL(k_cells, dim3((uint32_t)std::min<uint64_t>(g.cell_blocks, env_u32("MC33_HIP_CELLS_BLOCKS", 4u * c->cells_blocks)), ny), dim3(256), 0, st, CA);
+	hipLaunchKernelGGL(k_cells, dim3((uint32_t)std::min<uint64_t>(g.cell_blocks, c->sw.cells_blocks ? c->sw.cells_blocks : 4u * c->cells_blocks), ny), dim3(256), 0, st, CA);
 	// (blocks beyond the lists end at once.  A grid sized from the last extraction's counts - 69 blocks instead of 1024 at 1024^3,
 	// whose 8 820 slow cells are 35 blocks' worth - changes nothing: 13.5 / 6 / 8.7 us either way.  What these kernels take is
 	// the chain of dependent loads of the cells that ARE slow, not their empty blocks; round 3)
-	const uint32_t slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 1024);
+	const uint32_t slow_blocks = c->sw.slow_blocks ? c->sw.slow_blocks : 1024u;
 	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
 	{  // k_slow_count only when the last extraction of (one of) the set(s) had records for it, or nothing is known: k_seg_fix counts what is left over
 		bool wanted = false;
 		for (int q = 0; q < n; q++) wanted |= !c->ts[sidx[q]].count_known || c->ts[sidx[q]].count_needed;
-		const char *fc = getenv("MC33_HIP_SLOW_COUNT");
-		if (fc && *fc) wanted = atoi(fc) != 0;
+		if (c->sw.slow_count >= 0) wanted = c->sw.slow_count != 0;
 		if (wanted) hipLaunchKernelGGL(k_slow_count, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
 	}
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
@@ -3580,14 +3642,14 @@ static int enqueue_count(mc33hip_ctx *c, bool rerun = false) {
 		sweep_args(c, g, a);
 		set_lane(a, 0, *L, P.iso);
 #ifdef MC33_DEV
-		a.debug = env_u32("MC33_HIP_DEBUG", 0);
+		a.debug = c->sw.debug;
 		if (a.debug) {  // never silent: with this set the call measures the sweep's read stream and finds no surface
 			static bool warned = false;
 			if (!warned) fprintf(stderr, "[mc33hip] MC33_HIP_DEBUG=%u: timing experiment, every extraction returns an EMPTY surface\n", a.debug);
 			warned = true;
 		}
 #endif
-		if (getenv("MC33_HIP_TRACE_FILE")) {
+		if (c->sw.trace_file) {
 			(void)hipFree(c->trace);
 			c->trace = nullptr;
 			c->trace_waves = ((c->ntiles + 3) / 4) * 4;
@@ -3638,13 +3700,14 @@ static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n, bool ta
 	if (int rc = plan_sweep(c, c->P.zs, c->range.z_end)) return rc;
 	SlotGeom g;
 	if (int rc = slot_geometry(c, g)) return rc;
-	if (const char *ta = getenv("MC33_HIP_TAILS_AHEAD")) tails_ahead = atoi(ta) != 0;  // (developer A/B of the two flows)
+	if (c->sw.tails_ahead >= 0) tails_ahead = c->sw.tails_ahead != 0;  // (developer A/B of the two flows)
 	if (tails_ahead) {
 		// records to make room for in a new set: what the last extraction of this context needed
 		uint64_t hint = 0;
 		for (int k = 0; k < MC33_LANES; k++) hint = std::max<uint64_t>(hint, c->ts[k].records_hint);
 		for (int k = 0; k < n && tails_ahead; k++)
 			if (ensure_set(c, c->ts[k], hint) != 0) {  // (out of device memory: no sets beyond the first, no tails ahead)
+				forget_sweeps(c);  // (first: a lane that still said "tail made" would send a later count to a set that is gone)
 				for (int j = 1; j <= k; j++) free_set(c->ts[j]);
 				(void)hipGetLastError();
 				c->w = &c->ts[0];  // (the last count may have worked in one of the sets that are gone)
@@ -3659,7 +3722,7 @@ static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n, bool ta
 		SweepArgs a;
 		sweep_args(c, g, a);
 #ifdef MC33_DEV
-		a.debug = env_u32("MC33_HIP_DEBUG", 0);
+		a.debug = c->sw.debug;
 #endif
 		for (int q = 0; q < ni; q++) {
 			IsoLane &L = c->lanes[k + q];
@@ -3690,7 +3753,11 @@ static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n, bool ta
 	return 0;
 }
 
-static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t capV, uint64_t capT) {
+// Host destinations of a pipelined download (mc33hip_emit_download): every array is copied on the context's copy stream as soon as
+// the passes that write it have been through, while the remaining passes still run.
+struct DownloadPlan { void *hV, *hN, *hT; size_t bV, bN, bT; };
+
+static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t capV, uint64_t capT, const DownloadPlan *dl = nullptr) {
 	EmitArgs a;
 	a.c.tab.lut = c->d_lut; a.c.tab.rule_words = c->d_rules; a.c.tab.rule_index = c->d_rule_index;
 	a.c.P = c->P;
@@ -3712,11 +3779,11 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	// rows may be staged in 16-byte chunks when every row of the grid starts on a 16-byte boundary (always so for the library's
 	// own copy; a caller's device buffer may have any pitch: its records then load for themselves)
 	a.stage_rows = ((uintptr_t)c->d_grid % 16u) == 0 && (c->pitch * sizeof(sample_t)) % 16u == 0 && (c->slice * sizeof(sample_t)) % 16u == 0 &&
-	               !env_u32("MC33_HIP_NO_STAGE", 0);
+	               !c->sw.no_stage;
 	// The triangle pass is fastest with a thread per record (C5, 14.4 M records: 16 384 / 32 768 / 65 536 blocks 392 / 363 /
 	// 352 us; C3, 3.9 M: 2 048 / 4 096 / 8 192 / 16 384 blocks 106 / 98 / 93 / 88 us).  How many records this extraction has is
 	// on the device only: the grid follows the last extraction whose counters were read, 16 384 blocks at least.
-	const uint32_t blocks = env_u32("MC33_HIP_EMIT_BLOCKS", std::max(256u * 64u, std::min(1u << 20, ((c->w->records_hint + 255u) / 256u + 7u) & ~7u)));
+	const uint32_t blocks = c->sw.emit_blocks ? c->sw.emit_blocks : std::max(256u * 64u, std::min(1u << 20, ((c->w->records_hint + 255u) / 256u + 7u) & ~7u));
 	if (!c->cus) HIP_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, c->device));
 	// The three emit passes are independent (V/N vs T, fast vs slow records).  While each of them waited through a chain of
 	// dependent loads (rounds 1 and most of 2) running them side by side on three streams paid on large grids (0.15 instead
@@ -3725,9 +3792,9 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	// the events between the streams.  MC33_HIP_NO_FORK=0 still runs them side by side.
 	// MC33_HIP_NO_FORK: 0 = all three side by side, 1 = all in sequence, unset = the two fast passes in sequence and the slow one
 	// behind them (few slow records) or, on large grids, beside them on a second stream (many: see below).
-	const char *fork_env = getenv("MC33_HIP_NO_FORK");
+	const bool fork_env = c->sw.no_fork >= 0;
 	const uint64_t range_cells = (uint64_t)c->P.nx * c->P.ny * (c->range.z_end - c->P.zs);
-	const bool fork_all = fork_env && !atoi(fork_env);
+	const bool fork_all = c->sw.no_fork == 0;
 	// Which fast pass goes first (round 4).  The triangle pass lives on dependent look-ups in what the tail has just written - records,
 	// directory lines, segment bases: 144 MB at 1024^3 float - and right behind the tail it finds them in the 256 MB last-level cache;
 	// behind the vertex pass, which pulls 0.45 GB of sample lines through that cache, it does not: 85 -> 68 - 70 us at 1024^3 with
@@ -3744,11 +3811,9 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	// ended 0 - 3 us behind the triangle pass (profiles/r04_vertex_pass_bimodal.txt).  MANY slow records (noise, integer isovalues on
 	// integer grids) - or an unknown number - take a thread each (k_emit_slow), on large grids beside the fast passes on the second
 	// stream as before, the vertex pass first as before.  MC33_HIP_SLOW_SLOTS=0 / 1 forces the kernel, MC33_HIP_NO_FORK the streams.
-	const char *se = getenv("MC33_HIP_SLOW_SLOTS");
-	const bool slow_slots = se && *se ? atoi(se) != 0 : (c->w->slow_hint != 0u && c->w->slow_hint <= 32768u);
+	const bool slow_slots = c->sw.slow_slots >= 0 ? c->sw.slow_slots != 0 : (c->w->slow_hint != 0u && c->w->slow_hint <= 32768u);
 	const bool fork_slow = fork_all || (!fork_env && !slow_slots && range_cells >= 300000000ull);  // (small grids: the events cost more than they gain)
-	const char *tf = getenv("MC33_HIP_TRI_FIRST");
-	const bool tri_first = !fork_all && (tf ? atoi(tf) != 0 : (c->w->records_hint <= 6000000u && !fork_slow));
+	const bool tri_first = !fork_all && (c->sw.tri_first >= 0 ? c->sw.tri_first != 0 : (c->w->records_hint <= 6000000u && !fork_slow));
 	hipStream_t sv = fork_all ? c->aux : c->stream, ss = fork_slow ? c->aux2 : c->stream;
 	if (fork_slow) {
 		HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
@@ -3760,19 +3825,37 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	// exhausted cost it), 1 024 at most and while nothing is known.  A lane per slot, 16 records per block and round: as many blocks as
 	// the records need and an eighth more, 1 024 at least (a block beyond the list leaves at once, and should the count have been an
 	// earlier isovalue's and far too small, the kernel goes through the list with a thread per record: it needs the threads then).
-	const uint32_t slow_grid = env_u32("MC33_HIP_SLOW_BLOCKS", slow_slots ? std::max(1024u, (c->w->slow_hint + c->w->slow_hint / 8u + 15u) / 16u)
-	                                                                    : c->w->slow_hint ? std::min(1024u, std::max(64u, (c->w->slow_hint + 255u) / 256u * 4u)) : 1024u);
+	const uint32_t slow_grid = c->sw.slow_blocks ? c->sw.slow_blocks
+	                           : slow_slots ? std::max(1024u, (c->w->slow_hint + c->w->slow_hint / 8u + 15u) / 16u)
+	                           : c->w->slow_hint ? std::min(1024u, std::max(64u, (c->w->slow_hint + 255u) / 256u * 4u)) : 1024u;
 #define MC33_LAUNCH_SLOW(st) do { if (slow_slots) hipLaunchKernelGGL(k_emit_slow_slots, dim3(slow_grid), dim3(256), 0, st, a); else hipLaunchKernelGGL(k_emit_slow, dim3(slow_grid), dim3(256), 0, st, a); } while (0)
 	if (fork_slow) {  // (first: it is the one with the long chains)
 		MC33_LAUNCH_SLOW(ss);
 		HIP_TRY(hipEventRecord(c->ev_join2, c->aux2));
 	}
+	// A pipelined download wants every array complete as early as possible: the slow records - which write V, N AND T - go first
+	// then (in sequence all the same: 14 us with the GPU to itself), and each fast pass is followed by the copies it completes.
+	const bool dl_split = dl && !fork_all && !fork_slow;
+	if (dl_split) MC33_LAUNCH_SLOW(ss);
+	auto copy_T = [&]() -> int {
+		HIP_TRY(hipEventRecord(c->ev_dl[0], c->stream));
+		HIP_TRY(hipStreamWaitEvent(c->copy, c->ev_dl[0], 0));
+		if (dl->bT) HIP_TRY(hipMemcpyAsync(dl->hT, dT, dl->bT, hipMemcpyDeviceToHost, c->copy));
+		return 0;
+	};
+	auto copy_VN = [&]() -> int {
+		HIP_TRY(hipEventRecord(c->ev_dl[1], c->stream));
+		HIP_TRY(hipStreamWaitEvent(c->copy, c->ev_dl[1], 0));
+		if (dl->bV) HIP_TRY(hipMemcpyAsync(dl->hV, dV, dl->bV, hipMemcpyDeviceToHost, c->copy));
+		if (dl->bN) HIP_TRY(hipMemcpyAsync(dl->hN, dN, dl->bN, hipMemcpyDeviceToHost, c->copy));
+		return 0;
+	};
 #ifdef MC33_DEV
 	// developer experiment (MC33_HIP_TRI_BELOW=1): what would the triangle pass take if every record knew where its owners' records
 	// are?  A first pass keeps the positions it finds through the directory (k_emit_fast_triangles<1>), a second one takes them from
 	// that array with the record and never looks at the directory (<2>: same triangles) - the second is the one to time.
 	static uint32_t *s_below = nullptr; static uint64_t s_below_cap = 0;
-	const bool tri_below = env_u32("MC33_HIP_TRI_BELOW", 0) != 0;
+	const bool tri_below = c->sw.tri_below != 0;
 	a.below_idx = nullptr;
 	if (tri_below) {
 		if (s_below_cap < c->w->entry_cap) { (void)hipFree(s_below); s_below = nullptr; HIP_TRY(hipMalloc(&s_below, c->w->entry_cap * 12ull)); s_below_cap = c->w->entry_cap; }
@@ -3782,16 +3865,19 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 #else
 #define MC33_LAUNCH_TRI(st) hipLaunchKernelGGL(k_emit_fast_triangles, dim3(blocks), dim3(256), 0, st, a)
 #endif
-	if (tri_first) MC33_LAUNCH_TRI(sv);
+	if (tri_first) {
+		MC33_LAUNCH_TRI(sv);
+		if (dl_split) { if (int rc = copy_T()) return rc; }
+	}
 #ifdef MC33_DEV
-	if (env_u32("MC33_HIP_OLD_VERTEX_PASS", 0)) hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);  // (the round-2 pass, for A/B timing)
+	if (c->sw.old_vertex_pass) hipLaunchKernelGGL(k_emit_fast_vertices, dim3(blocks), dim3(256), 0, c->stream, a);  // (the round-2 pass, for A/B timing)
 	else
 #endif
 	{
 		// as many blocks as the device holds at once (one more round of blocks would run with most of the GPU idle); every wave
 		// walks many batches, its next batch's records in flight while it works on one
 		if (!c->emit_v_blocks_per_cu) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->emit_v_blocks_per_cu, k_emit_vertices<3>, 256, 0));
-		const uint32_t vblocks = (uint32_t)std::max(1, c->cus) * env_u32("MC33_HIP_EMIT_V_BLOCKS_PER_CU", (uint32_t)std::max(1, c->emit_v_blocks_per_cu));
+		const uint32_t vblocks = (uint32_t)std::max(1, c->cus) * (c->sw.emit_v_blocks_per_cu ? c->sw.emit_v_blocks_per_cu : (uint32_t)std::max(1, c->emit_v_blocks_per_cu));
 		const dim3 vgrid((vblocks + 7u) & ~7u);
 		switch (c->P.store_mode) {
 		case 0: hipLaunchKernelGGL(k_emit_vertices<0>, vgrid, dim3(256), 0, c->stream, a); break;
@@ -3800,14 +3886,22 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 		default: hipLaunchKernelGGL(k_emit_vertices<3>, vgrid, dim3(256), 0, c->stream, a); break;
 		}
 	}
-	if (!tri_first) MC33_LAUNCH_TRI(sv);
+	if (dl_split) { if (int rc = copy_VN()) return rc; }
+	if (!tri_first) {
+		MC33_LAUNCH_TRI(sv);
+		if (dl_split) { if (int rc = copy_T()) return rc; }
+	}
 #undef MC33_LAUNCH_TRI
 	if (fork_all) HIP_TRY(hipEventRecord(c->ev_join, c->aux));
-	if (!fork_slow) MC33_LAUNCH_SLOW(ss);
+	if (!fork_slow && !dl_split) MC33_LAUNCH_SLOW(ss);
 #undef MC33_LAUNCH_SLOW
 	HIP_TRY(hipGetLastError());
 	if (fork_all) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
 	if (fork_slow) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+	if (dl && !dl_split) {  // (passes on several streams: everything behind the join)
+		if (int rc = copy_T()) return rc;
+		if (int rc = copy_VN()) return rc;
+	}
 	if (c->timing_level > 0) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
 	c->emit_pending = true;
 	return 0;
@@ -3821,24 +3915,24 @@ static int fetch_counters(mc33hip_ctx *c) {
 	c->w->records_hint = c->w->h_ctr->entry_cursor == 0xFFFFFFFFu ? 0u : c->w->h_ctr->entry_cursor;
 	c->w->slow_hint = c->w->h_ctr->slow_cursor + 1u;
 	c->w->count_known = true; c->w->count_needed = c->w->h_ctr->count_pending != 0u;
-	if (getenv("MC33_HIP_VERBOSE"))
+	if (c->sw.verbose)
 		fprintf(stderr, "[mc33hip] cut cells %u (slow %u, dirty segments %u, record batches %u)\n", c->w->h_ctr->entry_cursor,
 		        c->w->h_ctr->slow_cursor, c->w->h_ctr->dirty_cursor, c->w->h_ctr->batch_cursor);
 	if (c->w->h_ctr->debug[0])
 		fprintf(stderr, "[mc33hip] DEBUG words %u: first %u count %u z %u y0 %u xbase %u batch %u of %u\n", c->w->h_ctr->debug[0], c->w->h_ctr->debug[1], c->w->h_ctr->debug[2],
 		        c->w->h_ctr->debug[3], c->w->h_ctr->debug[4], c->w->h_ctr->debug[5], c->w->h_ctr->debug[6], c->w->h_ctr->debug[7]);
-	if (c->trace_cells && getenv("MC33_HIP_TRACE_CELLS")) {
+	if (c->trace_cells && c->sw.trace_cells) {
 		void *h = malloc(c->trace_cells_n * 32);
 		if (h && hipMemcpy(h, c->trace_cells, c->trace_cells_n * 32, hipMemcpyDeviceToHost) == hipSuccess) {
-			FILE *f = fopen(getenv("MC33_HIP_TRACE_CELLS"), "wb");
+			FILE *f = fopen(c->sw.trace_cells, "wb");
 			if (f) { fwrite(h, 32, c->trace_cells_n, f); fclose(f); }
 		}
 		free(h);
 	}
-	if (c->trace && getenv("MC33_HIP_TRACE_FILE")) {  // developer tracing: per-wave stamps of the last sweep
+	if (c->trace && c->sw.trace_file) {  // developer tracing: per-wave stamps of the last sweep
 		void *h = malloc(c->trace_waves * 32);
 		if (h && hipMemcpy(h, c->trace, c->trace_waves * 32, hipMemcpyDeviceToHost) == hipSuccess) {
-			FILE *f = fopen(getenv("MC33_HIP_TRACE_FILE"), "wb");
+			FILE *f = fopen(c->sw.trace_file, "wb");
 			if (f) { fwrite(h, 32, c->trace_waves, f); fclose(f); }
 		}
 		free(h);
@@ -3972,6 +4066,25 @@ extern "C" int mc33hip_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsign
 	return enqueue_emit(c, dV, dN, dT, capV, capT);
 }
 
+extern "C" int mc33hip_emit_download(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long long capV, unsigned long long capT,
+                                     void *hV, void *hN, void *hT) {
+	if (!c || !c->counted) { set_err("mc33hip_emit_download needs a successful mc33hip_count first"); return MC33HIP_EINVAL; }
+	if (capV < c->counts.nV || capT < c->counts.nT) { set_err("output buffers too small"); return MC33HIP_ECAPACITY; }
+	if ((c->counts.nV && (!dV || !dN || !hV || !hN)) || (c->counts.nT && (!dT || !hT))) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	const DownloadPlan dl{hV, hN, hT, (size_t)c->counts.nV * 3 * sizeof(real_t), (size_t)c->counts.nV * 12, (size_t)c->counts.nT * 12};
+	return enqueue_emit(c, dV, dN, dT, capV, capT, &dl);
+}
+
+extern "C" int mc33hip_download_wait(mc33hip_ctx *c) {
+	if (!c) return MC33HIP_EINVAL;
+	if (hipSetDevice(c->device) != hipSuccess) return MC33HIP_ERUNTIME;
+	HIP_TRY(hipStreamSynchronize(c->copy));    // (ordered behind the passes by the events: the arrays are complete and on the host)
+	HIP_TRY(hipStreamSynchronize(c->stream));  // (... and nothing of the emit is left running when the caller gets its surface)
+	return MC33HIP_OK;
+}
+
 extern "C" int mc33hip_extract(mc33hip_ctx *c, double iso, const mc33hip_range *range, void *dV, void *dN, void *dT,
                                unsigned long long capV, unsigned long long capT, mc33hip_counts *out) {
 	if (!c) return MC33HIP_EINVAL;
@@ -3999,6 +4112,10 @@ extern "C" int mc33hip_extract(mc33hip_ctx *c, double iso, const mc33hip_range *
 
 extern "C" int mc33hip_last_timing(mc33hip_ctx *c, mc33hip_timing *t) {
 	if (!c || !t) return MC33HIP_EINVAL;
+	if (c->timing_level == 0) {  // no events were recorded for the last call: zeros, not an older call's numbers
+		c->emit_pending = false;
+		c->timing.sweep_ms = c->timing.scan_ms = c->timing.emit_ms = c->timing.total_ms = 0.f;
+	}
 	if (c->emit_pending) {  // a separate mc33hip_emit: wait for it and add its time
 		if (hipEventSynchronize(c->ev[3]) == hipSuccess) {
 			(void)hipEventElapsedTime(&c->timing.emit_ms, c->ev[2], c->ev[3]);
@@ -4038,13 +4155,17 @@ extern "C" int mc33hip_probe_read(mc33hip_ctx *c, int reps, float *ms_best, floa
 	if (!c || reps < 1 || reps > 64 || !c->d_grid) return MC33HIP_EINVAL;
 	int rc = use_device(c);
 	if (rc) return rc;
-	const uint64_t nbytes = ((uint64_t)c->slice * c->desc.npz_resident * sizeof(sample_t)) & ~(uint64_t)15;
+	// (a grid the context does not own may be a strided view into a larger allocation: its last plane ends with its last row)
+	const uint64_t nsamples = c->owns_grid ? (uint64_t)c->slice * c->desc.npz_resident
+	                                       : (uint64_t)c->slice * (c->desc.npz_resident - 1u) + (uint64_t)c->pitch * (c->desc.npy - 1u) + c->desc.npx;
+	const uint64_t nbytes = (nsamples * sizeof(sample_t)) & ~(uint64_t)15;
+	if (nbytes < 64) return MC33HIP_EINVAL;
 	const u32x4_t *p = (const u32x4_t *)(((uintptr_t)c->d_grid + 15u) & ~(uintptr_t)15);
 	const uint64_t n16 = (nbytes - ((uintptr_t)p - (uintptr_t)c->d_grid)) / 16;
 	if (!c->cus) HIP_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, c->device));
 	hipEvent_t e0, e1;
 	HIP_TRY(hipEventCreate(&e0));
-	HIP_TRY(hipEventCreate(&e1));
+	if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_err("hipEventCreate failed"); return MC33HIP_ERUNTIME; }
 	std::vector<float> t;
 	for (int k = 0; k < reps + 1; k++) {  // (the first launch is a warm-up)
 		(void)hipEventRecord(e0, c->stream);

@@ -352,7 +352,51 @@ def test_plateau_field_with_integer_isovalue_large(products, reflibs):
         print("u8 plateaus 704 iso %g nV %d nT %d bit-exact V %s N %s" % (iso, got.nV, got.nT, vb, nb))
 
 
-def test_config2_cos1024_full_size(products, reflibs):
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0", "0,0,0,0,0,0,0,0"])
+def test_capi_multi_device_rehearsal(products, reflibs, devices, monkeypatch):
+    """MC33_HIP_DEVICES behind the unchanged C API (create_MC33 / calculate_isosurface / size_of_isosurface): the grid cut into
+    z-slabs, a context per slab, counts on all of them side by side, every slab emitting at its global vertex base and copying
+    straight to its place in the caller's arrays.  This pool has one-GPU boxes: the same ordinal named N times puts the N slabs
+    on the one GPU (the code path is the same; what is NOT exercised is more than one device).  Degenerate-rich grids - aliases
+    that cross the slab interfaces - and smooth ones, float / ushort / uchar, against the reference; a grid with fewer slices
+    than devices; an empty surface."""
+    import ctypes as C
+    monkeypatch.setenv("MC33_HIP_DEVICES", devices)
+    check(products, reflibs, "f32", fx.noise_quant(32, 2), 1.0, label="quant s2 iso 1 devices " + devices)
+    check(products, reflibs, "f32", fx.noise_quant(0, 9, L=3, shape=(40, 9, 300)), 0.0, label="quant L3 wide devices " + devices)
+    check(products, reflibs, "f32", fx.noise_f32(0, 11, shape=(66, 65, 258)), 0.05, label="ragged noise devices " + devices)
+    data, r0, d = fx.cos_field(130)
+    check(products, reflibs, "f32", data, 0.0, r0, d, "cos130 devices " + devices)
+    check(products, reflibs, "f32", data, 0.3, r0, (8 / 129, 4 / 129, 8 / 129), "cos130 anisotropic devices " + devices)
+    check(products, reflibs, "f32", fx.cos_field(40)[0], 0.1, (0.0, 0.0, 0.0), (0.2, 0.3, 0.45), "inclined devices " + devices, inclined=fx.general_matrices())
+    check(products, reflibs, "u16", fx.noise_u16(24, 3, 7), 3.0, label="u16 mod 7 devices " + devices)
+    check(products, reflibs, "u16", fx.cos_field_u16(600, 150, 70), 32768.0, label="u16 smooth integer iso devices " + devices)
+    check(products, reflibs, "u8", (fx.noise_quant(40, 5, L=6) * 20 + 100).astype(np.uint8), 100.0, label="u8 integer iso devices " + devices)
+    check(products, reflibs, "f64", fx.noise_quant(24, 2).astype(np.float64), 1.0, (1.0, 2.0, 3.0), (0.5, 0.25, 1.0), label="f64 devices " + devices)
+    check(products, reflibs, "f32", fx.noise_f32(0, 5, shape=(3, 17, 33)), 0.1, label="two slices devices " + devices)  # fewer slices than devices
+    empty = products["f32"].isosurface(fx.cos_field(20)[0], 100.0)
+    assert (empty.nV, empty.nT) == (0, 0)
+    # size_of_isosurface and a second isovalue on the same object
+    lib, ref = products["f32"], reflibs["f32"]
+    G, keep = lib.make_grid(data, r0, d)
+    M = lib.lib.create_MC33(G)
+    try:
+        for iso in (0.0, 1.5, 0.0):
+            nV, nT = C.c_uint(0), C.c_uint(0)
+            lib.lib.size_of_isosurface(M, C.c_float(iso), C.byref(nV), C.byref(nT))
+            want = ref.isosurface(data, iso, r0, d)
+            assert (nV.value, nT.value) == (want.nV, want.nT)
+            S = lib.lib.calculate_isosurface(M, C.c_float(iso))
+            got = lib.copy_surface(S)
+            lib.lib.free_surface_memory(S)
+            assert_surface_parity(got, want, 8.0, "reused object devices " + devices, bit_exact=True)
+    finally:
+        lib.lib.free_MC33(M)
+        lib.lib.free_memory_grd(G)
+        del keep
+
+
+def test_config2_cos1024_full_size(products, reflibs, monkeypatch):
     """BASELINE.json configs[2] at full size through the reference C API: 1024^3 float grid (4 GiB upload),
     iso 0 - counts as published in SURVEY.md section 6, triangles identical to the reference run on this host,
     positions / normals within 1e-5 (bit-identical in practice)."""
@@ -365,6 +409,12 @@ def test_config2_cos1024_full_size(products, reflibs):
     # size-independent properties: closed level set away from the box faces -> every interior edge is shared by
     # exactly two triangles; ids are dense
     assert got.T.max() == got.nV - 1 and np.all(got.color == got.color[0])
+    # configs[3] behind the C API: MC33_HIP_DEVICES cuts the grid into 8 z-slabs inside create_MC33 (here: all on the one GPU)
+    monkeypatch.setenv("MC33_HIP_DEVICES", "0,0,0,0,0,0,0,0")
+    got8 = products["f32"].isosurface(data, 0.0, r0, d)
+    monkeypatch.delenv("MC33_HIP_DEVICES")
+    assert_surface_parity(got8, ref, 4.0, "cos1024 as 8 slabs behind the C API", bit_exact=True)
+    del got8
     # BASELINE.json configs[3] at ITS size, as far as one GPU allows: the same 1024^3 grid cut into 8 z-slabs of 128 / 127
     # cell slices (the --strong reading; `Slab` is what every rank of bench.py builds), each slab a context of its own
     # holding only its planes + ghost, one after the other on this GPU: counts exchanged on the host, every slab emitting at
@@ -822,6 +872,7 @@ def test_config4_u16_full_size(products, reflibs):
     equal to the reference's calculate_isosurface on the same buffer.  Before that, on the device-level API: two z-slabs of the
     grid concatenate to the whole-volume result."""
     import ctypes as C
+    import os
     import torch
     from mc33_c_library_amd import DeviceGrid
     from mc33_c_library_amd.fields import cos_field_u16
@@ -881,6 +932,21 @@ def test_config4_u16_full_size(products, reflibs):
         S = R.calculate_isosurface(Mr, C.c_float(isos[k]))
         want = ref.copy_surface(S)
         R.free_surface_memory(S)
+        if k == 3:  # the 8-GPU half of configs[4] behind the C API: the same grid as 8 z-slabs (MC33_HIP_DEVICES; here on the one GPU)
+            os.environ["MC33_HIP_DEVICES"] = "0,0,0,0,0,0,0,0"
+            try:
+                L.free_MC33(M)
+                M = L.create_MC33(G)
+                assert M
+                S8 = L.calculate_isosurface(M, C.c_float(isos[k]))
+                assert S8
+                got8 = lib.copy_surface(S8)
+                L.free_surface_memory(S8)
+            finally:
+                del os.environ["MC33_HIP_DEVICES"]
+            _, _, vb8, nb8 = assert_surface_parity(got8, want, 2048.0, "u16 full size iso#%d as 8 slabs" % k)
+            assert vb8 and nb8
+            del got8
         _, _, vb, nb = assert_surface_parity(got, want, 2048.0, "u16 full size iso#%d" % k)
         assert vb and nb
         assert int(got.T.max()) == got.nV - 1 and np.all(got.color == got.color[0])
