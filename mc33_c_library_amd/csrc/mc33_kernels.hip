@@ -92,7 +92,7 @@ struct Counters {
 	uint32_t emit_skipped;  // set by the emit kernels when they refused to run (capacity / overflow)
 	uint32_t count_pending; // set by k_slow_plan when a record waits for k_slow_count
 	uint32_t live_cursor;   // slice slots with cut cells listed by k_slots for k_cells (k_scan_apply, the last kernel of a tail, clears it)
-	uint32_t pad_;
+	uint32_t slow_barrier;  // blocks of k_slow_all that have finished a phase (k_slots zeroes it)
 	uint64_t totV, totT;    // totals over all classified slices (ghost included)
 	uint64_t ghostV, ghostT;
 	uint32_t debug[8];      // (-DMC33_DEV: what a guarded kernel found wrong)
@@ -1296,7 +1296,7 @@ __global__ __launch_bounds__(256) void k_slots(const PerLane<SlotsArgs> A, uint6
 	if (c == 0) for (uint32_t q = gridDim.x + t; q < part_cap; q += 256u) part_next[q] = 0;  // (a later range may be longer)
 	if (c == 0) for (uint32_t q = t; q < LIST_CHUNKS; q += 256u) { lc.slow_cnt[q] = 0; lc.dirty_cnt[q] = 0; }  // the list cursors of this extraction
 	if (c == 0 && t == 0) {        // ... and so are the counters the later passes of this one add to
-		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0; ctr->count_pending = 0;
+		ctr->slow_cursor = 0; ctr->dirty_cursor = 0; ctr->emit_skipped = 0; ctr->count_pending = 0; ctr->slow_barrier = 0;
 		ctr->totV = ctr->totT = ctr->ghostV = ctr->ghostT = 0;
 		for (int q = 0; q < 8; q++) ctr->debug[q] = 0;
 	}
@@ -1728,10 +1728,8 @@ struct SlowArgs {
 	Counters *ctr;
 };
 
-__global__ __launch_bounds__(256) void k_slow_plan(const PerLane<SlowArgs> A) {
-	const SlowArgs &a = A.a[blockIdx.y];
-	__shared__ real_t s_v[8][256];
-	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+// (the bodies of the three kernels as functions: each is a kernel of its own, and all three are the phases of k_slow_all)
+__device__ __forceinline__ void slow_plan_body(const SlowArgs &a, real_t (*s_v)[256], uint32_t *s_pre, uint32_t *s_red, uint32_t *s_dirty) {
 	ChunkMap cm;
 	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);  // (first: its loads and the one of the cursor below go out together)
 	if (a.ctr->entry_cursor > a.entry_cap) return;  // the sweep will be repeated with more room
@@ -1740,7 +1738,6 @@ __global__ __launch_bounds__(256) void k_slow_plan(const PerLane<SlowArgs> A) {
 		uint32_t d = 0;
 		for (uint32_t k = threadIdx.x; k < a.lc.n; k += 256u) d += a.lc.dirty_cnt[k];
 		d = (uint32_t)wave_sum((uint64_t)d);
-		__shared__ uint32_t s_dirty[4];
 		if ((threadIdx.x & 63u) == 0) s_dirty[threadIdx.x >> 6] = d;
 		__syncthreads();
 		if (threadIdx.x == 0) { a.ctr->slow_cursor = n; a.ctr->dirty_cursor = s_dirty[0] + s_dirty[1] + s_dirty[2] + s_dirty[3]; }
@@ -1771,13 +1768,14 @@ __global__ __launch_bounds__(256) void k_slow_plan(const PerLane<SlowArgs> A) {
 		if (en.w3 & ENTRY_SLOW) a.entries_c[ei] = entry_c(pl);
 	}
 }
+__global__ __launch_bounds__(256) void k_slow_plan(const PerLane<SlowArgs> A) {
+	__shared__ real_t s_v[8][256];
+	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256], s_dirty[4];
+	slow_plan_body(A.a[blockIdx.y], s_v, s_pre, s_red, s_dirty);
+}
 
 // the triangles of the slow cells that have a corner equal to the isovalue, counted by vertex identity on the stored plans
-__global__ __launch_bounds__(256) void k_slow_count(const PerLane<SlowArgs> A) {
-	const SlowArgs &a = A.a[blockIdx.y];
-	__shared__ real_t s_w[8][256];
-	__shared__ uint64_t s_key[12][256];
-	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+__device__ __forceinline__ void slow_count_body(const SlowArgs &a, real_t (*s_w)[256], uint64_t (*s_key)[256], uint32_t *s_pre, uint32_t *s_red) {
 	if (!a.ctr->count_pending) return;  // (no sample of a slow cell equals the isovalue: most calls)
 	ChunkMap cm;
 	cm.build(s_pre, s_red, a.lc.slow_cnt, a.lc.n);
@@ -1805,6 +1803,12 @@ __global__ __launch_bounds__(256) void k_slow_count(const PerLane<SlowArgs> A) {
 		a.entries_a[ei].a0 = (ea.a0 & ~(15u << 20) & ~ENTRYA_COUNT) | nt << 20;
 	}
 }
+__global__ __launch_bounds__(256) void k_slow_count(const PerLane<SlowArgs> A) {
+	__shared__ real_t s_w[8][256];
+	__shared__ uint64_t s_key[12][256];
+	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+	slow_count_body(A.a[blockIdx.y], s_w, s_key, s_pre, s_red);
+}
 
 // one thread per row segment that holds slow cells: running offsets of its records, segment totals.  A record that still waits
 // for its triangle count (ENTRYA_COUNT) is counted on the way: k_slow_count, a launch of its own for exactly that, costs 5 - 6 us
@@ -1812,11 +1816,7 @@ __global__ __launch_bounds__(256) void k_slow_count(const PerLane<SlowArgs> A) {
 // extraction of the context had such records (then they are many, and a thread per RECORD is the faster way through them), and
 // whatever is left over when it was not enqueued - the isovalue has moved onto the samples since - is caught here, a segment's
 // records one after the other.
-__global__ __launch_bounds__(256) void k_seg_fix(const PerLane<SlowArgs> A) {
-	const SlowArgs &a = A.a[blockIdx.y];
-	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
-	__shared__ real_t s_w[8][256];
-	__shared__ uint64_t s_key[12][256];
+__device__ __forceinline__ void seg_fix_body(const SlowArgs &a, real_t (*s_w)[256], uint64_t (*s_key)[256], uint32_t *s_pre, uint32_t *s_red) {
 	const uint32_t dirty_total = a.ctr->dirty_cursor, records = a.ctr->entry_cursor;  // (asked for together)
 	const bool pending = a.ctr->count_pending != 0u;  // (k_slow_plan: some record waits for its count - unless k_slow_count has been through)
 	if (blockIdx.x * 256u >= dirty_total) return;  // (k_slow_plan left the total there)
@@ -1855,6 +1855,48 @@ __global__ __launch_bounds__(256) void k_seg_fix(const PerLane<SlowArgs> A) {
 		}
 		a.seg_cnt[s] = seg_tagged(nv, nt, a.seg_tag);
 	}
+}
+__global__ __launch_bounds__(256) void k_seg_fix(const PerLane<SlowArgs> A) {
+	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256];
+	__shared__ real_t s_w[8][256];
+	__shared__ uint64_t s_key[12][256];
+	seg_fix_body(A.a[blockIdx.y], s_w, s_key, s_pre, s_red);
+}
+
+// The three as ONE launch (round 5; built, bit-identical, SLOWER - MC33_HIP_SLOW_MERGED=1 runs it, the library does not): for the
+// usual case of FEW slow records - cells on the grid's faces, a corner equal to the isovalue here and there: 8 800 at 1024^3 are 35
+// blocks' worth of work behind three launches, each a grid-wide dependency (plans must all be stored before identities are
+// counted, counts before the offsets of a row segment are rebuilt).  The blocks of this kernel - as few as the last extraction's
+// slow records need, 64 at most, all resident at once - pass two barriers instead: every block adds one to a counter in the
+// isovalue's Counters (k_slots has zeroed it) when its share of a phase is stored, and waits until all have.  Measured at 1024^3
+// (profiles/r05_tail_merge.txt): 39 us against 13 + 10 for k_slow_plan + k_seg_fix as launches of their own, the tail 0.141
+// against 0.126 ms.  The blocks sit on eight XCDs, each behind an L2 of its own: a barrier between them is a write-back of that
+// L2 (buffer_wbl2 sc1), a device-scope atomic, a polling loop on a line that comes from memory every time, and an invalidate
+// (buffer_inv sc1) - ~8 us each, where the end of a kernel does the same for every XCD at once in ~1 us (the sum of the tail's
+// kernel durations IS its event time: there is no gap between launches to win back).  The same holds for anything else that
+// would fold a grid-wide dependency of the tail into a kernel - the slice between two sweep tiles done by whichever wave ends
+// second, k_slots at the head of k_cells: each needs this release / acquire pair per wave or block.  Not pursued.
+constexpr uint32_t SLOW_ALL_MAX_BLOCKS = 64;
+__device__ __forceinline__ void slow_barrier(uint32_t *counter, uint32_t target) {
+	__threadfence();   // (every thread: its stores of the phase, released to the device - the blocks run on different XCDs, each behind an L2 of its own)
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+	}
+	__syncthreads();
+	__threadfence();   // (acquire: nothing read below may come from a line cached before the others' stores)
+}
+__global__ __launch_bounds__(256) void k_slow_all(const PerLane<SlowArgs> A) {
+	const SlowArgs &a = A.a[blockIdx.y];
+	__shared__ real_t s_w[8][256];
+	__shared__ uint64_t s_key[12][256];
+	__shared__ uint32_t s_pre[LIST_CHUNKS + 1], s_red[256], s_dirty[4];
+	slow_plan_body(a, s_w, s_pre, s_red, s_dirty);
+	slow_barrier(&a.ctr->slow_barrier, gridDim.x);
+	slow_count_body(a, s_w, s_key, s_pre, s_red);
+	slow_barrier(&a.ctr->slow_barrier, 2u * gridDim.x);
+	seg_fix_body(a, s_w, s_key, s_pre, s_red);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2122,12 +2164,29 @@ __global__ __launch_bounds__(256) void k_emit_fast_vertices(const EmitArgs a) {
 constexpr uint32_t EV_W = MC33_EV_W;
 constexpr uint32_t EV_ROWS = 65;         // sample rows 0..64 of a tile (63 cell rows, y + 2 above the last)
 constexpr uint32_t EV_EMPTY = 0xFFFFFFFFu;
+// The image as a RING of planes (round 5; built, measured, NOT the form that runs: MC33_EV_RING=1 in developer builds).  Plane z
+// lives in slot z % 3 and stays there while the wave goes on to the next batch - a wave takes a CONTIGUOUS piece of the batches
+// (MC33_EV_PIECE; or runs of MC33_EV_RUN batches), i.e. the batches of a slice one after the other and then the next slice of the
+// same tile column (slice_slot: the four slices of a group are adjacent), whose stencils (MC:990-1000, 1029-1039, 1175-1185) read
+// two of the same three planes.  Every (slot, row) carries a tag - which chunks of the row it holds - and a batch loads only the
+// windows its records need that are not there yet.  Bit-identical (148 GPU tests), and slower (profiles/r05_vertex_ring.txt):
+// float 1024^3 123 -> 150 us, 322 -> 518 MB read; ushort 2048 x 2048 x 1024 485 -> 750 us per isovalue, 1.42 -> 1.71 GB.  What the
+// strided walk shares between neighbouring waves at the same moment is whole 128-byte LINES in L2 (32 floats of a row: any shift
+// of the surface from slice to slice stays inside), what the ring keeps is the 48-byte window one batch needed - the next slice's
+// records, a cell or two further along x, miss it half of the time; and a wave that walks consecutive batches alone has no
+// neighbour to share lines with (the reads grow with the run: 326 / 438 / 497 / 495 MB for runs of 1 / 4 / 8 / 16).  The tags and
+// selects cost 14 % more vector instructions on top (46.2 M against 40.5 M per launch; 138 us with the ring's code on the strided
+// walk, where it can reuse nothing).
+#ifndef MC33_EV_RING
+#define MC33_EV_RING 0
+#endif
 struct EmitVLds {                        // per wave
 	uint32_t rowA[64], rowB[64];         // cell rows 0..62 of the tile: first / last record of the batch in that row, lane << 8 | x in the segment
 	uint32_t rowvb[64];                  // cell rows: id of the first vertex of the row segment (seg_base)
 	uint32_t rowinfo[EV_ROWS + 1];       // sample rows: staged << 31 | chunks - 1 << 16 | first chunk - chunk of the segment's first sample
 	uint32_t vlist[256];                 // vertices of the batch: record (lane) | kind << 8, by kind
-	uint4 data[3 * EV_ROWS * EV_W];      // [plane][row][chunk]
+	uint32_t tag[3][EV_ROWS + 1];        // what slot s holds of sample row r: valid << 31 | chunks - 1 << 16 | first chunk (as rowinfo)
+	uint4 data[3 * EV_ROWS * EV_W];      // [slot][row][chunk]
 };
 
 // Which wave takes which batch: each XCD gets one contiguous eighth of the batches (its own L2: see XcdWalk), and the waves
@@ -2167,6 +2226,16 @@ struct XcdBatchWalk {
 #endif
 		base = xcd * per_xcd; waves = blocks_per_xcd * 4u; wave = slot * 4u + (threadIdx.x >> 6);
 		if (MC33_EV_RUN > 1) first = at(0u);
+#ifndef MC33_EV_PIECE
+#define MC33_EV_PIECE MC33_EV_RING
+#endif
+#if MC33_EV_PIECE
+		// every wave ONE contiguous piece of its XCD's eighth (the image in LDS is carried from batch to batch)
+		const uint32_t piece = (per_xcd + waves - 1u) / waves;
+		first = min(base + wave * piece, xend);
+		end = min(first + piece, xend);
+		stride = 1u;
+#endif
 	}
 };
 
@@ -2248,6 +2317,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 		}
 		asm volatile("" ::"v"(r.seg), "v"(r.rowvb));
 	};
+	// ring of planes: the image holds the planes ring_z .. ring_z + 2 of tile column (ring_y0, ring_xbase) - those of the batch staged last (wave-uniform)
+	uint32_t ring_z = 0u, ring_y0 = 0xFFFFFFFFu, ring_xbase = 0xFFFFFFFFu;
 	uint32_t t = 0, j = w.at(0u);
 	BatchInfo d0 = load_batch(a.batches, j), d1 = d0;
 	if (w.at(1u) < w.end) d1 = load_batch(a.batches, w.at(1u));
@@ -2337,14 +2408,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 				const uint32_t pitchB = G.pitch * SZ;
 				constexpr uint32_t NITEM = EV_ROWS * EV_W, NGRP = (NITEM + 63u) / 64u;
 				static_assert(NGRP <= 5, "groups of the staging loads");
+				// ring: plane z + k of this slice lives in slot (z + k) % 3.  A slot that holds another plane, or a plane of another
+				// tile column, is empty: its tags are cleared (wave-uniform decisions) before anybody looks at them.
+				const uint32_t s0 = MC33_EV_RING ? z % 3u : 0u, s1 = s0 == 2u ? 0u : s0 + 1u, s2 = s1 == 2u ? 0u : s1 + 1u;
+				if (MC33_EV_RING) {
+					const bool other = ring_y0 != y0 || ring_xbase != xbase;
+					const uint32_t sk[3] = {s0, s1, s2};
+#pragma unroll
+					for (uint32_t k = 0; k < 3u; k++)
+						if (other || z + k - ring_z > 2u) {  // (unsigned: also a plane below the ones held)
+							L.tag[sk[k]][lane] = 0u;
+							if (lane < EV_ROWS + 1u - 64u) L.tag[sk[k]][64u + lane] = 0u;
+						}
+					ring_z = z; ring_y0 = y0; ring_xbase = xbase;
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				}
 				// (the row words of all groups first: one LDS wait, not one per group)
 				uint32_t info[NGRP];
+				uint32_t have0[NGRP], have1[NGRP], have2[NGRP];
 #pragma unroll
-				for (uint32_t g = 0; g < NGRP; g++) info[g] = L.rowinfo[min((g * 64u + lane) / EV_W, EV_ROWS - 1u)];
+				for (uint32_t g = 0; g < NGRP; g++) {
+					const uint32_t rr = min((g * 64u + lane) / EV_W, EV_ROWS - 1u);
+					info[g] = L.rowinfo[rr];
+					if (MC33_EV_RING) { have0[g] = L.tag[s0][rr]; have1[g] = L.tag[s1][rr]; have2[g] = L.tag[s2][rr]; }
+				}
+				// does the window a slot holds of a row (tag) cover the one the batch needs (rowinfo)?
+				auto covers = [](uint32_t have, uint32_t want) -> bool {
+					const uint32_t hl = have & 0xFFFFu, wl = want & 0xFFFFu;
+					return (have >> 31) && hl <= wl && wl + ((want >> 16) & 3u) <= hl + ((have >> 16) & 3u);
+				};
 				const uint4 zero4 = {0u, 0u, 0u, 0u};
 				uint4 qa0 = zero4, qa1 = zero4, qa2 = zero4, qb0 = zero4, qb1 = zero4, qb2 = zero4, qc0 = zero4, qc1 = zero4, qc2 = zero4;
 				uint4 qd0 = zero4, qd1 = zero4, qd2 = zero4, qe0 = zero4, qe1 = zero4, qe2 = zero4;
-				auto fetch = [&](uint32_t g, uint4 &q0, uint4 &q1, uint4 &q2) -> bool {
+				// (returns bit k: plane z + k of the item was loaded)
+				auto fetch = [&](uint32_t g, uint4 &q0, uint4 &q1, uint4 &q2) -> uint32_t {
 					const uint32_t it = g * 64u + lane;
 					const uint32_t r = it / EV_W, ck = it - r * EV_W;
 					const bool need = it < NITEM && (info[g] >> 31) && ck <= ((info[g] >> 16) & 3u);
@@ -2352,24 +2449,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 					// through a buffer descriptor with those lanes aimed past its end - the hardware answers zeros, no branch, no
 					// registers to clear, 54 vector instructions less in the kernel - 112 -> 115 us at C3, 501 -> 525 at C5: a lane that is
 					// switched off costs the memory pipeline nothing, a lane that is refused does)
+					uint32_t got = 0u;
 					if (need) {
 						const char *addr = plane0 + (uint64_t)r * pitchB + (uint64_t)((info[g] & 0xFFFFu) + ck) * 16u;
-						q0 = *(const uint4 *)addr;
-						q1 = *(const uint4 *)(addr + sliceB);
-						if (zin) q2 = *(const uint4 *)(addr + 2u * sliceB);
+						if (!MC33_EV_RING || !covers(have0[g], info[g])) { q0 = *(const uint4 *)addr; got |= 1u; }
+						if (!MC33_EV_RING || !covers(have1[g], info[g])) { q1 = *(const uint4 *)(addr + sliceB); got |= 2u; }
+						if (zin && (!MC33_EV_RING || !covers(have2[g], info[g]))) { q2 = *(const uint4 *)(addr + 2u * sliceB); got |= 4u; }
 					}
-					return need;
+					return got;
 				};
-				auto put = [&](uint32_t g, bool need, const uint4 &q0, const uint4 &q1, const uint4 &q2) {
+				// (the chunk goes to its slot, and the lane of a row's first chunk notes what the slot now holds of the row)
+				auto put = [&](uint32_t g, uint32_t got, const uint4 &q0, const uint4 &q1, const uint4 &q2) {
 					const uint32_t it = g * 64u + lane;
-					if (need) {
-						L.data[it] = q0;
-						L.data[NITEM + it] = q1;
-						L.data[2u * NITEM + it] = q2;
-					}
+					const uint32_t r = it / EV_W, ck = it - r * EV_W;
+					if (got & 1u) { L.data[s0 * NITEM + it] = q0; if (MC33_EV_RING && ck == 0u) L.tag[s0][r] = info[g]; }
+					if (got & 2u) { L.data[s1 * NITEM + it] = q1; if (MC33_EV_RING && ck == 0u) L.tag[s1][r] = info[g]; }
+					if (got & 4u) { L.data[s2 * NITEM + it] = q2; if (MC33_EV_RING && ck == 0u) L.tag[s2][r] = info[g]; }
 				};
-				const bool na = fetch(0u, qa0, qa1, qa2), nb = fetch(1u, qb0, qb1, qb2), nc = fetch(2u, qc0, qc1, qc2);
-				const bool nd = NGRP > 3 ? fetch(3u, qd0, qd1, qd2) : false, ne = NGRP > 4 ? fetch(4u, qe0, qe1, qe2) : false;
+				const uint32_t na = fetch(0u, qa0, qa1, qa2), nb = fetch(1u, qb0, qb1, qb2), nc = fetch(2u, qc0, qc1, qc2);
+				const uint32_t nd = NGRP > 3 ? fetch(3u, qd0, qd1, qd2) : 0u, ne = NGRP > 4 ? fetch(4u, qe0, qe1, qe2) : 0u;
 				put(0u, na, qa0, qa1, qa2); put(1u, nb, qb0, qb1, qb2); put(2u, nc, qc0, qc1, qc2);
 				if (NGRP > 3) put(3u, nd, qd0, qd1, qd2);
 				if (NGRP > 4) put(4u, ne, qe0, qe1, qe2);
@@ -2396,7 +2494,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 				const uint32_t rw0 = xl | rho << 8 | r5 << 16 | r6 << 20 | r10 << 24 | (xin ? 1u << 28 : 0u) | (yin ? 1u << 29 : 0u);
 				const uint32_t rw1 = (i0 & 0xFFu) | (i1 & 0xFFu) << 8 | (i2 & 0xFFu) << 16;  // first chunk of rows rho, rho + 1, rho + 2 | rho
 				const char *img = (const char *)L.data;
+#ifdef MC33_EV_ONE_ITER  // (developer timing experiment, results wrong: what would the pass take if no batch had more than 64 vertices?)
+				for (uint32_t v0 = 0; v0 < min(nv, 64u); v0 += 64u) {
+#else
 				for (uint32_t v0 = 0; v0 < nv; v0 += 64u) {  // wave-uniform
+#endif
 					const bool act = v0 + lane < nv;
 					const uint32_t ent = L.vlist[act ? v0 + lane : 0u];
 					const uint32_t src = (ent & 63u) << 2, kind = ent >> 8;
@@ -2409,12 +2511,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 						// sample (dx, dy, dz) of the cell: byte in the image
 						const uint32_t xb0 = vxl * SZ + ((xbase * SZ) & 15u);
 						// (the byte of sample x in the three rows of the cell, once; a plane is EV_ROWS * EV_W chunks on)
+#if MC33_EV_RING
+						// ring: plane z + dz sits in slot (z + dz) % 3, and what a slot holds of a row begins at the chunk its TAG names
+						// (the window may have been staged for an earlier batch with other records)
+						const uint32_t zs0 = z % 3u, zs1 = zs0 == 2u ? 0u : zs0 + 1u, zs2 = zs1 == 2u ? 0u : zs1 + 1u;
+						const uint32_t vr2 = vyin ? vrho + 2u : vrho;
+						auto rowbyte = [&](uint32_t sl, uint32_t rw) -> uint32_t {  // byte of the cell's sample x in slot sl, row rw
+							return sl * (EV_ROWS * EV_W * 16u) + (rw * EV_W - (L.tag[sl][rw] & 0xFFFFu)) * 16u + xb0;
+						};
+						// (nine named values and selects: an array indexed by dy / dz - some are per-lane values - lived in scratch memory)
+						const uint32_t b00 = rowbyte(zs0, vrho), b01 = rowbyte(zs0, vrho + 1u), b02 = rowbyte(zs0, vr2);
+						const uint32_t b10 = rowbyte(zs1, vrho), b11 = rowbyte(zs1, vrho + 1u), b12 = rowbyte(zs1, vr2);
+						const uint32_t b20 = rowbyte(zs2, vrho), b21 = rowbyte(zs2, vrho + 1u), b22 = rowbyte(zs2, vr2);
+						(void)w1;
+						auto smp = [&](uint32_t dx, uint32_t dy, uint32_t dz) -> sample_t {
+							const uint32_t p0 = dy == 0u ? b00 : dy == 1u ? b01 : b02, p1 = dy == 0u ? b10 : dy == 1u ? b11 : b12, p2 = dy == 0u ? b20 : dy == 1u ? b21 : b22;
+							return *(const sample_t *)(img + (dz == 0u ? p0 : dz == 1u ? p1 : p2) + dx * SZ);
+						};
+#else
 						const uint32_t rb0 = (vrho * EV_W - (w1 & 0xFFu)) * 16u + xb0, rb1 = ((vrho + 1u) * EV_W - ((w1 >> 8) & 0xFFu)) * 16u + xb0,
 						               rb2 = ((vrho + 2u) * EV_W - ((w1 >> 16) & 0xFFu)) * 16u + xb0;
 						auto smp = [&](uint32_t dx, uint32_t dy, uint32_t dz) -> sample_t {
 							const uint32_t rb = dy == 0u ? rb0 : dy == 1u ? rb1 : rb2;
 							return *(const sample_t *)(img + rb + dz * (EV_ROWS * EV_W * 16u) + dx * SZ);
 						};
+#endif
 						// corner A of the edge: (1,1,0) edge 5 | (1,0,1) edge 6 | (0,1,1) edge 10; B = (1,1,1)
 						const uint32_t ax = kind != 2u, ay = kind != 1u, az = kind != 0u;
 						const real_t iso = P.iso;
@@ -2755,9 +2876,9 @@ struct TailSet {
 // The environment switches (developer A/B, the tests that force a code path), read ONCE when a context is created: a getenv walks
 // the whole environment, and there were some twenty of them on every call.  0 / -1 / nullptr = not set: the library decides.
 struct Switches {
-	uint32_t rz, sweep_blocks_per_cu, min_depth, cells_blocks, slow_blocks, emit_blocks, emit_v_blocks_per_cu;
+	uint32_t rz, sweep_blocks_per_cu, min_depth, cells_blocks, slow_blocks, emit_blocks, emit_v_blocks_per_cu, slow_slots_max;
 	bool no_pack, no_stage, verbose;
-	int slow_count, tails_ahead, no_fork, slow_slots, tri_first;  // -1: not set
+	int slow_count, tails_ahead, no_fork, slow_slots, tri_first, slow_merged;  // -1: not set
 	char *trace_cells, *trace_file;                               // (developer tracing: file names; copies)
 	uint32_t debug, cells_dev, sweep_subtract, tri_below, old_vertex_pass;  // (looked at by -DMC33_DEV builds only)
 };
@@ -2826,10 +2947,10 @@ static int env_flag(const char *name) {  // -1: not set
 static void read_switches(Switches &w) {
 	w.rz = env_u32("MC33_HIP_RZ", 0); w.sweep_blocks_per_cu = env_u32("MC33_HIP_SWEEP_BLOCKS_PER_CU", 0); w.min_depth = env_u32("MC33_HIP_MIN_DEPTH", 0);
 	w.cells_blocks = env_u32("MC33_HIP_CELLS_BLOCKS", 0); w.slow_blocks = env_u32("MC33_HIP_SLOW_BLOCKS", 0); w.emit_blocks = env_u32("MC33_HIP_EMIT_BLOCKS", 0);
-	w.emit_v_blocks_per_cu = env_u32("MC33_HIP_EMIT_V_BLOCKS_PER_CU", 0);
+	w.emit_v_blocks_per_cu = env_u32("MC33_HIP_EMIT_V_BLOCKS_PER_CU", 0); w.slow_slots_max = env_u32("MC33_HIP_SLOW_SLOTS_MAX", 0);
 	w.no_pack = env_u32("MC33_HIP_NO_PACK", 0) != 0; w.no_stage = env_u32("MC33_HIP_NO_STAGE", 0) != 0; w.verbose = getenv("MC33_HIP_VERBOSE") != nullptr;
 	w.slow_count = env_flag("MC33_HIP_SLOW_COUNT"); w.tails_ahead = env_flag("MC33_HIP_TAILS_AHEAD"); w.no_fork = env_flag("MC33_HIP_NO_FORK");
-	w.slow_slots = env_flag("MC33_HIP_SLOW_SLOTS"); w.tri_first = env_flag("MC33_HIP_TRI_FIRST");
+	w.slow_slots = env_flag("MC33_HIP_SLOW_SLOTS"); w.tri_first = env_flag("MC33_HIP_TRI_FIRST"); w.slow_merged = env_flag("MC33_HIP_SLOW_MERGED");
 	w.trace_cells = getenv("MC33_HIP_TRACE_CELLS") ? strdup(getenv("MC33_HIP_TRACE_CELLS")) : nullptr;
 	w.trace_file = getenv("MC33_HIP_TRACE_FILE") ? strdup(getenv("MC33_HIP_TRACE_FILE")) : nullptr;
 	w.debug = env_u32("MC33_HIP_DEBUG", 0); w.cells_dev = env_u32("MC33_HIP_CELLS_DEV", 0); w.sweep_subtract = env_u32("MC33_HIP_SWEEP_SUBTRACT", 0);
@@ -3105,6 +3226,7 @@ extern "C" int mc33hip_adopt_device(mc33hip_ctx *c, const void *dptr, size_t pit
 	c->owns_grid = false;
 	c->pitch = pitch;
 	c->slice = slice;
+	c->tiles_ze = 0u;  // (the plan counts its work in batches of the form - packed or not - this buffer's alignment allows)
 	c->counted = false;
 	forget_sweeps(c);
 	return MC33HIP_OK;
@@ -3233,6 +3355,7 @@ static int grow_entries(TailSet &w, uint64_t need) {
 // about `depth` slices deep), and the number of chunks is a whole multiple of what the device holds at
 // once whenever the grid is large enough.  Measured on MI355X at 1024^3: with 1088 equal tiles on 256 CUs
 // the 64 CUs that got a fifth block finished 12 % after the others.
+static bool sweep_packed(const mc33hip_ctx *c);
 static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 	const Params &P = c->P;
 	const uint32_t depth = c->sw.rz ? c->sw.rz : 16u;
@@ -3257,7 +3380,12 @@ static int plan_sweep(mc33hip_ctx *c, uint32_t zs, uint32_t ze) {
 		for (uint32_t xg = 0; xg < nXG; xg++) {
 			const uint64_t i = (uint64_t)yt * nXG + xg;
 			waves[i] = std::min(4u, P.nseg - xg * 4);
-			w[i] = (double)std::min(64u, P.ny + 1 - yt * 63u);
+			// (in whole BATCHES of sample rows - 4 rows of float samples, 8 / 16 of packed ushort / uchar ones: a wave's time is the
+			// number of batches it waits for, and a y tile of 2 rows costs a batch per plane like one of 4.  Counted in rows, the
+			// 2-row last y tile of a 128^3 grid got pieces twice as deep as its time allows and the sweep took 0.060 ms where the
+			// 256^3 one takes 0.035: VERDICT r4 weak 12)
+			const uint32_t rb = sweep_packed(c) ? 4u * (uint32_t)SWEEP_PACK : 4u;
+			w[i] = (double)((std::min(64u, P.ny + 1 - yt * 63u) + rb - 1u) / rb * rb);
 			W += w[i] * waves[i];
 		}
 	// wave tiles wanted: W * nzc / (64 * depth), rounded to whole rounds of the resident set
@@ -3586,6 +3714,16 @@ static int enqueue_tail(mc33hip_ctx *c, const int *idx, const int *sidx, const d
 	// whose 8 820 slow cells are 35 blocks' worth - changes nothing: 13.5 / 6 / 8.7 us either way.  What these kernels take is
 	// the chain of dependent loads of the cells that ARE slow, not their empty blocks; round 3)
 	const uint32_t slow_blocks = c->sw.slow_blocks ? c->sw.slow_blocks : 1024u;
+	// planning, identity counts and segment offsets: three launches - or, with MC33_HIP_SLOW_MERGED=1, ONE whose blocks wait for
+	// each other (k_slow_all: 64 blocks at most, all resident together)
+	bool merged = false;  // (measured and lost: see k_slow_all)
+	uint32_t hint = 0;
+	for (int q = 0; q < n; q++) hint = std::max(hint, c->ts[sidx[q]].slow_hint);
+	if (c->sw.slow_merged >= 0) merged = c->sw.slow_merged != 0;
+	if (merged) {
+		const uint32_t blocks = std::min(SLOW_ALL_MAX_BLOCKS, std::max(1u, (hint + hint / 4u + 255u) / 256u));  // (any number is right: the phases stride)
+		hipLaunchKernelGGL(k_slow_all, dim3(blocks, ny), dim3(256), 0, st, WA);
+	} else {
 	hipLaunchKernelGGL(k_slow_plan, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
 	{  // k_slow_count only when the last extraction of (one of) the set(s) had records for it, or nothing is known: k_seg_fix counts what is left over
 		bool wanted = false;
@@ -3594,6 +3732,7 @@ static int enqueue_tail(mc33hip_ctx *c, const int *idx, const int *sidx, const d
 		if (wanted) hipLaunchKernelGGL(k_slow_count, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
 	}
 	hipLaunchKernelGGL(k_seg_fix, dim3(slow_blocks, ny), dim3(256), 0, st, WA);
+	}
 	hipLaunchKernelGGL(k_scan_reduce, dim3(nb, ny), dim3(256), 0, st, NA, c->nsegs, c->P);
 	hipLaunchKernelGGL(k_scan_apply, dim3(nb, ny), dim3(256), 0, st, NA, c->nsegs, c->P, c->ghost_segs);
 	HIP_TRY(hipGetLastError());
@@ -3811,7 +3950,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
 	// ended 0 - 3 us behind the triangle pass (profiles/r04_vertex_pass_bimodal.txt).  MANY slow records (noise, integer isovalues on
 	// integer grids) - or an unknown number - take a thread each (k_emit_slow), on large grids beside the fast passes on the second
 	// stream as before, the vertex pass first as before.  MC33_HIP_SLOW_SLOTS=0 / 1 forces the kernel, MC33_HIP_NO_FORK the streams.
-	const bool slow_slots = c->sw.slow_slots >= 0 ? c->sw.slow_slots != 0 : (c->w->slow_hint != 0u && c->w->slow_hint <= 32768u);
+	const bool slow_slots = c->sw.slow_slots >= 0 ? c->sw.slow_slots != 0 : (c->w->slow_hint != 0u && c->w->slow_hint <= (c->sw.slow_slots_max ? c->sw.slow_slots_max : 32768u));
 	const bool fork_slow = fork_all || (!fork_env && !slow_slots && range_cells >= 300000000ull);  // (small grids: the events cost more than they gain)
 	const bool tri_first = !fork_all && (c->sw.tri_first >= 0 ? c->sw.tri_first != 0 : (c->w->records_hint <= 6000000u && !fork_slow));
 	hipStream_t sv = fork_all ? c->aux : c->stream, ss = fork_slow ? c->aux2 : c->stream;

@@ -102,7 +102,8 @@ def test_product_matches_committed_golden_vectors(products, name):
 
 @pytest.mark.parametrize("switch", ["MC33_HIP_TRI_FIRST=0", "MC33_HIP_TRI_FIRST=1", "MC33_HIP_NO_FORK=0", "MC33_HIP_NO_FORK=1",
                                     "MC33_HIP_TRI_FIRST=0,MC33_HIP_NO_FORK=1", "MC33_HIP_TRI_FIRST=1,MC33_HIP_NO_FORK=1",
-                                    "MC33_HIP_NO_PACK=1", "MC33_HIP_NO_STAGE=1", "MC33_HIP_SLOW_SLOTS=0,MC33_HIP_NO_FORK=0"])
+                                    "MC33_HIP_NO_PACK=1", "MC33_HIP_NO_STAGE=1", "MC33_HIP_SLOW_SLOTS=0,MC33_HIP_NO_FORK=0",
+                                    "MC33_HIP_SLOW_MERGED=0", "MC33_HIP_SLOW_MERGED=1", "MC33_HIP_SLOW_MERGED=1,MC33_HIP_SLOW_COUNT=0"])
 def test_every_emit_order_and_code_path_switch(products, reflibs, switch, monkeypatch):
     """The library picks the order of its emit passes, the streams they run on, the packed / unpacked form of the sweep and the
     staged / direct form of the vertex pass from what the last extraction looked like; each switch below forces one of those
