@@ -268,7 +268,7 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True, capi=F
     dist = E.dist
     from mc33_c_library_amd import DeviceGrid
     from mc33_c_library_amd.fields import cos_field_slab, cos_field_u16
-    from mc33_c_library_amd.slabs import Slab, SurfaceExchange, extract_slab, extract_slab_many
+    from mc33_c_library_amd.slabs import Slab, SurfaceExchange, extract_slab, extract_slab_many, extract_slab_on_device
     world, rank, dev, multi, rehearsal, all_reduce = E.world, E.rank, E.dev, E.multi, E.rehearsal, E.all_reduce
     steps = steps if steps is not None else args.steps
     warmup = warmup if warmup is not None else args.warmup
@@ -333,6 +333,9 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True, capi=F
     sweep_many = len(isos) > 1 and os.environ.get("MC33_BENCH_SWEEP_MANY", "1") != "0"
     # N > 1: count all isovalues, exchange ALL counts in one collective, then emit (MC33_BENCH_COUNT_ALL=0: one count exchange per isovalue)
     count_all = os.environ.get("MC33_BENCH_COUNT_ALL", "1") != "0"
+    # N > 1 over RCCL, `allgather`: the count exchange stays on the device (slabs.extract_slab_on_device; MC33_BENCH_DEVICE_COUNTS=0: the
+    # host-side flow - count, wait, collective, read back, emit).  The rehearsal over gloo needs host tensors and keeps the host flow.
+    device_counts = multi and not rehearsal and args.gather == "allgather" and os.environ.get("MC33_BENCH_DEVICE_COUNTS", "1") != "0"
     sweep_ms, scan_ms, emit_ms, step_ms = [], [], [], []
     state = {"step": 0, "counts": None, "b": 0}
 
@@ -368,7 +371,13 @@ def run_config(args, cfg, E, points=0, steps=None, warmup=None, cpu=True, capi=F
                 # (two sets of buffers; a set is reused only after its previous exchange has completed).
                 b = state["step"] % nbuf
                 state["step"] += 1
-                counts, c = extract_slab(grid, slab, ex, iso, b, async_op=overlap)
+                if device_counts:  # counts gathered and turned into id bases on the device: nothing waits between count and emit
+                    res = extract_slab_on_device(grid, slab, ex, iso, b, async_op=overlap)
+                    if res is None:   # (cannot be: the capacity pass above has sized this rank's record buffers for every isovalue)
+                        raise RuntimeError("rank %d: work records did not fit during a device-side step" % rank)
+                    counts, c = res
+                else:
+                    counts, c = extract_slab(grid, slab, ex, iso, b, async_op=overlap)
                 state["counts"], state["b"] = counts, b
                 if record == 2:
                     t = grid.timing()

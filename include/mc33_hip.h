@@ -127,6 +127,21 @@ int mc33hip_set_id_base(mc33hip_ctx *c, unsigned int id_base);
  * (MC:780-1252).  Asynchronous on the context's stream. */
 int mc33hip_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long long capV, unsigned long long capT);
 
+/* A z-slab's count, count exchange and emit with no host round trip in between (the reference has no such
+ * step - its one process numbers the vertices as it sweeps, MC:1783-1808).  mc33hip_count_async enqueues what mc33hip_count
+ * does and returns; mc33hip_counts_to_device leaves {vertices, triangles} of the counted range as two 64-bit integers in DEVICE
+ * memory (for a collective to gather: torch.distributed.all_gather_into_tensor over RCCL); mc33hip_bases_from_table turns the
+ * gathered table - rank r's pair at device_table[r * stride] - into this rank's vertex id base and, with concatenated != 0, the
+ * rows at which it writes into output arrays shared by all ranks (0: arrays of its own); mc33hip_emit_at_device_bases is
+ * mc33hip_emit with those words read on the device (capacities are checked there too).  All four only enqueue on the context's
+ * stream.  mc33hip_count_finish waits and brings the counts to the host: MC33HIP_ECAPACITY when the work records did not fit
+ * (room has been made: repeat the step with mc33hip_count) or the outputs were too small. */
+int mc33hip_count_async(mc33hip_ctx *c, double iso, const mc33hip_range *range);
+int mc33hip_counts_to_device(mc33hip_ctx *c, long long *device_dst);
+int mc33hip_bases_from_table(mc33hip_ctx *c, const long long *device_table, int stride, int rank, int concatenated);
+int mc33hip_emit_at_device_bases(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long long capV, unsigned long long capT);
+int mc33hip_count_finish(mc33hip_ctx *c, mc33hip_counts *out);
+
 /* mc33hip_emit with the copy to the HOST pipelined behind it (what calculate_isosurface does, reference MC:1869-1879:
  * the surface in the caller's malloc blocks): hT (nT x 3 unsigned) is copied on a stream of the context's own as soon as the
  * passes that write T have been through, hV (nV x 3 MC33_real) and hN (nV x 3 floats) as soon as theirs have - the copies of

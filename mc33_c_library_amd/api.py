@@ -35,7 +35,9 @@ class Timing(C.Structure):
 HIP_API = ["mc33hip_set_id_base", "mc33hip_create", "mc33hip_destroy", "mc33hip_last_error", "mc33hip_upload_rows",
            "mc33hip_upload_contiguous", "mc33hip_adopt_device", "mc33hip_set_stream", "mc33hip_count",
            "mc33hip_emit", "mc33hip_extract", "mc33hip_last_timing", "mc33hip_download",
-           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many", "mc33hip_set_normal_neg", "mc33hip_sweep_many", "mc33hip_set_timing", "mc33hip_probe_read", "mc33hip_prepare_many"]
+           "mc33hip_device_alloc", "mc33hip_device_free", "mc33hip_set_inclined", "mc33hip_download_concurrent", "mc33hip_synchronize", "mc33hip_download_many", "mc33hip_set_normal_neg", "mc33hip_sweep_many", "mc33hip_set_timing", "mc33hip_probe_read", "mc33hip_prepare_many",
+           "mc33hip_emit_download", "mc33hip_download_wait", "mc33hip_own_stream", "mc33hip_device_count", "mc33hip_count_async",
+           "mc33hip_counts_to_device", "mc33hip_bases_from_table", "mc33hip_emit_at_device_bases", "mc33hip_count_finish"]
 REFERENCE_API = ["create_MC33", "calculate_isosurface", "size_of_isosurface", "free_MC33", "free_surface_memory",
                  "adjustvectorlenght_s", "DefaultColorMC", "free_memory_grd", "alloc_F", "grid_from_data_pointer",
                  "generate_grid_from_fn", "_multTSA_bf", "_multA_bf", "mult_Abf",
@@ -93,6 +95,11 @@ def load_library(dtype="f32"):
     lib.mc33hip_set_timing.argtypes = [V, C.c_int]
     lib.mc33hip_prepare_many.argtypes = [V, P(C.c_double), C.c_int, P(Range)]
     lib.mc33hip_probe_read.argtypes = [V, C.c_int, P(C.c_float), P(C.c_float), P(C.c_ulonglong)]
+    lib.mc33hip_count_async.argtypes = [V, C.c_double, P(Range)]
+    lib.mc33hip_counts_to_device.argtypes = [V, V]
+    lib.mc33hip_bases_from_table.argtypes = [V, V, C.c_int, C.c_int, C.c_int]
+    lib.mc33hip_emit_at_device_bases.argtypes = [V, V, V, V, C.c_ulonglong, C.c_ulonglong]
+    lib.mc33hip_count_finish.argtypes = [V, P(Counts)]
     _libs[dtype] = lib
     return lib
 
@@ -201,6 +208,37 @@ class DeviceGrid:
             _check(self.lib, self.lib.mc33hip_set_id_base(self.ctx, id_base))
         _check(self.lib, self.lib.mc33hip_emit(self.ctx, C.c_void_p(V.data_ptr()), C.c_void_p(N.data_ptr()),
                                                C.c_void_p(T.data_ptr()), V.shape[0], T.shape[0]))
+
+    # -- a z-slab's count, count exchange and emit without a host round trip in between (slabs.py: extract_slab) --------------
+    def count_async(self, iso, rng=None):
+        """What count() does, enqueued only: the counters stay on the device until count_finish()."""
+        rng = rng or self.full_range()
+        _check(self.lib, self.lib.mc33hip_count_async(self.ctx, C.c_double(iso), C.byref(rng)))
+
+    def counts_to_device(self, dst):
+        """{vertices, triangles} of the range last counted into dst, an int64 device tensor of 2 elements (stream-ordered)."""
+        import torch
+        assert dst.is_cuda and dst.dtype == torch.int64 and dst.numel() >= 2 and dst.is_contiguous()
+        _check(self.lib, self.lib.mc33hip_counts_to_device(self.ctx, C.c_void_p(dst.data_ptr())))
+
+    def bases_from_table(self, table, stride, rank, concatenated):
+        """table: int64 device tensor, rank r's {vertices, triangles} at table[r * stride]: this rank's vertex id base and output rows."""
+        import torch
+        assert table.is_cuda and table.dtype == torch.int64 and table.is_contiguous() and table.numel() >= (rank + 1) * stride
+        _check(self.lib, self.lib.mc33hip_bases_from_table(self.ctx, C.c_void_p(table.data_ptr()), int(stride), int(rank), int(bool(concatenated))))
+
+    def emit_at_device_bases(self, V, N, T):
+        """emit_into with the id base / output rows that bases_from_table left on the device."""
+        _check(self.lib, self.lib.mc33hip_emit_at_device_bases(self.ctx, C.c_void_p(V.data_ptr()), C.c_void_p(N.data_ptr()),
+                                                              C.c_void_p(T.data_ptr()), V.shape[0], T.shape[0]))
+
+    def count_finish(self):
+        """Waits for what count_async (and the emit behind it) enqueued: (Counts, True), or (Counts, False) when the work
+        records or the output buffers were too small - room for the records has been made, repeat the step with count()."""
+        cnt = Counts()
+        rc = self.lib.mc33hip_count_finish(self.ctx, C.byref(cnt))
+        _check(self.lib, rc, allow=(ECAPACITY,))
+        return cnt, rc == OK
 
     def extract(self, iso, rng=None):
         """Count, allocate exact-size outputs with torch, emit.  Returns (V, N, T, Counts)."""

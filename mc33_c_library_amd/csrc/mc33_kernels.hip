@@ -2049,6 +2049,8 @@ struct EmitArgs {
 	uint64_t capV, capT;
 	uint64_t ghost_segs;  // row segments of the ghost slice (0 without ghost)
 	uint32_t id_base;
+	const unsigned long long *dev_base;  // (or nullptr) {id_base, first output vertex row, first output triangle row} in DEVICE memory: a z-slab whose
+	                                     // place among the ranks came out of a collective and has not been to the host (mc33hip_emit_at_device_bases)
 	const BatchDesc *batches;  // the records in batches of one slice slot (k_cells)
 	uint32_t batch_cap;
 	uint32_t stage_rows;  // every sample row of the grid starts on a 16-byte boundary: k_emit_vertices may stage rows in LDS
@@ -2083,19 +2085,24 @@ struct XcdWalk {
 template <bool TOGETHER = false>
 __device__ __forceinline__ bool emit_prepare(const EmitArgs &a, EmitCtx<sample_t> &c, const Counters &ctr) {
 	const uint64_t gV = a.ghost_segs ? ctr.ghostV : 0, gT = a.ghost_segs ? ctr.ghostT : 0;
+	// where this slab's part begins: from the launch arguments, or - a z-slab whose counts were exchanged on the device - from
+	// three words a one-thread kernel made of the gathered table (wave-uniform: scalar loads, asked for with the counters)
+	uint64_t idb = a.id_base, vo = 0, to = 0;
+	if (a.dev_base) { idb = a.dev_base[0]; vo = a.dev_base[1]; to = a.dev_base[2]; }
 	// TOGETHER: `|`, not `||` - every counter is asked for before the first is looked at; with short circuits the compiler fetches
 	// them one comparison at a time, a scalar round trip each (the triangle pass, whose waves live for one record per lane)
-	const bool over = TOGETHER ? (bool)((ctr.entry_cursor > a.entry_cap) | (ctr.totV - gV > a.capV) | (ctr.totT - gT > a.capT) | (ctr.totV > 0xFFFFFFFFull) |
-	                                    (ctr.totT > 0xFFFFFFFFull) | ((uint64_t)a.id_base + (ctr.totV - gV) > 0xFFFFFFFFull))
-	                           : (ctr.entry_cursor > a.entry_cap || ctr.totV - gV > a.capV || ctr.totT - gT > a.capT || ctr.totV > 0xFFFFFFFFull ||
-	                              ctr.totT > 0xFFFFFFFFull || (uint64_t)a.id_base + (ctr.totV - gV) > 0xFFFFFFFFull);
+	const bool over = TOGETHER ? (bool)((ctr.entry_cursor > a.entry_cap) | (vo + (ctr.totV - gV) > a.capV) | (to + (ctr.totT - gT) > a.capT) | (ctr.totV > 0xFFFFFFFFull) |
+	                                    (ctr.totT > 0xFFFFFFFFull) | (idb + (ctr.totV - gV) > 0xFFFFFFFFull))
+	                           : (ctr.entry_cursor > a.entry_cap || vo + (ctr.totV - gV) > a.capV || to + (ctr.totT - gT) > a.capT || ctr.totV > 0xFFFFFFFFull ||
+	                              ctr.totT > 0xFFFFFFFFull || idb + (ctr.totV - gV) > 0xFFFFFFFFull);
 	if (over) {
 		if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr->emit_skipped = 1;
 		return false;
 	}
 	c.v_skip = (uint32_t)gV;
 	c.t_skip = (uint32_t)gT;
-	c.id_delta = a.id_base - (uint32_t)gV;
+	c.id_delta = (uint32_t)idb - (uint32_t)gV;
+	if (a.dev_base) { c.V += 3ull * vo; c.N += 3ull * vo; c.Tri += 3ull * to; }
 	return true;
 }
 
@@ -2800,6 +2807,23 @@ __global__ __launch_bounds__(256) void k_emit_slow_slots(const EmitArgs a) {
 // ===================================================================================================
 // Host side: context, uploads, launches (C ABI of include/mc33_hip.h)
 // ===================================================================================================
+// ---------------------------------------------------------------------------------------------------
+// Counts and bases of a z-slab that never leave the device (mc33hip_count_async ... mc33hip_emit_at_device_bases):
+// the slab's {vertices, triangles} for a collective to gather, and what the emit passes need from the gathered table.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_publish_counts(const Counters *ctr, uint64_t ghost_segs, long long *dst) {
+	const uint64_t gV = ghost_segs ? ctr->ghostV : 0, gT = ghost_segs ? ctr->ghostT : 0;
+	dst[0] = (long long)(ctr->totV - gV);
+	dst[1] = (long long)(ctr->totT - gT);
+}
+// table[r * stride] / [r * stride + 1]: vertices / triangles of rank r.  out: {id of this rank's first vertex = vertices of the ranks
+// below; the rows at which it writes into the output arrays: the same when the arrays are the concatenated ones, 0 when they are its own}
+__global__ void k_slab_bases(const long long *table, int stride, int rank, int concatenated, unsigned long long *out) {
+	unsigned long long v = 0, t = 0;
+	for (int r = 0; r < rank; r++) { v += (unsigned long long)table[(size_t)r * stride]; t += (unsigned long long)table[(size_t)r * stride + 1]; }
+	out[0] = v; out[1] = concatenated ? v : 0ull; out[2] = concatenated ? t : 0ull;
+}
+
 static thread_local char g_err[512] = "";
 static void set_err(const char *fmt, ...) {
 	va_list ap;
@@ -2918,6 +2942,8 @@ struct mc33hip_ctx {
 	hipStream_t aux, aux2;    // the triangle pass and the slow-record pass run beside the vertex pass
 	hipStream_t copy;         // mc33hip_download_concurrent
 	hipEvent_t ev_fork, ev_join, ev_join2;
+	unsigned long long *d_bases;  // {id base, output vertex row, output triangle row} made on the device (mc33hip_bases_from_table)
+	bool async_count;         // the last count was enqueued without waiting for its counters (mc33hip_count_async)
 	hipEvent_t ev_dl[2];      // mc33hip_emit_download: behind the pass that completes T / behind the one that completes V and N
 	bool emit_pending;        // an emit was enqueued after the last timing read
 	int timing_level;         // MC33_HIP_TIMING: 0 none (default), 1 whole call, 2 per pass - the event records cost ~20 us per call
@@ -3095,6 +3121,7 @@ extern "C" void mc33hip_destroy(mc33hip_ctx *c) {
 	}
 	(void)hipFree(c->d_tiles);
 	(void)hipFree(c->d_bounds);
+	(void)hipFree(c->d_bases);
 	(void)hipFree(c->trace); (void)hipFree(c->trace_cells);
 	if (c->aux) (void)hipStreamSynchronize(c->aux);
 	if (c->aux2) (void)hipStreamSynchronize(c->aux2);
@@ -3896,8 +3923,10 @@ static int enqueue_sweep_many(mc33hip_ctx *c, const double *isos, int n, bool ta
 // the passes that write it have been through, while the remaining passes still run.
 struct DownloadPlan { void *hV, *hN, *hT; size_t bV, bN, bT; };
 
-static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t capV, uint64_t capT, const DownloadPlan *dl = nullptr) {
+static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t capV, uint64_t capT, const DownloadPlan *dl = nullptr,
+                        const unsigned long long *dev_base = nullptr) {
 	EmitArgs a;
+	a.dev_base = dev_base;
 	a.c.tab.lut = c->d_lut; a.c.tab.rule_words = c->d_rules; a.c.tab.rule_index = c->d_rule_index;
 	a.c.P = c->P;
 	a.c.G.p = c->d_grid; a.c.G.pitch = (uint32_t)c->pitch; a.c.G.z0 = c->desc.plane0; a.c.G.slice = c->slice;
@@ -4203,6 +4232,68 @@ extern "C" int mc33hip_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsign
 	int rc = use_device(c);
 	if (rc) return rc;
 	return enqueue_emit(c, dV, dN, dT, capV, capT);
+}
+
+// ---- a z-slab's count, exchange and emit without a host round trip in between (slabs.py: extract_slab) ----
+extern "C" int mc33hip_count_async(mc33hip_ctx *c, double iso, const mc33hip_range *range) {
+	if (!c) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	if ((rc = check_range(c, range))) return rc;
+	c->counted = false;
+	fill_params(c, iso, range);
+	if ((rc = ensure_workspaces(c))) return rc;
+	if ((rc = enqueue_count(c, false))) return rc;
+	memset(&c->counts, 0, sizeof c->counts);  // (not known on the host until mc33hip_count_finish)
+	c->counted = true;
+	c->async_count = true;
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_counts_to_device(mc33hip_ctx *c, long long *device_dst) {
+	if (!c || !c->counted || !device_dst) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(1), 0, c->stream, (const Counters *)c->w->d_ctr, c->ghost_segs, device_dst);
+	HIP_TRY(hipGetLastError());
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_bases_from_table(mc33hip_ctx *c, const long long *device_table, int stride, int rank, int concatenated) {
+	if (!c || !device_table || stride < 2 || rank < 0) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	if (!c->d_bases) HIP_TRY(hipMalloc(&c->d_bases, 3 * sizeof(unsigned long long)));
+	hipLaunchKernelGGL(k_slab_bases, dim3(1), dim3(1), 0, c->stream, device_table, stride, rank, concatenated, c->d_bases);
+	HIP_TRY(hipGetLastError());
+	return MC33HIP_OK;
+}
+
+extern "C" int mc33hip_emit_at_device_bases(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long long capV, unsigned long long capT) {
+	if (!c || !c->counted || !c->d_bases) { set_err("mc33hip_emit_at_device_bases needs a count and mc33hip_bases_from_table first"); return MC33HIP_EINVAL; }
+	if (!dV || !dN || !dT) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	return enqueue_emit(c, dV, dN, dT, capV, capT, nullptr, c->d_bases);  // (capacities are checked on the device: emit_prepare)
+}
+
+extern "C" int mc33hip_count_finish(mc33hip_ctx *c, mc33hip_counts *out) {
+	if (!c || !c->counted) return MC33HIP_EINVAL;
+	int rc = use_device(c);
+	if (rc) return rc;
+	if ((rc = fetch_counters(c))) return rc;
+	c->async_count = false;
+	if (c->w->h_ctr->entry_cursor > c->w->entry_cap) {  // the records did not fit: nothing was emitted; the synchronous path makes room
+		const uint32_t need = c->w->h_ctr->entry_cursor;
+		c->counted = false;
+		if ((rc = grow_entries(*c->w, need))) return rc;
+		set_err("work records did not fit (%u): repeat with mc33hip_count", need);
+		return MC33HIP_ECAPACITY;
+	}
+	read_timing(c, false, 1);
+	if ((rc = finish_counts(c, out))) return rc;
+	if (c->w->h_ctr->emit_skipped) { set_err("output buffers too small: need %llu vertices, %llu triangles", c->counts.nV, c->counts.nT); return MC33HIP_ECAPACITY; }
+	return MC33HIP_OK;
 }
 
 extern "C" int mc33hip_emit_download(mc33hip_ctx *c, void *dV, void *dN, void *dT, unsigned long long capV, unsigned long long capT,

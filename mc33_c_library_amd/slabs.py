@@ -68,6 +68,7 @@ class SurfaceExchange:
             self.N = [torch.empty((capV, 3), dtype=f32, device=device) for _ in range(nbuf)]
             self.T = [torch.empty((capT, 3), dtype=i32, device=device) for _ in range(nbuf)]
         self.counts_dev = torch.zeros(world * 2, dtype=torch.int64, device="cpu" if host_collectives else device)
+        self.mine_dev = torch.zeros(2, dtype=torch.int64, device="cpu" if host_collectives else device)  # this rank's pair, written by a kernel (extract_slab_on_device)
         self.pending = [[] for _ in range(nbuf)]
         self.rows = [(0, 0)] * nbuf
         self.bytes_received = 0
@@ -176,6 +177,18 @@ class SurfaceExchange:
             for w in works:
                 w.wait()
 
+    def start_by_capacity(self, b, async_op=False):
+        """`allgather` exchange of buffer set b with every rank's rows = the CAPACITY of the buffers (the same on every rank):
+        needs no count on the host, moves the few per cent of slack with it (extract_slab_on_device)."""
+        import torch.distributed as dist
+        assert self.mode == "allgather" and not self.host
+        self.rows[b] = (self.capV, self.capT)
+        self.bytes_received = (self.world - 1) * (self.capV * 24 + self.capT * 12)
+        for out, inp in ((self.gV[b], self.V[b]), (self.gN[b], self.N[b]), (self.gT[b], self.T[b])):
+            w = dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1), async_op=async_op)
+            if async_op:
+                self.pending[b].append(w)
+
     # -- the result ----------------------------------------------------------------------------------------
     def concatenated(self, b, counts):
         """(V, N, T) of the whole volume on this rank (every rank; in `root` mode only rank 0 holds them)."""
@@ -188,6 +201,32 @@ class SurfaceExchange:
                       self.gT[b][:self.world * rt].view(self.world, rt, 3))
         return (torch.cat([gv[r, :counts[r][0]] for r in range(self.world)]), torch.cat([gn[r, :counts[r][0]] for r in range(self.world)]),
                 torch.cat([gt[r, :counts[r][1]] for r in range(self.world)]))
+
+
+def extract_slab_on_device(grid, slab, exchange, iso, b=0, async_op=False):
+    """extract_slab with the counts kept on the device between count and emit (`allgather` mode over RCCL): the slab's
+    {vertices, triangles} are written into a device tensor by a kernel behind the count, gathered by all_gather_into_tensor,
+    turned into this rank's vertex id base by a one-thread kernel and read by the emit passes from there; the surface arrays
+    are gathered by capacity (the same on every rank, a few per cent above the counts) instead of by the longest rank's rows.
+    Count, count exchange, emit and surface exchange are ENQUEUED back to back; only then does the host wait - for the gathered
+    table and this rank's counters.  (The host-side flow waits for its counters, runs a collective, reads the result back and
+    only then enqueues the emit: two host round trips and a collective inside every extraction.)
+    Returns (counts of all ranks, this rank's Counts), or None when this rank's work records did not fit - room has been made,
+    the caller repeats the step through extract_slab (every rank sees the same table, but only this rank its own overflow: the
+    caller decides collectively, see bench.py)."""
+    import torch.distributed as dist
+    assert exchange.mode == "allgather" and not exchange.host
+    exchange.wait(b)
+    grid.count_async(iso, slab.range())
+    grid.counts_to_device(exchange.mine_dev)
+    dist.all_gather_into_tensor(exchange.counts_dev, exchange.mine_dev, group=exchange.count_group)
+    grid.bases_from_table(exchange.counts_dev, 2, slab.rank, False)
+    grid.emit_at_device_bases(exchange.V[b], exchange.N[b], exchange.T[b])
+    exchange.start_by_capacity(b, async_op=async_op)
+    table = exchange.counts_dev.view(exchange.world, 2).tolist()   # (the one wait of the step: everything above is enqueued)
+    c, ok = grid.count_finish()
+    counts = [(int(a), int(t)) for a, t in table]
+    return (counts, c) if ok else None
 
 
 def extract_slab(grid, slab, exchange, iso, b=0, async_op=False):
@@ -208,6 +247,12 @@ def extract_slab_many(grid, slab, exchange, isos, b0=0, async_op=False, on_emitt
     isovalues and everything a count needs is made behind each pass (DeviceGrid.prepare_many), the counts of ALL isovalues
     are exchanged in ONE collective, then every isovalue is emitted at its global vertex base and its surface arrays are
     exchanged (buffer sets b0, b0 + 1, ... in turn; on_emitted(i) is called behind each isovalue's emit).  Returns [(counts of all ranks, this rank's Counts)] per isovalue."""
+    if len(isos) > 8:  # the library prepares at most 8 isovalues at a time (two passes over the slab, 4 isovalues each): in groups
+        out = []
+        for k in range(0, len(isos), 8):
+            out += extract_slab_many(grid, slab, exchange, isos[k:k + 8], b0=b0 + k, async_op=async_op,
+                                     on_emitted=(lambda i, k=k: on_emitted(k + i)) if on_emitted is not None else None)
+        return out
     grid.prepare_many(isos, slab.range())
     mine = [grid.count(iso, slab.range()) for iso in isos]           # (made already: these only fetch the counters)
     allc = exchange.exchange_counts_many([(c.nV, c.nT) for c in mine])

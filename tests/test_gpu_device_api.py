@@ -81,6 +81,78 @@ def test_z_slabs_reproduce_whole_volume(case, cuts):
     assert np.array_equal(T0, T1) and beq(V0, V1) and beq(N0, N1)
 
 
+@pytest.mark.parametrize("case", ["cos", "quant", "u16"])
+@pytest.mark.parametrize("concatenated", [False, True])
+def test_count_exchange_on_the_device(case, concatenated):
+    """The slab flow with the counts never on the host between count and emit (mc33hip_count_async / counts_to_device /
+    bases_from_table / emit_at_device_bases - slabs.extract_slab_on_device without the collective): every slab's kernel writes its
+    {vertices, triangles} into ITS row of one device table - what all_gather_into_tensor leaves on every rank - a one-thread kernel
+    makes the slab's id base (and, `concatenated`, its rows in arrays shared by all slabs) of it, the emit passes read that.  Enqueued
+    back to back for all slabs; the host looks only at the end.  Must equal the whole-volume arrays."""
+    import torch
+    from mc33_c_library_amd import DeviceGrid, Range
+    if case == "cos":
+        data, iso = fx.cos_field(48)[0], 0.0
+    elif case == "quant":
+        data, iso = fx.noise_quant(0, 5, shape=(48, 24, 40)), 0.0   # aliases chase across the slab interfaces
+    else:
+        data, iso = fx.noise_u16(0, 2, 7, shape=(48, 20, 30)), 3.0
+    V0, N0, T0, c0 = whole(data, iso)
+    nz_total, cuts = data.shape[0] - 1, (7, 8, 30)
+    bounds = [0] + list(cuts) + [nz_total]
+    world = len(bounds) - 1
+    grids, ranges = [], []
+    for r in range(world):
+        zb, ze = bounds[r], bounds[r + 1]
+        ghost = 1 if zb else 0
+        p_lo, p_hi = max(zb - ghost - 1, 0), min(ze + 1, nz_total)
+        t = torch.from_numpy(np.ascontiguousarray(data[p_lo:p_hi + 1])).cuda()
+        if t.dtype == torch.uint16:
+            t = t.view(torch.int16)
+        grids.append(DeviceGrid(t, nz_total=nz_total, plane0=p_lo))
+        ranges.append(Range(zb, ze, ghost, 0))
+    for attempt in range(2):  # (the first pass sizes every slab's record buffers through the synchronous path, as bench.py's capacity pass does)
+        for g, rg in zip(grids, ranges):
+            g.count(iso, rg)
+    table = torch.zeros(world * 2, dtype=torch.int64, device="cuda")
+    capV, capT = c0.nV + 64, c0.nT + 64
+    if concatenated:
+        V = torch.zeros((capV, 3), dtype=torch.float32, device="cuda"); N = torch.zeros_like(V)
+        T = torch.zeros((capT, 3), dtype=torch.int32, device="cuda")
+        outs = [(V, N, T)] * world
+    else:
+        outs = [(torch.zeros((capV, 3), dtype=torch.float32, device="cuda"), torch.zeros((capV, 3), dtype=torch.float32, device="cuda"),
+                 torch.zeros((capT, 3), dtype=torch.int32, device="cuda")) for _ in range(world)]
+    for r, (g, rg) in enumerate(zip(grids, ranges)):       # every "rank": count, its pair into the table - nothing waited for
+        g.count_async(iso, rg)
+        g.counts_to_device(table[2 * r:2 * r + 2])
+    for r, g in enumerate(grids):                          # (the collective would sit here) bases from the table, emit
+        g.bases_from_table(table, 2, r, concatenated)
+        g.emit_at_device_bases(*outs[r])
+    fin = [g.count_finish() for g in grids]                # only now does the host look
+    assert all(ok for _, ok in fin)
+    counts = [(int(a), int(b)) for a, b in table.view(world, 2).tolist()]
+    assert counts == [(c.nV, c.nT) for c, _ in fin] and sum(c[0] for c in counts) == c0.nV and sum(c[1] for c in counts) == c0.nT
+    if concatenated:
+        V1, N1, T1 = V[:c0.nV].cpu().numpy(), N[:c0.nV].cpu().numpy(), T[:c0.nT].cpu().numpy().view(np.uint32)
+    else:
+        V1 = np.concatenate([o[0][:c[0]].cpu().numpy() for o, c in zip(outs, counts)])
+        N1 = np.concatenate([o[1][:c[0]].cpu().numpy() for o, c in zip(outs, counts)])
+        T1 = np.concatenate([o[2][:c[1]].cpu().numpy().view(np.uint32) for o, c in zip(outs, counts)])
+    assert np.array_equal(T0, T1) and beq(V0, V1) and beq(N0, N1)
+    # output arrays that are too small: nothing is written past them, the step reports it
+    g = grids[1]
+    g.count_async(iso, ranges[1])
+    g.counts_to_device(table[2:4])
+    g.bases_from_table(table, 2, 1, concatenated)
+    small = (torch.zeros((8, 3), dtype=torch.float32, device="cuda"), torch.zeros((8, 3), dtype=torch.float32, device="cuda"), torch.zeros((8, 3), dtype=torch.int32, device="cuda"))
+    g.emit_at_device_bases(*small)
+    c, ok = g.count_finish()
+    assert not ok and c.nV == counts[1][0]
+    for g in grids:
+        g.close()
+
+
 def test_capacity_error_reports_sizes():
     import torch
     from mc33_c_library_amd import DeviceGrid

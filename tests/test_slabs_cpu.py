@@ -21,7 +21,7 @@ WORKER = textwrap.dedent('''
     sys.path.insert(0, %r); sys.path.insert(0, %r)
     import fixtures as fx
     from mc33_emu import Emu
-    from mc33_c_library_amd.slabs import Slab, SurfaceExchange, extract_slab, extract_slab_many, MODES
+    from mc33_c_library_amd.slabs import Slab, SurfaceExchange, extract_slab, extract_slab_many, extract_slab_on_device, MODES
 
     class EmuGrid:
         """DeviceGrid's count / emit_into on the host emulator (tensors on the CPU)"""
@@ -40,6 +40,19 @@ WORKER = textwrap.dedent('''
         def emit_into(self, V, N, T, id_base):
             s = self._run(self.iso, id_base)
             V[:s.nV] = torch.from_numpy(s.V); N[:s.nV] = torch.from_numpy(s.N); T[:s.nT] = torch.from_numpy(s.T.view(np.int32))
+        # the flow with the counts "on the device" (slabs.extract_slab_on_device): the emulator stands in for the kernels, the
+        # tensors live on the CPU and the collective is gloo - what is checked is the orchestration every rank runs over RCCL
+        def count_async(self, iso, rng):
+            self.iso, self.pending = iso, self._run(iso, 0)
+        def counts_to_device(self, dst):
+            dst[0], dst[1] = self.pending.nV, self.pending.nT
+        def bases_from_table(self, table, stride, rank, concatenated):
+            assert stride == 2 and not concatenated
+            self.base = int(table.view(-1, 2)[:rank, 0].sum())
+        def emit_at_device_bases(self, V, N, T):
+            self.emit_into(V, N, T, self.base)
+        def count_finish(self):
+            return self.pending, True
 
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -77,6 +90,20 @@ WORKER = textwrap.dedent('''
         else:
             assert ex.bytes_received == (sum(c[0] * 24 + c[1] * 12 for c in counts[1:]) if rank == 0 else 0)
         dist.barrier()
+    # count, count exchange and emit with no host look at the counts in between; the surfaces gathered by capacity
+    c0 = grid.count(iso, None)
+    caps = torch.tensor([c0.nV + 7, c0.nT + 5])
+    dist.all_reduce(caps, op=dist.ReduceOp.MAX)
+    ex = SurfaceExchange(world, rank, torch.device("cpu"), int(caps[0]), int(caps[1]), mode="allgather", nbuf=2, host_collectives=False)
+    for b in (0, 1, 0):
+        counts, c = extract_slab_on_device(grid, slab, ex, iso, b)
+        assert counts[rank] == (c.nV, c.nT)
+    ex.drain()
+    assert ex.rows[0] == (int(caps[0]), int(caps[1])) and ex.bytes_received == (world - 1) * (int(caps[0]) * 24 + int(caps[1]) * 12)
+    V, N, T = ex.concatenated(0, counts)
+    if rank == 0:
+        assert np.array_equal(T.numpy().view(np.uint32), whole.T) and np.array_equal(V.numpy().view(np.uint32), whole.V.view(np.uint32))
+    dist.barrier()
     # an iso sweep over the slabs: ALL counts in one collective, then the emits (extract_slab_many)
     isos = [0.0, 2.0, -3.5]
     c0 = [grid.count(v, None) for v in isos]
