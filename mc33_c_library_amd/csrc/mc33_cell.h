@@ -1002,6 +1002,71 @@ MC33_HD RootRef chase_root(const EmitCtx<T> &c, GridEdge g, const VRef &w) {
 }
 MC33_HD uint64_t root_key(const RootRef &r) { return r.rec == NO_ID ? ~0ull : (uint64_t)r.rec << 4 | r.rank; }
 
+// The roots of SEVERAL pattern slots of one cell, the first hop of all of them made together (round 5).  A slow record walks up
+// to nine foreign slots; chased one after the other that is nine times directory word -> owner's record (-> its half B) -> ...,
+// some twenty dependent round trips per record, and a kernel of such threads does little but wait.  Where a slot ends at its FIRST
+// owner - the cell that owns the grid edge created the vertex, the usual case next to a smooth surface - one hop settles it, so: the directory words of all wanted slots are asked for together, then the owners'
+// records, then (slow / tested owners only) their halves B; a slot that is not settled by then - an alias: the owner points on -
+// goes through chase_root as before.  Six slots at a time (the words of twelve would not fit the registers of the kernels
+// that call this).  `want`: the slots to resolve (visited, no rank of their own, not the centre); self_s / self_ri: the cell's own
+// row segment and record - addresses that are safe to read for the slots that are not wanted.
+// sink(e, k, root): called once per wanted slot e (the k-th of its group), group by group; sink.group_done(): behind every group of six (a place to ask for
+// what the group's results lead to - the emit pass fetches the six row-segment bases together there).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MC33_UNROLL _Pragma("unroll")
+#else
+#define MC33_UNROLL
+#endif
+template <typename T, typename Sink>
+MC33_HD void roots_together(const EmitCtx<T> &c, const CellPlan &p, uint32_t x, uint32_t y, uint32_t z, uint32_t want, uint64_t self_s,
+                            uint32_t self_ri, const VRef &w, Sink &sink) {
+	MC33_UNROLL
+	for (int g0 = 0; g0 < 12; g0 += 6) {
+		if (!((want >> g0) & 63u)) continue;
+		GridEdge ge[6];
+		OwnerRef ow[6];
+		uint32_t sg[6];
+		DirWord dw[6];
+		bool need[6];
+		MC33_UNROLL
+		for (int k = 0; k < 6; k++) {  // round 1: the directory words
+			const uint32_t e = (uint32_t)(g0 + k);
+			need[k] = ((want >> e) & 1u) != 0u;
+			ge[k] = tgt_edge(plan_tgt(p, e), x, y, z);
+			ow[k] = need[k] ? owner_of(ge[k].axis, ge[k].x, ge[k].y, ge[k].z) : OwnerRef{x, y, z, 0u};
+			sg[k] = need[k] ? (uint32_t)segment_index(c.P, ow[k].x, ow[k].y, ow[k].z) : (uint32_t)self_s;
+			dw[k] = dir_word(c, sg[k], ow[k].x % SEG_CELLS);
+		}
+		uint32_t ri[6];
+		EntryA ea[6];
+		MC33_UNROLL
+		for (int k = 0; k < 6; k++) {  // round 2: the owners' records
+			const uint32_t xl = ow[k].x % SEG_CELLS;
+			const uint64_t m = (uint64_t)dw[k].mhi << 32 | dw[k].mlo;
+			ri[k] = (need[k] && ((m >> (xl & 63u)) & 1ull)) ? record_rank(dw[k], xl) : NO_ID;
+			ea[k] = c.entries_a[ri[k] == NO_ID ? self_ri : ri[k]];
+		}
+		EntryB eb[6];
+		MC33_UNROLL
+		for (int k = 0; k < 6; k++) {  // round 3: half B - from the sign index for a fast owner, stored for a tested or slow one
+			eb[k] = fast_half_b(c, (ea[k].a0 >> 8) & 0xFFu);
+			if (ri[k] != NO_ID && (ea[k].a0 & (ENTRYA_SLOW | ENTRYA_TESTED))) eb[k] = c.entries_b[ri[k]];
+		}
+		MC33_UNROLL
+		for (int k = 0; k < 6; k++) {
+			if (!need[k]) continue;
+			RootRef r = {NO_ID, 15u, 0u, 0u};
+			if (ri[k] != NO_ID) {
+				const uint32_t rk = entry_rank(entry_join(ea[k], eb[k]), ow[k].e);
+				if (rk != 15u) r = RootRef{ri[k], rk, sg[k], ea[k].a1 & 0xFFFFu};
+				else if (ea[k].a0 & ENTRYA_SLOW) r = chase_root(c, ge[k], w);  // the owner points on: the walk, from the start (rare)
+			}
+			sink((uint32_t)(g0 + k), k, r);
+		}
+		sink.group_done();
+	}
+}
+
 // Roots of the slots of one cell, each chased at most once (count pass: a slot is compared with up to 2 x 12 others).
 // p == nullptr: nothing is remembered.
 struct RootMemo {
@@ -1031,8 +1096,26 @@ MC33_HD bool slots_differ_stored(const EmitCtx<T> &c, const CellPlan &p, uint32_
 	return slot_root(c, p, x, y, z, ea, w, memo) != slot_root(c, p, x, y, z, eb, w, memo);
 }
 // number of triangles the cell appends (MC:1235 drops triangles with two equal vertex ids), from the stored plans
+// (self_s, self_ri: the cell's row segment and record, see roots_together; self_ri == NO_ID: every slot chased by itself, as until round 5)
 template <typename T>
-MC33_HD uint32_t count_triangles_stored(const EmitCtx<T> &c, const CellPlan &p, uint32_t x, uint32_t y, uint32_t z, const VRef &w, RootMemo &memo) {
+MC33_HD uint32_t count_triangles_stored(const EmitCtx<T> &c, const CellPlan &p, uint32_t x, uint32_t y, uint32_t z, const VRef &w, RootMemo &memo,
+                                        uint64_t self_s = 0, uint32_t self_ri = NO_ID) {
+	if (p.zmask && memo.p && self_ri != NO_ID && !c.P.negzero_iso) {
+		// the slots whose identity can matter - foreign ones with an end point on a corner that equals the isovalue - resolved
+		// together and put into the memo, so that the pair tests below find them there
+		uint32_t want = 0;
+		for (uint32_t e = 0; e < 12; e++)
+			if ((p.visited & (1u << e)) && plan_rank(p, e) == 15u && (((1u << edge_a(e)) | (1u << edge_b(e))) & p.zmask)) want |= 1u << e;
+		if (want) {
+			struct MemoSink {
+				RootMemo &m;
+				MC33_HD void operator()(uint32_t e, int, const RootRef &r) { m.p[e * m.stride] = root_key(r); }
+				MC33_HD void group_done() {}
+			} sink{memo};
+			roots_together(c, p, x, y, z, want, self_s, self_ri, w, sink);
+			memo.have |= want;
+		}
+	}
 	uint32_t pos = p.poff, word, nt = 0;
 	do {
 		word = c.tab.lut[++pos];
@@ -1063,6 +1146,12 @@ MC33_HD void emit_cell(const EmitCtx<T> &c, uint32_t entry_index, const VRef &v,
 	plan_restore(p, c.tab.lut, en, c.entries_c[entry_index]);
 	plan_restore_points(p, v);
 	// ids of all slots of the pattern; NEW vertices are written on the way
+	// (Round 5: the foreign slots resolved together first - roots_together, then the bases of their row segments together.
+	// Bit-identical and slower: k_emit_slow 0.97 -> 1.39 ms on the 2 M slow records of a 1024^3 uchar field with an integer
+	// isovalue - 142 registers instead of 88, three waves per SIMD instead of five, and on such a field most owners are slow
+	// cells themselves that point on, so the first hop made for all slots at once is made again by the walk.  The count pass,
+	// which resolves only the slots at a corner equal to the isovalue, keeps the batched form: the tail of that field 1.32 -> 1.23 ms,
+	// profiles/r05_integer_iso.txt.)
 	for (uint32_t e = 0; e < 13; e++) {
 		if (!(p.visited & (1u << e))) continue;
 		const uint32_t r = plan_rank(p, e);

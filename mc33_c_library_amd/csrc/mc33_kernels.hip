@@ -1799,7 +1799,7 @@ __device__ __forceinline__ void slow_count_body(const SlowArgs &a, real_t (*s_w)
 		plan_restore(pl, a.tab.lut, en, a.entries_c[ei]);
 		const SegCoord sc = segment_coord(a.P, a.entry_seg[ei]);
 		RootMemo memo{&s_key[0][threadIdx.x], 256, 0u};
-		const uint32_t nt = count_triangles_stored(c, pl, sc.xbase + (ea.a0 & 0xFFu), sc.y, sc.z, w, memo);
+		const uint32_t nt = count_triangles_stored(c, pl, sc.xbase + (ea.a0 & 0xFFu), sc.y, sc.z, w, memo, (uint64_t)a.entry_seg[ei], ei);
 		a.entries_a[ei].a0 = (ea.a0 & ~(15u << 20) & ~ENTRYA_COUNT) | nt << 20;
 	}
 }
@@ -1845,7 +1845,7 @@ __device__ __forceinline__ void seg_fix_body(const SlowArgs &a, real_t (*s_w)[25
 				plan_restore(pl, a.tab.lut, en, a.entries_c[first + k]);
 				const SegCoord sc = segment_coord(a.P, s);
 				RootMemo memo{&s_key[0][threadIdx.x], 256, 0u};
-				const uint32_t ntri = count_triangles_stored(c, pl, sc.xbase + (ea.a0 & 0xFFu), sc.y, sc.z, w, memo);
+				const uint32_t ntri = count_triangles_stored(c, pl, sc.xbase + (ea.a0 & 0xFFu), sc.y, sc.z, w, memo, (uint64_t)s, first + k);
 				ea.a0 = (ea.a0 & ~(15u << 20) & ~ENTRYA_COUNT) | ntri << 20;
 				e->a0 = ea.a0;
 			}

@@ -144,7 +144,7 @@ static int run(const T *data, uint32_t npx, uint32_t npy, uint32_t npz, const do
 		const SegCoord sc = segment_coord(P, entry_seg[k]);
 		const uint32_t x = sc.xbase + (ea[k].a0 & 0xFFu);
 		RootMemo memo{keys, 1, 0u};
-		const uint32_t nt = count_triangles_stored(c, p, x, sc.y, sc.z, w, memo);
+		const uint32_t nt = count_triangles_stored(c, p, x, sc.y, sc.z, w, memo, (uint64_t)entry_seg[k], (uint32_t)k);  // (the slots resolved together: roots_together)
 		if (nt != count_triangles(p, tab, P, G, x, sc.y, sc.z, w)) return -11;
 		ea[k].a0 = (ea[k].a0 & ~(15u << 20) & ~ENTRYA_COUNT) | nt << 20;
 	}
