@@ -62,7 +62,9 @@ def _run(cmd):
 
 
 C_SOURCES = ["mc33_capi.c", "mc33_surface_io.c", "mc33_grid_io.c"]   # host side of the C API (gcc)
-HIP_HEADERS = ["mc33_cell.h", "mc33_lut_data.h", "mc33_rules_data.h"]
+HIP_HEADERS = ["mc33_cell.h", "mc33_lut_data.h", "mc33_rules_data.h",
+               # the parts of the one HIP translation unit (mc33_kernels.hip includes them in this order)
+               "mc33_records.hip.h", "mc33_sweep.hip.h", "mc33_tail.hip.h", "mc33_emit.hip.h", "mc33_context.hip.h", "mc33_extract.hip.h"]
 
 
 def build(dtype, force=False, verbose_resources=False):
