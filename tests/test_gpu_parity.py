@@ -397,6 +397,21 @@ def test_capi_multi_device_rehearsal(products, reflibs, devices, monkeypatch):
         del keep
 
 
+def test_capi_device_lists(products, reflibs, monkeypatch):
+    """MC33_HIP_DEVICES: `all` = every visible device; a list that names a device this machine does not have, or is not a list,
+    makes create_MC33 fail (NULL) instead of quietly running somewhere else."""
+    data, r0, d = fx.cos_field(70)
+    want = reflibs["f32"].isosurface(data, 0.0, r0, d)
+    monkeypatch.setenv("MC33_HIP_DEVICES", "all")
+    assert_surface_parity(products["f32"].isosurface(data, 0.0, r0, d), want, 8.0, "devices all", bit_exact=True)
+    for bad in ("0,99", "1x", "-1", "0;0"):
+        monkeypatch.setenv("MC33_HIP_DEVICES", bad)
+        with pytest.raises(MemoryError):
+            products["f32"].isosurface(data, 0.0, r0, d)
+    monkeypatch.setenv("MC33_HIP_DEVICES", " 0, 0 ")
+    assert_surface_parity(products["f32"].isosurface(data, 0.0, r0, d), want, 8.0, "devices with blanks", bit_exact=True)
+
+
 def test_config2_cos1024_full_size(products, reflibs, monkeypatch):
     """BASELINE.json configs[2] at full size through the reference C API: 1024^3 float grid (4 GiB upload),
     iso 0 - counts as published in SURVEY.md section 6, triangles identical to the reference run on this host,
@@ -609,8 +624,10 @@ def test_normal_neg_flavour(reflibs, dtype, ortho):
         assert np.array_equal(got.N[fin], -plain.N[fin])
 
 
-def test_grid_changed_uploads_the_samples_again(reflibs):
-    """The reference reads G->F on every call (marching_cubes_33.c:1792, 1832-1868); the product keeps a copy in HBM.
+@pytest.mark.parametrize("devices", [None, "0,0,0"])
+def test_grid_changed_uploads_the_samples_again(reflibs, devices, monkeypatch):
+    """(devices: also with the grid cut into z-slabs behind the C API, MC33_HIP_DEVICES - every slab uploads its planes again.)
+    The reference reads G->F on every call (marching_cubes_33.c:1792, 1832-1868); the product keeps a copy in HBM.
     MC33_grid_changed(M) (extension) is how a caller says it rewrote samples: the next extraction and the next
     size_of_isosurface see the new ones; without the call the resident copy is used (documented difference)."""
     import ctypes as C
@@ -619,6 +636,8 @@ def test_grid_changed_uploads_the_samples_again(reflibs):
     L = lib.lib
     L.MC33_grid_changed.restype = None
     L.MC33_grid_changed.argtypes = [C.POINTER(lib.MC33)]
+    if devices:
+        monkeypatch.setenv("MC33_HIP_DEVICES", devices)
     a = fx.cos_field(48)[0].copy()
     b = fx.noise_f32(48, 7)
     G, keep = lib.make_grid(a)
@@ -673,11 +692,15 @@ def test_epoch_stamps_wrap_around(reflibs):
         g.close()
 
 
-def test_batched_isovalues_equal_single_calls(products, reflibs):
+@pytest.mark.parametrize("devices", [None, "0,0,0,0"])
+def test_batched_isovalues_equal_single_calls(products, reflibs, devices, monkeypatch):
     """calculate_isosurfaces (extension): out[k] must be exactly what calculate_isosurface(M, iso[k]) returns -
-    growing and shrinking results (both staging sets are regrown), an empty one in the middle, n = 1 and n = 0."""
+    growing and shrinking results (both staging sets are regrown), an empty one in the middle, n = 1 and n = 0.
+    (devices: the same over z-slabs behind the C API - there the surfaces are made one after the other.)"""
     import ctypes as C
     from mc33_capi import SURFACE
+    if devices:
+        monkeypatch.setenv("MC33_HIP_DEVICES", devices)
     lib = products["f32"]
     L = lib.lib
     L.calculate_isosurfaces.restype = C.c_uint
