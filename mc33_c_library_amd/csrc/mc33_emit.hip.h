@@ -153,12 +153,13 @@ constexpr uint32_t EV_EMPTY = 0xFFFFFFFFu;
 #ifndef MC33_EV_RING
 #define MC33_EV_RING 0
 #endif
+constexpr uint32_t TS = MC33_EV_RING ? 1u : 0u;  // (the ring's tags exist only with the ring: every index into them goes through this)
 struct EmitVLds {                        // per wave
 	uint32_t rowA[64], rowB[64];         // cell rows 0..62 of the tile: first / last record of the batch in that row, lane << 8 | x in the segment
 	uint32_t rowvb[64];                  // cell rows: id of the first vertex of the row segment (seg_base)
 	uint32_t rowinfo[EV_ROWS + 1];       // sample rows: staged << 31 | chunks - 1 << 16 | first chunk - chunk of the segment's first sample
 	uint32_t vlist[256];                 // vertices of the batch: record (lane) | kind << 8, by kind
-	uint32_t tag[3][EV_ROWS + 1];        // what slot s holds of sample row r: valid << 31 | chunks - 1 << 16 | first chunk (as rowinfo)
+	uint32_t tag[MC33_EV_RING ? 3 : 1][MC33_EV_RING ? EV_ROWS + 1 : 1];  // (ring only) what slot s holds of sample row r: valid << 31 | chunks - 1 << 16 | first chunk (as rowinfo)
 	uint4 data[3 * EV_ROWS * EV_W];      // [slot][row][chunk]
 };
 
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 				for (uint32_t g = 0; g < NGRP; g++) {
 					const uint32_t rr = min((g * 64u + lane) / EV_W, EV_ROWS - 1u);
 					info[g] = L.rowinfo[rr];
-					if (MC33_EV_RING) { have0[g] = L.tag[s0][rr]; have1[g] = L.tag[s1][rr]; have2[g] = L.tag[s2][rr]; }
+					if (MC33_EV_RING) { have0[g] = L.tag[(s0) * TS][(rr) * TS]; have1[g] = L.tag[(s1) * TS][(rr) * TS]; have2[g] = L.tag[(s2) * TS][(rr) * TS]; }
 				}
 				// does the window a slot holds of a row (tag) cover the one the batch needs (rowinfo)?
 				auto covers = [](uint32_t have, uint32_t want) -> bool {
@@ -435,9 +436,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 				auto put = [&](uint32_t g, uint32_t got, const uint4 &q0, const uint4 &q1, const uint4 &q2) {
 					const uint32_t it = g * 64u + lane;
 					const uint32_t r = it / EV_W, ck = it - r * EV_W;
-					if (got & 1u) { L.data[s0 * NITEM + it] = q0; if (MC33_EV_RING && ck == 0u) L.tag[s0][r] = info[g]; }
-					if (got & 2u) { L.data[s1 * NITEM + it] = q1; if (MC33_EV_RING && ck == 0u) L.tag[s1][r] = info[g]; }
-					if (got & 4u) { L.data[s2 * NITEM + it] = q2; if (MC33_EV_RING && ck == 0u) L.tag[s2][r] = info[g]; }
+					if (got & 1u) { L.data[s0 * NITEM + it] = q0; if (MC33_EV_RING && ck == 0u) L.tag[(s0) * TS][(r) * TS] = info[g]; }
+					if (got & 2u) { L.data[s1 * NITEM + it] = q1; if (MC33_EV_RING && ck == 0u) L.tag[(s1) * TS][(r) * TS] = info[g]; }
+					if (got & 4u) { L.data[s2 * NITEM + it] = q2; if (MC33_EV_RING && ck == 0u) L.tag[(s2) * TS][(r) * TS] = info[g]; }
 				};
 				const uint32_t na = fetch(0u, qa0, qa1, qa2), nb = fetch(1u, qb0, qb1, qb2), nc = fetch(2u, qc0, qc1, qc2);
 				const uint32_t nd = NGRP > 3 ? fetch(3u, qd0, qd1, qd2) : 0u, ne = NGRP > 4 ? fetch(4u, qe0, qe1, qe2) : 0u;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC33_EV_WAV
 						const uint32_t zs0 = z % 3u, zs1 = zs0 == 2u ? 0u : zs0 + 1u, zs2 = zs1 == 2u ? 0u : zs1 + 1u;
 						const uint32_t vr2 = vyin ? vrho + 2u : vrho;
 						auto rowbyte = [&](uint32_t sl, uint32_t rw) -> uint32_t {  // byte of the cell's sample x in slot sl, row rw
-							return sl * (EV_ROWS * EV_W * 16u) + (rw * EV_W - (L.tag[sl][rw] & 0xFFFFu)) * 16u + xb0;
+							return sl * (EV_ROWS * EV_W * 16u) + (rw * EV_W - (L.tag[(sl) * TS][(rw) * TS] & 0xFFFFu)) * 16u + xb0;
 						};
 						// (nine named values and selects: an array indexed by dy / dz - some are per-lane values - lived in scratch memory)
 						const uint32_t b00 = rowbyte(zs0, vrho), b01 = rowbyte(zs0, vrho + 1u), b02 = rowbyte(zs0, vr2);

@@ -24,6 +24,14 @@ TYPES = ("f32", "u16", "u8", "u32", "f64")
 ALLOW_SCRATCH = {}
 # registers per lane a kernel may use at most, where the occupancy it was tuned for depends on it
 MAX_VGPRS = {"k_sweep<1, 1, 0>": 128, "k_cells": 128, "k_emit_fast_triangles": 64}
+# SGPRs the compiler parks in VGPR lanes (v_writelane / v_readlane): ceilings by demangled-name prefix, the longest matching prefix
+# counts.  The kernels whose inner loops run per record or per sample row have none or a handful; the sweeps over several
+# isovalues keep four sets of buffer pointers and masks and do spill - outside their row loop (that loop is 16
+# compares + 16 moves per sample row and nothing else) - and are held to what they have today, so that a change that pushes lane
+# moves INTO a loop shows up as a number here.
+MAX_SGPR_SPILLS = {"k_sweep<": 1300, "k_sweep<1, 1,": 32, "k_sweep<2, 1,": 32, "k_sweep<4, 1,": 32, "k_sweep<2, 4, 2>": 320, "k_sweep<4, 4, 2>": 320,
+                   "k_cells": 0, "k_slots": 0, "k_boundary": 0, "k_scan_reduce": 0, "k_scan_apply": 0, "k_emit_fast_triangles": 0,
+                   "k_emit_vertices<": 64, "k_emit_vertices<0>": 8, "k_emit_vertices<1>": 8, "k_emit_vertices<2>": 8}
 
 
 def _tool(name):
@@ -82,6 +90,9 @@ def test_no_kernel_has_a_scratch_segment(dtype):
         cap = MAX_VGPRS.get(k["pretty"])
         if cap is not None and k["vgpr_count"] > cap:
             bad.append("%s: %d VGPRs, tuned for at most %d" % (k["pretty"], k["vgpr_count"], cap))
+        pre = [p for p in MAX_SGPR_SPILLS if k["pretty"].startswith(p)]
+        if pre and k.get("sgpr_spill_count", 0) > MAX_SGPR_SPILLS[max(pre, key=len)]:
+            bad.append("%s: %d SGPRs spilled into VGPR lanes, ceiling %d" % (k["pretty"], k["sgpr_spill_count"], MAX_SGPR_SPILLS[max(pre, key=len)]))
     assert not bad, "libMC33_%s.so:\n  " % dtype + "\n  ".join(bad)
 
 
