@@ -22,6 +22,30 @@ def build_emu(force=False):
     return EMU_SO
 
 
+def build_hostlogic(dtype="f32", force=False):
+    """tests/host_emu/libMC33_hostlogic_<type>.so: the REAL host layer of the reference's API (csrc/mc33_capi.c, compiled as it
+    ships) on top of a fake device layer served by the emulator (fake_hip.cpp) - the host logic without a GPU.  Test
+    infrastructure: nothing of the product links or loads it."""
+    assert dtype in ("f32", "u16")
+    # MC33_HOSTLOGIC_SANITIZE=1 (developer): the same with -fsanitize=address,undefined; run the tests under
+    # LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0
+    san = os.environ.get("MC33_HOSTLOGIC_SANITIZE", "0") == "1"
+    out = os.path.join(EMU_DIR, "libMC33_hostlogic_%s%s.so" % (dtype, "_san" if san else ""))
+    csrc = os.path.join(ROOT, "mc33_c_library_amd", "csrc")
+    srcs = [os.path.join(EMU_DIR, "emu.cpp"), os.path.join(EMU_DIR, "fake_hip.cpp")]
+    capi = os.path.join(csrc, "mc33_capi.c")
+    deps = srcs + [capi] + [os.path.join(csrc, f) for f in ("mc33_cell.h", "mc33_lut_data.h", "mc33_rules_data.h")] + \
+        [os.path.join(ROOT, "include", f) for f in ("mc33_hip.h", "marching_cubes_33.h")]
+    if force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        obj = os.path.join(EMU_DIR, "mc33_capi_hostlogic_%s%s.o" % (dtype, "_san" if san else ""))
+        cdef = ["-DINTEGER_GRD", "-DGRD_TYPE_SIZE=2"] if dtype == "u16" else []
+        sflags = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"] if san else []
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-std=c11", "-fPIC", "-Wall", "-Wextra"] + sflags + cdef + ["-c", capi, "-o", obj])
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"] + sflags + (["-DFAKE_U16"] if dtype == "u16" else []) +
+                              srcs + [obj, "-o", out, "-lpthread"])
+    return out
+
+
 class SLAB(C.Structure):
     _fields_ = [("z_begin", C.c_uint32), ("z_end", C.c_uint32), ("ghost", C.c_uint32), ("id_base", C.c_uint32),
                 ("plane_lo", C.c_uint32), ("plane_hi", C.c_uint32)]
