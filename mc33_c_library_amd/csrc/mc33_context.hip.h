@@ -356,27 +356,60 @@ static int ensure_grid(mc33hip_ctx *c) {
 	return 0;
 }
 
-// Rows packed into the pitched device layout through a pinned staging buffer, one group of planes at a time.
-// row(k, j): host address of row j of resident plane k.
+// Rows packed into the pitched device layout through pinned staging buffers, one group of planes at a time.  row(k, j): host
+// address of row j of resident plane k.  What it costs is the packing - a memcpy per row, a million scattered 4 KiB rows for a
+// 1024^3 float grid made by alloc_F (every row an allocation of its own: what generate_grid_from_fn and the reference's file
+// readers make, MC33_util_grd.c:147-169): 240 ms on one core, whether or not the copies over the link (77 ms) run beside it - so
+// large grids are packed by up to four threads, each with two buffers of its own in turn (a group is packed while the thread's
+// group before it goes over the link) and every fourth group of planes: profiles/r05_upload_rows.txt.
 template <typename RowFn>
 static int upload_staged(mc33hip_ctx *c, RowFn row) {
 	const uint32_t npy = c->desc.npy, npz = c->desc.npz_resident;
 	const size_t rowb = (size_t)c->desc.npx * sizeof(sample_t);
 	const size_t planeb = c->slice * sizeof(sample_t);
-	size_t planes_per = (64u << 20) / planeb;
+	size_t planes_per = (16u << 20) / planeb;
 	if (planes_per < 1) planes_per = 1;
 	if (planes_per > npz) planes_per = npz;
-	char *stage = nullptr;
-	HIP_TRY(hipHostMalloc(&stage, planes_per * planeb, hipHostMallocDefault));
-	for (uint32_t k0 = 0; k0 < npz; k0 += (uint32_t)planes_per) {
-		const uint32_t kn = (uint32_t)((k0 + planes_per <= npz) ? planes_per : npz - k0);
-		for (uint32_t k = 0; k < kn; k++)
-			for (uint32_t j = 0; j < npy; j++)
-				memcpy(stage + k * planeb + (size_t)j * c->pitch * sizeof(sample_t), row(k0 + k, j), rowb);
-		hipError_t e = hipMemcpy((char *)c->d_grid + (size_t)k0 * planeb, stage, (size_t)kn * planeb, hipMemcpyHostToDevice);
-		if (e != hipSuccess) { (void)hipHostFree(stage); set_err("grid upload failed: %s", hipGetErrorString(e)); return MC33HIP_ERUNTIME; }
-	}
-	(void)hipHostFree(stage);
+	const uint32_t ngroups = (uint32_t)((npz + planes_per - 1) / planes_per);
+	const unsigned hw = std::thread::hardware_concurrency();
+	const unsigned nthreads = (uint64_t)planeb * npz < (256ull << 20) ? 1u : std::min(std::min(4u, std::max(1u, hw / 2u)), ngroups);
+	HIP_TRY(hipStreamSynchronize(c->stream));  // (nothing enqueued earlier may still be reading the grid: the copies run on a stream of their own)
+	std::vector<hipError_t> err(nthreads, hipSuccess);
+	auto worker = [&](unsigned t) {
+		hipError_t e = hipSetDevice(c->device);
+		char *stage[2] = {nullptr, nullptr};
+		hipEvent_t done[2] = {nullptr, nullptr};
+		const bool two = ngroups > nthreads;  // (a thread with one group needs one buffer)
+		if (e == hipSuccess) e = hipHostMalloc(&stage[0], planes_per * planeb, hipHostMallocDefault);
+		if (e == hipSuccess && two) e = hipHostMalloc(&stage[1], planes_per * planeb, hipHostMallocDefault);
+		for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
+		uint32_t turn = 0;
+		for (uint32_t g = t; g < ngroups && e == hipSuccess; g += nthreads, turn++) {
+			const uint32_t b = two ? (turn & 1u) : 0u, k0 = g * (uint32_t)planes_per;
+			const uint32_t kn = (uint32_t)((k0 + planes_per <= npz) ? planes_per : npz - k0);
+			if (turn >= (two ? 2u : 1u) && (e = hipEventSynchronize(done[b])) != hipSuccess) break;  // (the buffer's last copy has left it)
+			for (uint32_t k = 0; k < kn; k++)
+				for (uint32_t j = 0; j < npy; j++)
+					memcpy(stage[b] + k * planeb + (size_t)j * c->pitch * sizeof(sample_t), row(k0 + k, j), rowb);
+			if ((e = hipMemcpyAsync((char *)c->d_grid + (size_t)k0 * planeb, stage[b], (size_t)kn * planeb, hipMemcpyHostToDevice, c->copy)) == hipSuccess)
+				e = hipEventRecord(done[b], c->copy);
+		}
+		for (int b = 0; b < 2; b++) {  // (its own copies done before its buffers go)
+			if (done[b]) { if (e == hipSuccess && turn > (uint32_t)b) e = hipEventSynchronize(done[b]); (void)hipEventDestroy(done[b]); }
+		}
+		if (e != hipSuccess) (void)hipStreamSynchronize(c->copy);
+		for (int b = 0; b < 2; b++)
+			if (stage[b]) (void)hipHostFree(stage[b]);
+		err[t] = e;
+	};
+	std::vector<std::thread> th;
+	for (unsigned t = 1; t < nthreads; t++) th.emplace_back(worker, t);
+	worker(0u);
+	for (auto &x : th) x.join();
+	(void)hipSetDevice(c->device);
+	HIP_TRY(hipStreamSynchronize(c->copy));
+	for (unsigned t = 0; t < nthreads; t++)
+		if (err[t] != hipSuccess) { set_err("grid upload failed: %s", hipGetErrorString(err[t])); return err[t] == hipErrorOutOfMemory ? MC33HIP_ENOMEM : MC33HIP_ERUNTIME; }
 	return MC33HIP_OK;
 }
 

@@ -45,6 +45,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
