@@ -480,6 +480,14 @@ static void live_add(void *p, size_t cap) {
 		}
 }
 
+/* Fresh large blocks - pages the process has never touched - are populated by several threads at once before the copies from the
+ * GPU are started (populate_fresh).  The reference's own viewers KEEP every surface they make (GLUT_example/TestMC33_glut.c:421-458
+ * appends to a list), so for them every call lands in fresh pages: populated by the copy itself, one fault after the other, a
+ * 1024^3 surface costs 8 ms of page faults; profiles/r05_capi_walls.txt. */
+struct fresh_block { char *p; size_t n; };
+static __thread struct fresh_block t_fresh[4];
+static __thread int t_nfresh;
+
 /* a block of at least `bytes` bytes; *cap = what it can really hold */
 static void *surface_block(size_t bytes, size_t *cap) {
 	void *p = 0;
@@ -503,6 +511,7 @@ static void *surface_block(size_t bytes, size_t *cap) {
 		if (posix_memalign(&p, HUGE_PAGE, rounded) == 0) {
 			(void)madvise(p, rounded, MADV_HUGEPAGE);
 			*cap = rounded;
+			if (t_nfresh < 4) { t_fresh[t_nfresh].p = (char *)p; t_fresh[t_nfresh].n = bytes; t_nfresh++; }
 			pthread_mutex_lock(&g_cache_lock);
 			live_add(p, rounded);
 			pthread_mutex_unlock(&g_cache_lock);
@@ -562,10 +571,41 @@ static void surface_blocks_release(void **blk, int n) {
 static void surface_block_release(void *p) { surface_blocks_release(&p, 1); }
 
 /* the four arrays of a surface with nV vertices and nT triangles (caller-owned malloc blocks, MC:84-92); 0 when memory is short */
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23 /* Linux 5.14 */
+#endif
+static void *populate_thread(void *arg) {
+	struct fresh_block *b = (struct fresh_block *)arg;
+	if (madvise(b->p, b->n, MADV_POPULATE_WRITE) != 0) /* (older kernels: touch every page - nothing has been written into the block yet) */
+		for (size_t off = 0; off < b->n; off += 4096) ((volatile char *)b->p)[off] = 0;
+	return 0;
+}
+/* the fresh blocks surface_alloc has just made (this thread's list), in pieces of at most 32 MB, a thread per piece (16 at most) */
+static void populate_fresh(void) {
+	struct fresh_block piece[16];
+	pthread_t th[16];
+	int n = 0;
+	for (int k = 0; k != t_nfresh; k++)
+		for (size_t off = 0; off < t_fresh[k].n && n != 16; off += (size_t)32 << 20) {
+			piece[n].p = t_fresh[k].p + off;
+			piece[n].n = t_fresh[k].n - off < ((size_t)32 << 20) ? t_fresh[k].n - off : (size_t)32 << 20;
+			n++;
+		}
+	t_nfresh = 0;
+	int started[16];
+	for (int k = 1; k < n; k++) started[k] = pthread_create(&th[k], 0, populate_thread, &piece[k]) == 0;
+	if (n) populate_thread(&piece[0]);
+	for (int k = 1; k < n; k++) {
+		if (started[k]) pthread_join(th[k], 0);
+		else populate_thread(&piece[k]);
+	}
+}
+
 static surface *surface_alloc(size_t nV, size_t nT, MC33_real iso) {
 	surface *S = (surface *)malloc(sizeof(surface));
 	if (!S)
 		return 0;
+	t_nfresh = 0;
 	memset(S, 0, sizeof(surface)); /* (an empty surface is exactly this, MC:1880-1883) */
 	if (!nV)
 		return S;
@@ -573,8 +613,11 @@ static surface *surface_alloc(size_t nV, size_t nT, MC33_real iso) {
 	S->V = (MC33_real(*)[3])surface_block(nV * 3 * sizeof(MC33_real), &capV);
 	S->N = (float(*)[3])surface_block(nV * 3 * sizeof(float), &capN);
 	S->T = (unsigned int(*)[3])surface_block((nT ? nT : 1) * 3 * sizeof(int), &capT);
+	const int fresh_vnt = t_nfresh; /* (the colour block is populated by whoever fills it) */
 	S->color = (int *)surface_block(nV * sizeof(int), &capC);
+	t_nfresh = fresh_vnt;
 	if (!S->V || !S->N || !S->T || !S->color) {
+		t_nfresh = 0;
 		free_surface_memory(S);
 		return 0;
 	}
@@ -606,6 +649,7 @@ static surface *surface_from_staging(mc33_private *p, const struct staging *g, c
 	surface *S = surface_alloc((size_t)cnt->nV, (size_t)cnt->nT, iso);
 	if (!S || !S->nV)
 		return S;
+	populate_fresh();
 	void *const dst[3] = {S->V, S->N, S->T};
 	const void *const src[3] = {g->dV, g->dN, g->dT};
 	const size_t bytes[3] = {(size_t)S->nV * 3 * sizeof(MC33_real), (size_t)S->nV * 12, (size_t)S->nT * 12};
@@ -670,6 +714,7 @@ surface *calculate_isosurface(MC33 *M, MC33_real iso) {
 		}
 		pthread_t ct;
 		const int helper = S->nV >= 65536u && pthread_create(&ct, 0, fill_color_thread, S) == 0; /* 16 MB at 1024^3: 0.8 ms beside 3.4 ms of copies */
+		populate_fresh(); /* (blocks that did not come from the cache: their pages, before the copies need them) */
 		if (trace) t[3] = now_ms();
 		for_each_slab(p, slab_emit);
 		if (trace) t[4] = now_ms();
@@ -680,7 +725,7 @@ surface *calculate_isosurface(MC33 *M, MC33_real iso) {
 				ok = 0;
 		if (trace) {
 			t[5] = now_ms();
-			fprintf(stderr, "[mc33 capi] count %.3f  blocks %.3f  helper %.3f  emit + copies %.3f  colours joined %.3f  total %.3f ms\n", t[1] - t[0], t[2] - t[1],
+			fprintf(stderr, "[mc33 capi] count %.3f  blocks %.3f  helper + fresh pages %.3f  emit + copies %.3f  colours joined %.3f  total %.3f ms\n", t[1] - t[0], t[2] - t[1],
 			        t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
 		}
 		if (!ok) {
