@@ -403,8 +403,12 @@ static int upload_staged(mc33hip_ctx *c, RowFn row) {
 		err[t] = e;
 	};
 	std::vector<std::thread> th;
-	for (unsigned t = 1; t < nthreads; t++) th.emplace_back(worker, t);
+	std::vector<unsigned> inline_share;  // (a thread that could not be started: its groups on this thread)
+	for (unsigned t = 1; t < nthreads; t++) {
+		try { th.emplace_back(worker, t); } catch (...) { inline_share.push_back(t); }
+	}
 	worker(0u);
+	for (unsigned t : inline_share) worker(t);
 	for (auto &x : th) x.join();
 	(void)hipSetDevice(c->device);
 	HIP_TRY(hipStreamSynchronize(c->copy));
