@@ -93,7 +93,11 @@ int mc33hip_own_stream(mc33hip_ctx *c);
 int mc33hip_device_count(void);
 
 /* Count pass only: classification + prefix sums; the device twin of size_of_isosurface (MC:1892-1940).
- * Synchronises the stream. */
+ * Synchronises the stream.
+ * Over the library's own copy of the grid (mc33hip_upload*), a count that has not served an emit yet is reused by the next
+ * mc33hip_count of the same isovalue and range: size_of_isosurface followed by calculate_isosurface of that value streams the
+ * volume once.  Used once only - an extraction repeated with the same isovalue does all of its work again - and never with a
+ * buffer of the caller's (mc33hip_adopt_device), whose samples may change without this library knowing. */
 int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *range, mc33hip_counts *out);
 
 /* Iso sweep over the resident grid (BASELINE.json configs[4]; the caller of calculate_isosurfaces): classifies the

@@ -121,6 +121,7 @@ struct mc33hip_ctx {
 	hipEvent_t ev_fork, ev_join, ev_join2;
 	unsigned long long *d_bases;  // {id base, output vertex row, output triangle row} made on the device (mc33hip_bases_from_table)
 	bool async_count;         // the last count was enqueued without waiting for its counters (mc33hip_count_async)
+	bool count_unused;        // the last mc33hip_count has not served an emit yet: a count of the same isovalue and range may reuse it
 	hipEvent_t ev_dl[2];      // mc33hip_emit_download: behind the pass that completes T / behind the one that completes V and N
 	bool emit_pending;        // an emit was enqueued after the last timing read
 	int timing_level;         // MC33_HIP_TIMING: 0 none (default), 1 whole call, 2 per pass - the event records cost ~20 us per call

@@ -669,6 +669,7 @@ static int enqueue_emit(mc33hip_ctx *c, void *dV, void *dN, void *dT, uint64_t c
                         const unsigned long long *dev_base = nullptr) {
 	EmitArgs a;
 	a.dev_base = dev_base;
+	c->count_unused = false;  // (the count has served an emit: the next count of this isovalue is made anew)
 	a.c.tab.lut = c->d_lut; a.c.tab.rule_words = c->d_rules; a.c.tab.rule_index = c->d_rule_index;
 	a.c.P = c->P;
 	a.c.G.p = c->d_grid; a.c.G.pitch = (uint32_t)c->pitch; a.c.G.z0 = c->desc.plane0; a.c.G.slice = c->slice;
@@ -899,6 +900,16 @@ extern "C" int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *ra
 	int rc = use_device(c);
 	if (rc) return rc;
 	if ((rc = check_range(c, range))) return rc;
+	// The same isovalue over the same range of the library's OWN copy of the grid, counted by the call before and not emitted yet
+	// (size_of_isosurface and then calculate_isosurface of the value it asked about: what a viewer does to show the memory a
+	// surface will take, reference MC:1892-1940 / 1816-1889): everything the count made is still there - nothing is streamed
+	// again.  Only a COUNT is reused, once: an extraction repeated with the same isovalue does all its work again, like the
+	// reference's.  Not for a caller's device buffer (mc33hip_adopt_device): its samples may have been rewritten without this
+	// library knowing.
+	if (c->counted && c->count_unused && !c->async_count && c->owns_grid && c->timing_level == 0 && same_bits((real_t)iso, c->P.iso) && same_range(*range, c->range)) {
+		c->range.id_base = range->id_base;
+		return finish_counts(c, out);
+	}
 	c->counted = false;
 	fill_params(c, iso, range);
 	if ((rc = ensure_workspaces(c))) return rc;
@@ -913,6 +924,7 @@ extern "C" int mc33hip_count(mc33hip_ctx *c, double iso, const mc33hip_range *ra
 	read_timing(c, false, launches);
 	if ((rc = finish_counts(c, out))) return rc;
 	c->counted = true;
+	c->count_unused = true;
 	return MC33HIP_OK;
 }
 

@@ -318,6 +318,53 @@ def test_size_of_isosurface_matches(products, reflibs):
         assert products["f32"].sizes(data, iso) == reflibs["f32"].sizes(data, iso)
 
 
+@pytest.mark.parametrize("devices", [None, "0,0,0"])
+def test_count_reused_for_the_same_isovalue(products, reflibs, devices, monkeypatch):
+    """size_of_isosurface and then calculate_isosurface of the same value (what a viewer does to show the memory a surface will
+    take): the extraction finds the count made and only emits - same arrays; the same value extracted twice, another value in
+    between, and a changed grid are counted anew."""
+    import ctypes as C
+    if devices:
+        monkeypatch.setenv("MC33_HIP_DEVICES", devices)
+    lib, ref = products["f32"], reflibs["f32"]
+    L = lib.lib
+    L.MC33_grid_changed.restype = None
+    L.MC33_grid_changed.argtypes = [C.POINTER(lib.MC33)]
+    a = fx.noise_quant(40, 3).copy()
+    G, keep = lib.make_grid(a)
+    M = L.create_MC33(G)
+    assert M
+    want = {iso: ref.isosurface(a, iso) for iso in (0.0, 1.0)}
+    try:
+        def sizes(iso):
+            nV, nT = C.c_uint(0), C.c_uint(0)
+            L.size_of_isosurface(M, C.c_float(iso), C.byref(nV), C.byref(nT))
+            return nV.value, nT.value
+
+        def surf(iso):
+            S = L.calculate_isosurface(M, C.c_float(iso))
+            assert S
+            try:
+                return lib.copy_surface(S)
+            finally:
+                L.free_surface_memory(S)
+        for iso in (0.0, 0.0, 1.0, 0.0):
+            assert sizes(iso) == (want[iso].nV, want[iso].nT)
+            assert sizes(iso) == (want[iso].nV, want[iso].nT)
+            for _ in range(2):
+                assert_surface_parity(surf(iso), want[iso], 40.0, "iso %g" % iso, bit_exact=True)
+        b = fx.noise_quant(40, 9)
+        keep[...] = b
+        L.MC33_grid_changed(M)
+        wb = ref.isosurface(b, 0.0)
+        assert sizes(0.0) == (wb.nV, wb.nT)      # (the same isovalue as the last call - but not the same grid)
+        assert_surface_parity(surf(0.0), wb, 40.0, "after the change", bit_exact=True)
+    finally:
+        L.free_MC33(M)
+        L.free_memory_grd(G)
+        del keep
+
+
 def test_repeatable_and_reusable_context(products):
     """Same MC33 object, several isovalues, run twice: outputs must be bit-identical (no race)."""
     import ctypes as C

@@ -25,4 +25,14 @@ for rep in range(6):
     t2 = time.perf_counter()
     print("calculate_isosurface: %.2f ms (%d vertices, %d triangles, %.0f MB of surface -> %.1f GB/s); free_surface_memory %.2f ms"
           % ((t1 - t0) * 1e3, s.nV, s.nT, mb, mb / 1e3 / (t1 - t0), (t2 - t1) * 1e3), flush=True)
+# What a viewer does: the size first, then the surface of the same value (the extraction reuses the count the size made).
+for rep in range(4):
+    nV, nT = C.c_uint(0), C.c_uint(0)
+    t0 = time.perf_counter()
+    lib.lib.size_of_isosurface(M, C.c_float(0.0), C.byref(nV), C.byref(nT))
+    t1 = time.perf_counter()
+    S = lib.lib.calculate_isosurface(M, C.c_float(0.0))
+    t2 = time.perf_counter()
+    lib.lib.free_surface_memory(S)
+    print("size_of_isosurface %.2f ms, then calculate_isosurface of the same value %.2f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
 lib.lib.free_MC33(M)
