@@ -5,7 +5,7 @@ budget over all five sample types, random extents (single-cell axes, many row se
 smooth and quantised noise (quantised noise makes samples equal to the isovalue common, which is where the
 degenerate-vertex rules and the slow path live), random spacings and origins.
 
-    python tools/soak.py [--seconds 300] [--seed 1] [--max-cells 600000] [--modes single,reuse,batched,slabs,inclined,sizes]
+    python tools/soak.py [--seconds 300] [--seed 1] [--max-cells 600000] [--modes single,reuse,batched,slabs,inclined,sizes,viewer]
 
 Prints one line per 25 cases and a summary; exits non-zero at the first difference (the case is printed so that it
 can be replayed with --seed / --only).
@@ -119,6 +119,42 @@ def reuse_case(P, R, data, isos, r0, d, extent, label):
     return nv
 
 
+def viewer_case(rng, P, R, data, isos, r0, d, extent, label):
+    """What the reference's viewers do on one MC33 object, in a random order: size_of_isosurface of a value, then (often) the
+    surface of that value - the product's extraction then finds the count the size made - or of another one, or the size again."""
+    import ctypes as C
+    Gp, kp = P.make_grid(data, r0, d)
+    Gr, kr = R.make_grid(data, r0, d)
+    Mp, Mr = P.lib.create_MC33(Gp), R.lib.create_MC33(Gr)
+    nv = 0
+    try:
+        for step in range(int(rng.randint(3, 9))):
+            iso = isos[rng.randint(0, len(isos))]
+            if rng.randint(0, 3) != 0:
+                a, b = [], []
+                for L_, M_, X, out in ((P.lib, Mp, P, a), (R.lib, Mr, R, b)):
+                    n1, n2 = C.c_uint(0), C.c_uint(0)
+                    sz = L_.size_of_isosurface(M_, X.real(iso), C.byref(n1), C.byref(n2))
+                    out += [n1.value, n2.value, sz]
+                assert a == b, "%s: size_of_isosurface %s vs reference %s at iso %g (step %d)" % (label, a, b, iso, step)
+                if rng.randint(0, 4) == 0:
+                    iso = isos[rng.randint(0, len(isos))]  # (the surface of ANOTHER value than the one just sized)
+            if rng.randint(0, 4) != 0:
+                Sp, Sr = P.lib.calculate_isosurface(Mp, P.real(iso)), R.lib.calculate_isosurface(Mr, R.real(iso))
+                assert bool(Sp) and bool(Sr), "%s: NULL surface at iso %g" % (label, iso)
+                got, want = P.copy_surface(Sp), R.copy_surface(Sr)
+                P.lib.free_surface_memory(Sp)
+                R.lib.free_surface_memory(Sr)
+                _, _, vb, nb = assert_surface_parity(got, want, extent, "%s, viewer order, step %d iso %g of %s" % (label, step, iso, isos))
+                assert vb and nb, "%s: not bit-identical at iso %g (step %d)" % (label, iso, step)
+                nv += got.nV
+    finally:
+        P.lib.free_MC33(Mp); R.lib.free_MC33(Mr)
+        P.lib.free_memory_grd(Gp); R.lib.free_memory_grd(Gr)
+        del kp, kr
+    return nv
+
+
 def batched_case(P, R, data, isos, r0, d, extent, label):
     """calculate_isosurfaces (extension; a helper thread downloads surface k while k+1 is extracted) against single
     calls of the reference."""
@@ -174,7 +210,7 @@ def main():
     ap.add_argument("--start", type=int, default=0, help="first case number")
     ap.add_argument("--verbose", action="store_true", help="print every case before it runs")
     ap.add_argument("--threads", type=int, default=1, help="caller threads, each running its own sequence of cases")
-    ap.add_argument("--modes", default="single", help="comma list of single,reuse,batched,slabs,inclined,sizes: what a case may do")
+    ap.add_argument("--modes", default="single", help="comma list of single,reuse,batched,slabs,inclined,sizes,viewer: what a case may do")
     args = ap.parse_args()
     faulthandler.enable()
     prod = {d: MC33Lib(product_path(d), d) for d in DTYPES}
@@ -225,6 +261,9 @@ def worker(args, prod, ref, tid):
             if mode == "reuse":
                 isos = [iso] + other_isovalues(rng, dtype, iso, int(rng.randint(2, 6)))
                 nv, vb, nb = reuse_case(prod[dtype], ref[dtype], data, isos, r0, d, extent, label), True, True
+            elif mode == "viewer":
+                isos = [iso] + other_isovalues(rng, dtype, iso, int(rng.randint(1, 3)))
+                nv, vb, nb = viewer_case(rng, prod[dtype], ref[dtype], data, isos, r0, d, extent, label), True, True
             elif mode == "batched":
                 isos = [iso] + other_isovalues(rng, dtype, iso, int(rng.randint(1, 6)))
                 nv, vb, nb = batched_case(prod[dtype], ref[dtype], data, isos, r0, d, extent, label), True, True
