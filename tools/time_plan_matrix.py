@@ -52,7 +52,10 @@ def run(rz, bpc, stagger=None):
     g.close()
 
 
-if os.environ.get("PLAN_MATRIX", "plans") == "stagger":
+if os.environ.get("PLAN_MATRIX", "plans") == "base":
+    for rep in range(4):
+        run(None, None)
+elif os.environ.get("PLAN_MATRIX", "plans") == "stagger":
     for rep in range(2):
         for st in (None, 10, 20, 30, 40, 60):
             run(None, None, st)
