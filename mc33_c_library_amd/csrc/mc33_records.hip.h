@@ -418,6 +418,18 @@ struct SweepLog {  // per wave
 	uint32_t edge_hdr[8];
 };
 
+// The same for the passes over several isovalues (MC33_SWEEP_DEFER_N, round 5): one log per wave for all its isovalue lanes, so an
+// entry carries where it goes.  Small - 12 compact planes, 12 headers, 3.8 KB per wave - because the 4-isovalue forms keep the bit
+// rows of the plane below in LDS already (32 KB per block) and the log costs them the fourth block per CU.
+constexpr uint32_t LOGN_PLANES = 12, LOGN_SLICES = 12;
+struct SweepLogN {  // per wave
+	uint32_t plane[LOGN_PLANES][64];  // compact records: dword r = row r
+	uint64_t plane_dst[LOGN_PLANES];  // the record's place in its lane's slice_compact ...
+	uint64_t fmt_dst[LOGN_PLANES];    // ... and its byte in plane_fmt
+	uint32_t hdr[LOGN_SLICES][10];    // the ten words of a SliceHeader
+	uint64_t hdr_dst[LOGN_SLICES];
+};
+
 // (slot: of the slice; slot_up: of the slice above = the slot of the upper plane; write_prev / write_cur: the
 // plane has not been written by this wave yet)
 template <int S>

@@ -37,6 +37,9 @@
 #ifndef MC33_SWEEP_DEFER
 #define MC33_SWEEP_DEFER 1  // (0: developer A/B - every store of the sweep where its data is made, as until round 4)
 #endif
+#ifndef MC33_SWEEP_DEFER_N
+#define MC33_SWEEP_DEFER_N 0  // (1: the hand-over of the passes over several isovalues through a log in LDS too - SweepLogN; round 5, measured, off)
+#endif
 #ifndef MC33_EDGE_LAST_COMPACT
 #define MC33_EDGE_LAST_COMPACT 1
 #endif
@@ -139,6 +142,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 	constexpr bool DEFER = NI == 1 && MC33_SWEEP_DEFER;   // the hand-over goes through the wave's log in LDS (SweepLog)
 	__shared__ typename std::conditional<DEFER, SweepLog, uint32_t>::type s_log[DEFER ? 4 : 1];
 	uint32_t log_np = 0, log_ns = 0, log_edge = LOG_NONE;  // planes / slices in the log; the format of the pending first edge record (wave-uniform)
+	constexpr bool DEFER_N = NI >= 2 && MC33_SWEEP_DEFER_N;
+	__shared__ typename std::conditional<DEFER_N, SweepLogN, uint32_t>::type s_logn[DEFER_N ? 4 : 1];
+	uint32_t logn_np = 0, logn_ns = 0;
+#if defined(MC33_DEV) && defined(MC33_SWEEP_LDS_PAD)  // (developer A/B: the LDS of a log without the log - what the lost block per CU costs by itself)
+	__shared__ uint32_t s_pad[NI >= 4 ? MC33_SWEEP_LDS_PAD / 4 : 1];
+	if (a.ntiles == 0xFFFFFFFFu) s_pad[threadIdx.x & 0u] = 1u;
+#endif
 	uint32_t pend_chunk[NI];            // (NI >= 2) partial sums not yet added to memory: their chunk of slots ...
 	unsigned long long pend_sum[NI];    // ... batches << 32 | cells (wave-uniform)
 #pragma unroll
@@ -317,6 +327,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 				G.hdr_slot[log_ns] = slot;
 			}
 			log_ns++;
+		}
+	};
+	// ---- the same for the passes over several isovalues (DEFER_N; see SweepLogN) ----
+	auto logn_flush = [&](bool at_end = false) __attribute__((always_inline)) {
+		if constexpr (DEFER_N) {
+#if defined(MC33_DEV) && defined(MC33_LOGN_DROP)  // (developer timing experiment: a log that is full is dropped, only the tile's end writes - results wrong)
+			if (!at_end) { logn_np = 0; logn_ns = 0; return; }
+#endif
+			SweepLogN &G = s_logn[wv];
+			const uint32_t ln = fresh_lane();
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			for (uint32_t k = 0; k < logn_np; k++) {  // wave-uniform
+				const uint64_t dst = readlane64(G.plane_dst[k], 0), fdst = readlane64(G.fmt_dst[k], 0);
+				__builtin_amdgcn_raw_buffer_store_b32(G.plane[k][ln], record_rsrc((const void *)dst, 256u), ln * 4u, 0u, 0);
+				if (ln == 0) *(uint8_t *)fdst = (uint8_t)PLANE_COMPACT;
+			}
+			if (ln < logn_ns) {
+				const uint32_t *w = G.hdr[ln];
+				uint32_t *h = (uint32_t *)G.hdr_dst[ln];
+				*(uint4 *)h = uint4{w[0], w[1], w[2], w[3]};
+				*(uint4 *)(h + 4) = uint4{w[4], w[5], w[6], w[7]};
+				*(uint2 *)(h + 8) = uint2{w[8], w[9]};
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the log is written again)
+			logn_np = 0; logn_ns = 0;
+		}
+	};
+	auto logn_plane = [&](const SweepLane &L, uint64_t slot, const uint64_t (&w)[4], uint32_t ln) __attribute__((always_inline)) {
+		if constexpr (DEFER_N) {
+			uint32_t desc;
+			if (encode_plane<S>(w, desc)) {  // (wave-uniform)
+				if (logn_np == LOGN_PLANES) logn_flush();
+				SweepLogN &G = s_logn[wv];
+				G.plane[logn_np][ln] = desc;
+				if (ln == 0) { G.plane_dst[logn_np] = (uint64_t)(L.slice_compact + slot * 64u); G.fmt_dst[logn_np] = (uint64_t)(L.plane_fmt + slot); }
+				logn_np++;
+			} else {
+				store_plane_raw<S>(L.slice_bits + slot * 128u, w, ln);
+				if (ln == 0) L.plane_fmt[slot] = (uint8_t)PLANE_RAW;
+			}
+		}
+	};
+	// (the partial sums per chunk of slots as in hand_over_slice: one atomic when the wave's slices leave a chunk)
+	auto logn_header = [&](const SweepLane &L, uint64_t slot, uint64_t bp, uint64_t bc, uint64_t zrows, uint64_t zcols, const uint64_t (&act)[4], uint32_t ln,
+	                       uint32_t &pchunk, unsigned long long &psum) __attribute__((always_inline)) {
+		if constexpr (DEFER_N) {
+			uint32_t ncell = __popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3]);
+#pragma unroll
+			for (int dlt = 32; dlt; dlt >>= 1) ncell += __shfl_xor(ncell, dlt);
+			if (logn_ns == LOGN_SLICES) logn_flush();
+			if (ln == 0) {
+				SweepLogN &G = s_logn[wv];
+				uint32_t *w = G.hdr[logn_ns];
+				w[0] = L.epoch << 2 | SLICE_VALID | (zrows ? SLICE_HAS_ISO : 0u);
+				w[1] = (uint32_t)bp; w[2] = (uint32_t)(bp >> 32); w[3] = (uint32_t)bc; w[4] = (uint32_t)(bc >> 32); w[5] = ncell;
+				w[6] = (uint32_t)zrows; w[7] = (uint32_t)(zrows >> 32); w[8] = (uint32_t)zcols; w[9] = (uint32_t)(zcols >> 32);
+				G.hdr_dst[logn_ns] = (uint64_t)(L.slice_hdr + slot);
+			}
+			logn_ns++;
+			const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(slot / SLOT_CHUNK));
+			const uint32_t nc = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncell);
+			if (pchunk != chunk) {
+				if (psum && ln == 0) atomicAdd(L.slot_part + pchunk, psum);
+				pchunk = chunk; psum = 0ull;
+			}
+			psum += (unsigned long long)((nc + 63u) >> 6) << 32 | nc;
 		}
 	};
 	real_t halo = 0;  // lane r: halo sample of row r of the plane being assembled
@@ -541,6 +617,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 							if (!prev_written[q]) log_plane(slot, pq, lp);
 							log_plane(slot_up, cur[q], lp);
 							log_header(slot, __ballot(ph != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act, lp);
+						} else if (DEFER_N && !MC33_DEBUG_BITS(a)) {
+							const uint64_t slot = slice_slot(p - 1 - P.zs, yt, seg, a.sd), slot_up = slice_slot(p - P.zs, yt, seg, a.sd);
+							if (!prev_written[q]) logn_plane(L, slot, pq, lp);
+							logn_plane(L, slot_up, cur[q], lp);
+							logn_header(L, slot, __ballot(ph != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act, lp, pend_chunk[q], pend_sum[q]);
 						} else
 						hand_over_slice<S>(L, slice_slot(p - 1 - P.zs, yt, seg, a.sd), slice_slot(p - P.zs, yt, seg, a.sd), pq, cur[q],
 						                   !prev_written[q], true, __ballot(ph != 0), __ballot(cur_h[q] != 0), pz | cur_z[q], pzc | cur_zc[q], act, lp,
@@ -614,6 +695,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 		if (t + 1 < T) { process(dB, hB, pp, pb); MC33_ADV(pp, pb); }
 	}
 	log_flush();  // (DEFER: everything the tile hands on, behind its last load)
+	logn_flush(true);
 	if constexpr (NI >= 2) {
 #pragma unroll
 		for (int q = 0; q < NI; q++)
